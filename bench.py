@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Throughput of the Chebyshev graph-CNN training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward + loss + backward + (RCCL gradient all-reduce) + TF-form Adam on one batch
+of synthetic fMRI windows, inputs resident in HBM.  Workload = BASELINE.json configs[1]:
+ChebNet K=5, 6 conv layers (F=32, no pooling, per-vertex biases), FC 512-256-22, the seeded
+synthetic N=10000 kNN graph (M=10466 after one coarsening level), block_dura=15, batch 64
+per GPU (weak scaling; configs[2] is the same at 8 GPUs).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = 'fMRI-windows/sec (fwd+bwd) 6-layer ChebNet K=5 N≈10k; HBM GB/s vs roofline'
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def load_graph(n_nodes, levels, rank, world, barrier):
+    """Seeded synthetic brain graph; built once per node, cached in /tmp."""
+    import scipy.sparse as sp
+    path = '/tmp/chebgcn_bench_graph_n%d_l%d.npz' % (n_nodes, levels)
+    if rank == 0 and not os.path.exists(path):
+        from gcn_fmri_decoding_amd import graph
+        Ls, perm, _ = graph.synthetic_graph(n_nodes, k=8, levels=levels)
+        fields = {'perm': np.asarray(perm, np.int32), 'nl': np.int64(len(Ls))}
+        for i, L in enumerate(Ls):
+            L = sp.csr_matrix(L)
+            fields.update({'p%d' % i: L.indptr, 'i%d' % i: L.indices, 'd%d' % i: L.data, 's%d' % i: np.array(L.shape)})
+        np.savez(path + '.tmp.npz', **fields)
+        os.replace(path + '.tmp.npz', path)
+    if world > 1:
+        barrier()
+    z = np.load(path)
+    Ls = [sp.csr_matrix((z['d%d' % i], z['i%d' % i], z['p%d' % i]), shape=tuple(z['s%d' % i])) for i in range(int(z['nl']))]
+    return Ls, z['perm']
+
+
+def cpu_baseline(Ls, cfg, n_windows, seed=0):
+    """The oracle (NumPy/SciPy restatement of the reference's algorithm) timed on the host:
+    forward + loss + backward + Adam for ``n_windows`` windows of the same workload."""
+    from oracle import layers_ref as R
+    try:
+        import threadpoolctl
+        threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    net = R.Net(Ls, cfg['F'], cfg['K'], cfg['p'], cfg['M'], channel=cfg['channel'], brelu='b2relu', regularization=5e-4)
+    rs = np.random.RandomState(seed)
+    params = {}
+    for k, s in net.param_shapes().items():
+        params[k] = (np.full(s, 0.2, np.float32) if k.endswith('bias')
+                     else (rs.randn(*s) * np.sqrt(2.0 / s[0])).astype(np.float32))
+    x = rs.randn(n_windows, Ls[0].shape[0], cfg['channel']).astype(np.float32)
+    labels = rs.randint(0, 21, n_windows)
+    t0 = time.time()
+    logits, cache = net.forward(params, x)
+    loss, dlogits = net.loss(params, logits, labels)
+    grads = net.backward(params, cache, dlogits)
+    R.adam_tf_step(params, grads, {})
+    dt = time.time() - t0
+    return {'value': n_windows / dt, 'unit': 'windows/s', 'cores': int(threads), 'kind': 'port',
+            'sample': '%d windows, full 6-layer fwd+loss+bwd+Adam, NumPy/SciPy oracle (SciPy SpMM is single-threaded, '
+                      'BLAS uses %d threads), %.1f s' % (n_windows, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='windows per GPU')
+    ap.add_argument('--nodes', type=int, default=10000)
+    ap.add_argument('--korder', type=int, default=5)
+    ap.add_argument('--block-dura', type=int, default=15)
+    ap.add_argument('--cpu-windows', type=int, default=16, help='0 disables the CPU baseline leg')
+    ap.add_argument('--no-timers', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs torch.distributed.run with %d processes' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    from gcn_fmri_decoding_amd import models_gcn, ops
+    from gcn_fmri_decoding_amd import dist as gdist
+
+    Ls, perm = load_graph(args.nodes, 1, rank, world, barrier)
+    cfg = dict(F=[32] * 6, K=[args.korder] * 6, p=[1] * 6, M=[512, 256, 22], channel=args.block_dura)
+    torch.manual_seed(0)
+    net = models_gcn.cgcnn({'device': dev}, Ls[:1], cfg['F'], cfg['K'], cfg['p'], cfg['M'], filter='chebyshev5',
+                           brelu='b2relu', pool='mpool1', initial='he', channel=cfg['channel'], regularization=5e-4,
+                           dropout=0.5, batch_size=args.batch, learning_rate=0.001, decay_rate=0.9, momentum=0.9,
+                           verbose=False)
+    if world > 1:
+        gdist.DataParallel(net)
+
+    # synthetic dataset resident in HBM: [S, N, block_dura] z-scored signals, uniform labels
+    S = 4 * args.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    data = torch.randn((S, args.nodes, args.block_dura), generator=g, device=dev)
+    labels = torch.randint(0, 21, (S,), generator=g, device=dev)
+    perm_dev = torch.as_tensor(perm.astype(np.int32)).to(dev)
+    order = torch.stack([torch.randperm(S, generator=g, device=dev)[:args.batch].to(torch.int32)
+                         for _ in range(args.steps + args.warmup)])
+
+    def step(i):
+        idx = order[i]
+        x = ops.perm_data(data, perm_dev, idx)          # perm_data_3d + batch gather, on device
+        return net.train_step(x, labels[idx.long()])
+
+    for i in range(args.warmup):
+        step(i)
+    if not args.no_timers:
+        ops.timers = ops.KernelTimers()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        _, loss = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern = ops.timers.summary() if ops.timers is not None else {}
+    ops.timers = None
+    loss = float(loss)
+
+    if rank == 0:
+        global_batch = args.batch * world
+        line = {
+            'metric': METRIC, 'value': global_batch * args.steps / dt, 'unit': 'windows/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: ChebNet K=%d x6 conv (F=32, p=1, b2relu), FC 512-256-22, '
+                                   'synthetic N=%d kNN-8 graph -> M=%d, block_dura=%d, batch %d per GPU'
+                                   % (args.korder, args.nodes, Ls[0].shape[0], args.block_dura, args.batch),
+                       'global_batch': global_batch, 'parallelism': 'dp%d' % world,
+                       'step': 'fwd+loss+bwd+allreduce+Adam, batch gathered on device'},
+            'final_loss': loss,
+        }
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]['total_ms'])
+            d = kern[dom]
+            achieved = d['bytes'] / (d['total_ms'] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(dom)
+            line['roofline'] = {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                                'avg_launch_ms': d['avg_ms'], 'launches': d['launches'],
+                                'algorithmic_bytes_per_launch': d['bytes'] / d['launches']}
+            line['kernels'] = {k: {'avg_ms': v['avg_ms'], 'launches': v['launches'],
+                                   'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
+                                   'TFLOPs': v['flops'] / (v['total_ms'] * 1e-3) / 1e12,
+                                   'share_of_step': v['total_ms'] / (1e3 * dt)} for k, v in kern.items()}
+        if world == 1 and args.cpu_windows > 0:
+            line['cpu_baseline'] = cpu_baseline(Ls[:1], cfg, args.cpu_windows)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

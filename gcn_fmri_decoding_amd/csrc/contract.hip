@@ -1,0 +1,512 @@
+// Dense contraction of the Chebyshev stack with the learned filter bank on the gfx950
+// matrix cores, fused with bias + ReLU + graph pooling, and its two gradients.
+//
+//   forward (lib_new/models_gcn.py:611-617 + :619-648):
+//       y[b][o][m] = act( sum_{fin,k} W[fin*K+k][o] * stack[k][b][fin][m] + bias ) -> pool over m
+//   bwd_x:  gstack[k][b][fin][m] = sum_o W[fin*K+k][o] * dy[b][o][m]
+//   bwd_w:  dW[fin*K+k][o]       = sum_{b,m} stack[k][b][fin][m] * dy[b][o][m]
+//
+// All three are f32-in / f32-accumulate MFMA (v_mfma_f32_32x32x2_f32: exact fp32, an
+// fmaf chain in k order), so results carry fp32 round-off only.
+//
+// Why the plane layout makes this cheap: with vertices fastest, the "N" side of the GEMM
+// (vertices) is what a wave's lanes index, so the B operand of the MFMA is loaded
+// straight from HBM with 16-byte per-lane loads (half-wave = 512 contiguous bytes of one
+// plane) -- no LDS staging, no transpose of the [K,M,Fin,N] stack that the reference
+// performs (models_gcn.py:612).  A wave owns 128 consecutive vertices: lane c of each
+// half-wave holds vertices 4c..4c+3 in the four components of its float4, and component
+// r feeds accumulator r (vertex <-> MFMA column is a free permutation).  The A operand
+// (a 32 x 2 sliver of W) is 8 B per lane from L1/L2.
+#include "common.h"
+
+namespace chebgcn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// streaming (non-temporal) 16-byte load: the stack / gradient planes are read once
+__device__ __forceinline__ float4 ld_stream(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of accumulator register j for a lane in half h (32x32 C/D layout)
+__device__ __forceinline__ int acc_row(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+
+// --------------------------------------------------------------------------------------
+// forward
+// --------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* stack; const float* W; const float* bias; float* out; uint8_t* argmax;
+    int B, M, Mp, Fin, K, Fout, FinK;
+    int pool, pool_kind, relu, bias_kind;
+    int Mo, Mpo;
+    size_t slab;                 // B*Fin*Mp
+};
+
+constexpr int FWD_UNROLL = 8;
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+contract_fwd_kernel(FwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int fo0 = blockIdx.z * (32 * NT);
+    const int m0 = (blockIdx.x * 4 + wave) * 128;
+    if (m0 >= a.M) return;
+    const int n0 = m0 + 4 * c;
+    const bool valid = n0 < a.Mp;
+
+    f32x16 acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][r][j] = 0.f;
+
+    const float* base = a.stack + (size_t)b * a.Fin * a.Mp + (valid ? n0 : 0);
+    const int npairs = (a.FinK + 1) >> 1;
+    // this lane's reduction index kk = 2*i + h, tracked as (fin, k)
+    int fin = h / a.K, k = h % a.K;
+
+    for (int i0 = 0; i0 < npairs; i0 += FWD_UNROLL) {
+        float4 bv[FWD_UNROLL];
+        float av[FWD_UNROLL][NT];
+#pragma unroll
+        for (int u = 0; u < FWD_UNROLL; ++u) {
+            const int kk = 2 * (i0 + u) + h;
+            const bool live = kk < a.FinK;
+            // dead iterations re-read the last plane (finite data) against a zero weight
+            const int fc = live ? fin : a.Fin - 1, kc = live ? k : a.K - 1;
+            const float* p = base + (size_t)kc * a.slab + (size_t)fc * a.Mp;
+            bv[u] = valid ? ld_stream(p)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int fo = fo0 + 32 * t + c;
+                av[u][t] = (live && fo < a.Fout) ? a.W[(size_t)kk * a.Fout + fo] : 0.f;
+            }
+            k += 2;
+            if (k >= a.K) { k -= a.K; ++fin; }
+            if (k >= a.K) { k -= a.K; ++fin; }
+        }
+#pragma unroll
+        for (int u = 0; u < FWD_UNROLL; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t][0] = mfma(av[u][t], bv[u].x, acc[t][0]);
+                acc[t][1] = mfma(av[u][t], bv[u].y, acc[t][1]);
+                acc[t][2] = mfma(av[u][t], bv[u].z, acc[t][2]);
+                acc[t][3] = mfma(av[u][t], bv[u].w, acc[t][3]);
+            }
+    }
+
+    // ---- epilogue: bias, relu, pool, store ----------------------------------------------
+    const int p = a.pool;
+    const int lanes_per_win = p > 4 ? (p >> 2) : 1;     // lanes sharing one pooling window
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int fo = fo0 + 32 * t + acc_row(j, h);
+            const bool fo_ok = fo < a.Fout;
+            float v[4] = {acc[t][0][j], acc[t][1][j], acc[t][2][j], acc[t][3][j]};
+            if (a.bias_kind == CHEBGCN_BIAS_FILTER) {
+                const float bb = fo_ok ? a.bias[fo] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bb;
+            } else if (a.bias_kind == CHEBGCN_BIAS_VERTEX) {
+                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fo_ok && valid) bb = *reinterpret_cast<const float4*>(a.bias + (size_t)fo * a.Mp + n0);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            float* orow = a.out + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo;
+            uint8_t* arow = a.argmax ? a.argmax + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo : nullptr;
+            if (p == 1) {
+                if (fo_ok && valid) *reinterpret_cast<float4*>(orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (a.pool_kind == CHEBGCN_POOL_MAX) {
+                if (p == 2) {
+                    const int no = n0 >> 1;
+                    if (fo_ok && no < a.Mpo) {
+                        const bool s0 = v[1] > v[0], s1 = v[3] > v[2];
+                        *reinterpret_cast<float2*>(orow + no) = make_float2(s0 ? v[1] : v[0], s1 ? v[3] : v[2]);
+                        if (arow) *reinterpret_cast<uchar2*>(arow + no) = make_uchar2(s0 ? 1 : 0, s1 ? 1 : 0);
+                    }
+                } else {
+                    float m = v[0];
+                    int idx = 0;
+#pragma unroll
+                    for (int r = 1; r < 4; ++r)
+                        if (v[r] > m) { m = v[r]; idx = r; }
+                    idx += 4 * (c & (lanes_per_win - 1));
+                    for (int d = 1; d < lanes_per_win; d <<= 1) {
+                        const float om = __shfl_xor(m, d);
+                        const int oi = __shfl_xor(idx, d);
+                        if (om > m || (om == m && oi < idx)) { m = om; idx = oi; }
+                    }
+                    const int no = n0 / p;
+                    if (fo_ok && (c & (lanes_per_win - 1)) == 0 && no < a.Mpo) {
+                        orow[no] = m;
+                        if (arow) arow[no] = (uint8_t)idx;
+                    }
+                }
+            } else {
+                // average pooling; the argmax buffer receives the ReLU mask of the window
+                // (bit i set <=> element i of the window is > 0), which is all the
+                // gradient needs (pool <= 8)
+                const int mask = (v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0);
+                if (p == 2) {
+                    const int no = n0 >> 1;
+                    if (fo_ok && no < a.Mpo) {
+                        *reinterpret_cast<float2*>(orow + no) = make_float2(0.5f * (v[0] + v[1]), 0.5f * (v[2] + v[3]));
+                        if (arow) *reinterpret_cast<uchar2*>(arow + no) = make_uchar2(mask & 3, mask >> 2);
+                    }
+                } else {
+                    float s = (v[0] + v[1]) + (v[2] + v[3]);
+                    int mk = mask << (4 * (c & (lanes_per_win - 1) & 1));
+                    for (int d = 1; d < lanes_per_win; d <<= 1) {
+                        s += __shfl_xor(s, d);
+                        mk |= __shfl_xor(mk, d);
+                    }
+                    const int no = n0 / p;
+                    if (fo_ok && (c & (lanes_per_win - 1)) == 0 && no < a.Mpo) {
+                        orow[no] = s / (float)p;
+                        if (arow) arow[no] = (uint8_t)mk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// bwd_x:  D[kk][m] = sum_o W[kk][o] dy[o][m]
+// --------------------------------------------------------------------------------------
+struct BwdXArgs {
+    const float* dy; const float* W; float* gstack;
+    int B, M, Mp, Fin, K, Fout, FinK;
+    size_t slab;
+};
+
+// HOLD: dy tile (Fout <= 32 -> 16 float4 per lane) stays in registers across the row tiles.
+template <bool HOLD>
+__global__ void __launch_bounds__(256)
+contract_bwd_x_kernel(BwdXArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int m0 = (blockIdx.x * 4 + wave) * 128;
+    if (m0 >= a.M) return;
+    const int n0 = m0 + 4 * c;
+    const bool valid = n0 < a.Mp;
+    const float* dyb = a.dy + (size_t)b * a.Fout * a.Mp + (valid ? n0 : 0);
+    const int nfo2 = (a.Fout + 1) >> 1;
+    const int ntiles = (a.FinK + 31) >> 5;
+
+    float4 hold[HOLD ? 16 : 1];
+    if (HOLD) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int fo = 2 * j + h;
+            hold[j] = (valid && fo < a.Fout) ? ld_stream(dyb + (size_t)fo * a.Mp)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    for (int t = 0; t < ntiles; ++t) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+        const int kkA = t * 32 + c;                       // A row handled by this lane
+        const float* wrow = a.W + (size_t)(kkA < a.FinK ? kkA : 0) * a.Fout;
+        if (HOLD) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int fo = 2 * j + h;
+                const float av = (kkA < a.FinK && fo < a.Fout) ? wrow[fo] : 0.f;
+                acc[0] = mfma(av, hold[j].x, acc[0]);
+                acc[1] = mfma(av, hold[j].y, acc[1]);
+                acc[2] = mfma(av, hold[j].z, acc[2]);
+                acc[3] = mfma(av, hold[j].w, acc[3]);
+            }
+        } else {
+            for (int j = 0; j < nfo2; ++j) {
+                const int fo = 2 * j + h;
+                const bool live = fo < a.Fout;
+                const float av = (kkA < a.FinK && live) ? wrow[fo] : 0.f;
+                const float4 bv = valid ? *reinterpret_cast<const float4*>(dyb + (size_t)(live ? fo : 0) * a.Mp)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc[0] = mfma(av, bv.x, acc[0]);
+                acc[1] = mfma(av, bv.y, acc[1]);
+                acc[2] = mfma(av, bv.z, acc[2]);
+                acc[3] = mfma(av, bv.w, acc[3]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int kk = t * 32 + acc_row(j, h);
+            if (kk < a.FinK && valid) {
+                const int fin = kk / a.K, k = kk - fin * a.K;
+                float* dst = a.gstack + (size_t)k * a.slab + ((size_t)b * a.Fin + fin) * a.Mp + n0;
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[0][j], acc[1][j], acc[2][j], acc[3][j]);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// bwd_w:  D[kk][o] = sum_{b,m} stack[kk][b,m] dy[o][b,m]
+// Both operands are read along their planes: lane (i, h) owns plane i of its tile and
+// pulls 16-byte pieces at vertex m0 + 8q + 4h; the pairing of vertices inside one MFMA
+// is irrelevant for a reduction.  A wave accumulates RT row tiles x 1 column tile over a
+// strided set of (window, 64-vertex) chunks; the four waves of a workgroup are reduced
+// through LDS and every workgroup leaves one partial; reduce_partials sums them in a
+// fixed order (deterministic).
+// --------------------------------------------------------------------------------------
+struct BwdWArgs {
+    const float* stack; const float* dy; float* partial;
+    int B, M, Mp, Fin, K, Fout, FinK;
+    int nchunks_m;               // ceil(M / 64)
+    int ntiles;                  // ceil(FinK / 32)
+    size_t slab;
+};
+
+constexpr int BW_Q = 8;          // float4 pieces per lane per chunk (64 vertices)
+
+template <int RT>
+__global__ void __launch_bounds__(256)
+contract_bwd_w_kernel(BwdWArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][RT*16*64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int tile0 = blockIdx.y * RT;                  // first row tile of this group
+    const int fo0 = blockIdx.z * 32;                    // column tile
+    const int fo = fo0 + c;
+    const bool fo_ok = fo < a.Fout;
+
+    f32x16 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+    // plane offsets of the RT A rows owned by this lane (row = tile*32 + c)
+    size_t aoff[RT];
+    bool a_ok[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int kk = (tile0 + t) * 32 + c;
+        a_ok[t] = kk < a.FinK;
+        const int kc = a_ok[t] ? kk : 0;
+        const int fin = kc / a.K, k = kc - fin * a.K;
+        aoff[t] = (size_t)k * a.slab + (size_t)fin * a.Mp;
+    }
+
+    const int total = a.B * a.nchunks_m;
+    const int nwaves_total = gridDim.x * 4;
+    for (int ch = blockIdx.x * 4 + wave; ch < total; ch += nwaves_total) {
+        const int b = ch / a.nchunks_m;
+        const int m0 = (ch - b * a.nchunks_m) * 64;
+        const int nb = m0 + 4 * h;                     // + 8q
+        const float* dyp = a.dy + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mp;
+        float4 bv[BW_Q];
+#pragma unroll
+        for (int q = 0; q < BW_Q; ++q) {
+            const int n = nb + 8 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fo_ok && n < a.Mp) v = ld_stream(dyp + n);
+            v.x = (n + 0 < a.M) ? v.x : 0.f;
+            v.y = (n + 1 < a.M) ? v.y : 0.f;
+            v.z = (n + 2 < a.M) ? v.z : 0.f;
+            v.w = (n + 3 < a.M) ? v.w : 0.f;
+            bv[q] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const float* ap = a.stack + aoff[t] + (size_t)b * a.Fin * a.Mp;
+            float4 av[BW_Q];
+#pragma unroll
+            for (int q = 0; q < BW_Q; ++q) {
+                const int n = nb + 8 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_ok[t] && n < a.Mp) v = ld_stream(ap + n);
+                v.x = (n + 0 < a.M) ? v.x : 0.f;
+                v.y = (n + 1 < a.M) ? v.y : 0.f;
+                v.z = (n + 2 < a.M) ? v.z : 0.f;
+                v.w = (n + 3 < a.M) ? v.w : 0.f;
+                av[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < BW_Q; ++q) {
+                acc[t] = mfma(av[q].x, bv[q].x, acc[t]);
+                acc[t] = mfma(av[q].y, bv[q].y, acc[t]);
+                acc[t] = mfma(av[q].z, bv[q].z, acc[t]);
+                acc[t] = mfma(av[q].w, bv[q].w, acc[t]);
+            }
+        }
+    }
+
+    // ---- workgroup reduction (fixed order: wave 0 + 1 + 2 + 3) ----------------------------
+    float* mine = red + (size_t)wave * (RT * 16 * 64);
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mine[(t * 16 + j) * 64 + lane] = acc[t][j];
+    __syncthreads();
+    const int per = RT * 16 * 64;
+    float* dst = a.partial + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * per;
+    for (int o = threadIdx.x; o < per; o += 256)
+        dst[o] = ((red[o] + red[per + o]) + red[2 * per + o]) + red[3 * per + o];
+}
+
+// partial: [Z][Y][X][RT*16*64] raw accumulator images -> dW[kk][o]
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dW, int nx, int ny,
+                       int rt, int FinK, int Fout) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int per = rt * 16 * 64;
+    const int row = blockIdx.x;                          // (t*16 + j) within the group image
+    const int y = blockIdx.y, z = blockIdx.z;
+    const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
+    float s = 0.f;
+    for (int x = part; x < nx; x += 4) s += base[(size_t)x * per];
+    red[part][lane] = s;
+    __syncthreads();
+    if (part == 0) {
+        s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        const int t = row >> 4, j = row & 15, h = lane >> 5;
+        const int kk = (y * rt + t) * 32 + acc_row(j, h);
+        const int fo = z * 32 + (lane & 31);
+        if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = s;
+    }
+}
+
+static int bw_rt(int ntiles) { return ntiles < 5 ? ntiles : 5; }
+static int bw_grid_x(int B, int M) {
+    static int cus = 0;                       // cached: hipGetDeviceProperties is slow
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                  ? prop.multiProcessorCount : 256;
+    }
+    int total = B * ((M + 63) / 64);
+    int gx = cus * 2;
+    if (gx * 4 > total) gx = (total + 3) / 4;
+    return gx < 1 ? 1 : gx;
+}
+
+}  // namespace chebgcn
+
+using namespace chebgcn;
+
+static int check_pool(int pool, int M) {
+    if (pool < 1 || pool > 128 || (pool & (pool - 1)) != 0 || (M % pool) != 0) return 0;
+    return 1;
+}
+
+extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const float* bias, int bias_kind,
+                                    float* out, uint8_t* argmax, int B, int M, int Fin, int K, int Fout,
+                                    int pool, int pool_kind, int relu, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(stack && W && out, "contract_fwd: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_fwd: bad shape");
+    CG_REQUIRE(B <= 65535, "contract_fwd: B > 65535");
+    CG_REQUIRE(check_pool(pool, M), "contract_fwd: pool=%d must be a power of two <= 128 dividing M=%d", pool, M);
+    CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || bias, "contract_fwd: bias_kind set but bias is NULL");
+    CG_REQUIRE(bias_kind >= 0 && bias_kind <= 2 && (pool_kind == 0 || pool_kind == 1), "contract_fwd: bad kind");
+    FwdArgs a;
+    a.stack = stack; a.W = W; a.bias = bias; a.out = out;
+    CG_REQUIRE(!(pool_kind == CHEBGCN_POOL_AVG && relu && argmax && pool > 8),
+               "contract_fwd: average pooling keeps a ReLU mask only for pool <= 8");
+    a.argmax = pool > 1 ? argmax : nullptr;
+    a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
+    a.pool = pool; a.pool_kind = pool_kind; a.relu = relu; a.bias_kind = bias_kind;
+    a.Mo = M / pool; a.Mpo = plane_stride(a.Mo);
+    a.slab = (size_t)B * Fin * a.Mp;
+    const int gx = (M + 511) / 512;
+    if (Fout > 32) {
+        dim3 grid(gx, B, (Fout + 63) / 64);
+        hipLaunchKernelGGL(contract_fwd_kernel<2>, grid, dim3(256), 0, stream, a);
+    } else {
+        dim3 grid(gx, B, 1);
+        hipLaunchKernelGGL(contract_fwd_kernel<1>, grid, dim3(256), 0, stream, a);
+    }
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_contract_bwd_x(const float* dy, const float* W, float* gstack, int B, int M,
+                                      int Fin, int K, int Fout, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(dy && W && gstack, "contract_bwd_x: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0 && B <= 65535, "contract_bwd_x: bad shape");
+    BwdXArgs a;
+    a.dy = dy; a.W = W; a.gstack = gstack;
+    a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
+    a.slab = (size_t)B * Fin * a.Mp;
+    dim3 grid((M + 511) / 512, B, 1);
+    if (Fout <= 32) hipLaunchKernelGGL(contract_bwd_x_kernel<true>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(contract_bwd_x_kernel<false>, grid, dim3(256), 0, stream, a);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K, int Fout) {
+    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
+    const int ntiles = (Fin * K + 31) / 32, rt = bw_rt(ntiles);
+    const int gy = (ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
+    return (size_t)gx * gy * gz * rt * 16 * 64 * sizeof(float);
+}
+
+extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void* workspace,
+                                      size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
+                                      chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(stack && dy && dW && workspace, "contract_bwd_w: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w: bad shape");
+    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout),
+               "contract_bwd_w: workspace too small");
+    BwdWArgs a;
+    a.stack = stack; a.dy = dy; a.partial = (float*)workspace;
+    a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
+    a.nchunks_m = (M + 63) / 64;
+    a.ntiles = (a.FinK + 31) / 32;
+    a.slab = (size_t)B * Fin * a.Mp;
+    const int rt = bw_rt(a.ntiles);
+    const int gy = (a.ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
+    dim3 grid(gx, gy, gz);
+    const size_t lds = (size_t)4 * rt * 16 * 64 * sizeof(float);
+#define CG_BW(N)                                                                                        \
+    case N:                                                                                             \
+        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_kernel<N>),             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        hipLaunchKernelGGL(contract_bwd_w_kernel<N>, grid, dim3(256), lds, stream, a);                  \
+        break
+    switch (rt) {
+        CG_BW(1); CG_BW(2); CG_BW(3); CG_BW(4); CG_BW(5);
+        default: return fail(CHEBGCN_EUNSUPPORTED, "contract_bwd_w: rt=%d", rt);
+    }
+#undef CG_BW
+    CG_HIP(hipGetLastError());
+    dim3 rgrid(rt * 16, gy, gz);
+    hipLaunchKernelGGL(reduce_partials_kernel, rgrid, dim3(256), 0, stream, (const float*)workspace, dW, gx, gy,
+                       rt, a.FinK, Fout);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}

@@ -1,0 +1,279 @@
+// HBM-bound streaming kernels around the two hot kernels: gradient of pooling/ReLU/bias,
+// input staging (perm_data_3d gather + layout change), the feature mean in front of the
+// FC head, and the Adam update.  All accesses are coalesced along the vertex axis.
+#include "common.h"
+
+namespace chebgcn {
+
+// ---- d(pool o relu o bias): MaxPoolGrad + ReluGrad + bias reductions -------------------
+// thread = one pre-pool element (f, m); loops over the batch so that the per-vertex bias
+// gradient of b2relu (models_gcn.py:625-629) is a private register sum.
+template <int BIAS>
+__global__ void __launch_bounds__(256)
+brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                      const uint8_t* __restrict__ argmax, float* __restrict__ dy,
+                      float* __restrict__ dbias, int B, int M, int Mp, int F, int pool, int pool_kind,
+                      int relu, int Mpo) {
+    __shared__ float red[4];
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const bool live = m < M;
+    const int mo = live ? m / pool : 0;
+    const int pos = m - mo * pool;
+    const float inv = 1.0f / (float)pool;
+    float sum = 0.f;
+    if (live) {
+        for (int b = 0; b < B; ++b) {
+            const size_t oi = ((size_t)b * F + f) * Mpo + mo;
+            float g = dout[oi];
+            if (pool == 1) {
+                if (relu && !(out[oi] > 0.f)) g = 0.f;
+            } else if (pool_kind == CHEBGCN_POOL_MAX) {
+                const bool sel = argmax[oi] == pos;
+                if (!sel || (relu && !(out[oi] > 0.f))) g = 0.f;
+            } else {
+                g *= inv;
+                if (relu && !((argmax[oi] >> pos) & 1)) g = 0.f;
+            }
+            dy[((size_t)b * F + f) * Mp + m] = g;
+            sum += g;
+        }
+    }
+    if (BIAS == CHEBGCN_BIAS_VERTEX) {
+        if (live) dbias[(size_t)f * Mp + m] = sum;
+    } else if (BIAS == CHEBGCN_BIAS_FILTER) {
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(dbias + f, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// ---- standalone bias + ReLU + pooling forward (b1relu / b2relu / mpool1 / apool1 called on
+// their own, lib_new/models_gcn.py:619-648); the fused form lives in contract.hip ----------
+__global__ void __launch_bounds__(256)
+brelu_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out,
+                      uint8_t* __restrict__ argmax, int M, int Mp, int F, int pool, int pool_kind, int relu,
+                      int bias_kind, int Mo, int Mpo) {
+    const int mo = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y, b = blockIdx.z;
+    if (mo >= Mpo) return;
+    const size_t oi = ((size_t)b * F + f) * Mpo + mo;
+    if (mo >= Mo) { out[oi] = 0.f; return; }
+    const float* xp = x + ((size_t)b * F + f) * Mp + (size_t)mo * pool;
+    float best = 0.f, sum = 0.f;
+    int arg = 0, mask = 0;
+    for (int i = 0; i < pool; ++i) {
+        float v = xp[i];
+        if (bias_kind == CHEBGCN_BIAS_FILTER) v += bias[f];
+        else if (bias_kind == CHEBGCN_BIAS_VERTEX) v += bias[(size_t)f * Mp + (size_t)mo * pool + i];
+        if (relu) v = fmaxf(v, 0.f);
+        if (i == 0 || v > best) { best = v; arg = i; }
+        sum += v;
+        if (v > 0.f && i < 8) mask |= 1 << i;
+    }
+    if (pool == 1 || pool_kind == CHEBGCN_POOL_MAX) {
+        out[oi] = best;
+        if (argmax && pool > 1) argmax[oi] = (uint8_t)arg;
+    } else {
+        out[oi] = sum / (float)pool;
+        if (argmax) argmax[oi] = (uint8_t)mask;
+    }
+}
+
+// ---- perm_data_3d gather into plane layout (lib_new/coarsening.py:244-265) --------------
+// block = 64 output vertices x all F features of one sample, transposed through LDS so
+// that reads run along the feature axis of x[S][N][F] and writes along the vertex axis.
+__global__ void __launch_bounds__(256)
+perm_data_kernel(const float* __restrict__ x, const int32_t* __restrict__ perm,
+                 const int32_t* __restrict__ sample, float* __restrict__ out, int N, int M, int Mp, int F) {
+    extern __shared__ float tile[];                     // [F][65]
+    const int s = blockIdx.y;
+    const int i0 = blockIdx.x * 64;
+    const size_t src = (size_t)(sample ? sample[s] : s) * N * F;
+    for (int e = threadIdx.x; e < 64 * F; e += 256) {
+        const int j = e / F, f = e - j * F;
+        const int i = i0 + j;
+        float v = 0.f;
+        if (i < M) {
+            const int node = perm ? perm[i] : i;
+            if (node < N) v = x[src + (size_t)node * F + f];
+        }
+        tile[f * 65 + j] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * F; e += 256) {
+        const int f = e >> 6, j = e & 63;
+        const int i = i0 + j;
+        if (i < Mp) out[((size_t)s * F + f) * Mp + i] = tile[f * 65 + j];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+from_plane_kernel(const float* __restrict__ xp, float* __restrict__ out, int M, int Mp, int F) {
+    extern __shared__ float tile[];                     // [F][65]
+    const int b = blockIdx.y;
+    const int i0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * F; e += 256) {
+        const int f = e >> 6, j = e & 63;
+        const int i = i0 + j;
+        tile[f * 65 + j] = (i < M) ? xp[((size_t)b * F + f) * Mp + i] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * F; e += 256) {
+        const int j = e / F, f = e - j * F;
+        const int i = i0 + j;
+        if (i < M) out[((size_t)b * M + i) * F + f] = tile[f * 65 + j];
+    }
+}
+
+// ---- tf.reduce_mean(x, -1) in front of the FC head (models_gcn.py:673) ------------------
+__global__ void __launch_bounds__(256)
+feature_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int Mp, int F) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (m >= M) return;
+    const float* p = x + (size_t)b * F * Mp + m;
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += p[(size_t)f * Mp];
+    y[(size_t)b * M + m] = s / (float)F;
+}
+
+__global__ void __launch_bounds__(256)
+feature_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int M, int Mp, int F) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (m >= Mp) return;
+    const float g = (m < M) ? dy[(size_t)b * M + m] / (float)F : 0.f;
+    float* p = dx + (size_t)b * F * Mp + m;
+    for (int f = 0; f < F; ++f) p[(size_t)f * Mp] = g;
+}
+
+// ---- Adam, TensorFlow form (epsilon outside the bias correction) ------------------------
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+            float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps, float gscale,
+            float l2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = fmaf(l2, pi, gscale * g[i]);
+        const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+        const float vi = v[i] + (1.f - b2) * (gi * gi - v[i]);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace chebgcn
+
+using namespace chebgcn;
+
+extern "C" int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bias_kind, float* out, uint8_t* argmax,
+                                      int B, int M, int F, int pool, int pool_kind, int relu,
+                                      chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(x && out, "brelu_pool_fwd: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535 && B <= 65535, "brelu_pool_fwd: bad shape");
+    CG_REQUIRE(pool >= 1 && (pool & (pool - 1)) == 0 && pool <= 128 && M % pool == 0, "brelu_pool_fwd: bad pool %d", pool);
+    CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || bias, "brelu_pool_fwd: bias is NULL");
+    CG_REQUIRE(!(pool_kind == CHEBGCN_POOL_AVG && relu && argmax && pool > 8),
+               "brelu_pool_fwd: average pooling keeps a ReLU mask only for pool <= 8");
+    const int Mp = plane_stride(M), Mo = M / pool, Mpo = plane_stride(Mo);
+    dim3 grid((Mpo + 255) / 256, F, B);
+    hipLaunchKernelGGL(brelu_pool_fwd_kernel, grid, dim3(256), 0, stream, x, bias, out, argmax, M, Mp, F, pool,
+                       pool_kind, relu, bias_kind, Mo, Mpo);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const uint8_t* argmax, float* dy,
+                                      float* dbias, int bias_kind, int B, int M, int F, int pool,
+                                      int pool_kind, int relu, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(dout && dy, "brelu_pool_bwd: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "brelu_pool_bwd: bad shape");
+    CG_REQUIRE(pool >= 1 && (pool & (pool - 1)) == 0 && pool <= 128 && M % pool == 0, "brelu_pool_bwd: bad pool %d", pool);
+    CG_REQUIRE(!relu || out, "brelu_pool_bwd: relu needs the forward output");
+    CG_REQUIRE(pool == 1 || argmax || (pool_kind == CHEBGCN_POOL_AVG && !relu), "brelu_pool_bwd: pooling needs argmax/mask");
+    CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || dbias, "brelu_pool_bwd: dbias is NULL");
+    const int Mp = plane_stride(M), Mpo = plane_stride(M / pool);
+    dim3 grid((M + 255) / 256, F);
+    if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));
+        hipLaunchKernelGGL(brelu_pool_bwd_kernel<CHEBGCN_BIAS_FILTER>, grid, dim3(256), 0, stream, dout, out, argmax, dy,
+                           dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo);
+    } else if (bias_kind == CHEBGCN_BIAS_VERTEX) {
+        hipLaunchKernelGGL(brelu_pool_bwd_kernel<CHEBGCN_BIAS_VERTEX>, grid, dim3(256), 0, stream, dout, out, argmax, dy,
+                           dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo);
+    } else {
+        hipLaunchKernelGGL(brelu_pool_bwd_kernel<CHEBGCN_BIAS_NONE>, grid, dim3(256), 0, stream, dout, out, argmax, dy,
+                           dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo);
+    }
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_perm_data(const float* x, const int32_t* perm, const int32_t* sample, float* out, int S,
+                                 int N, int M, int F, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(x && out, "perm_data: NULL argument");
+    CG_REQUIRE(S > 0 && N > 0 && M > 0 && F > 0 && S <= 65535, "perm_data: bad shape");
+    CG_REQUIRE(perm || M == N, "perm_data: identity permutation needs M == N");
+    const int Mp = plane_stride(M);
+    const size_t lds = (size_t)F * 65 * sizeof(float);
+    CG_REQUIRE(lds <= 64 * 1024, "perm_data: F=%d too large", F);
+    dim3 grid((Mp + 63) / 64, S);
+    hipLaunchKernelGGL(perm_data_kernel, grid, dim3(256), lds, stream, x, perm, sample, out, N, M, Mp, F);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_to_plane(const float* x_bmf, float* out_plane, int B, int M, int F, chebgcn_stream stream) {
+    return chebgcn_perm_data(x_bmf, nullptr, nullptr, out_plane, B, M, M, F, stream);
+}
+
+extern "C" int chebgcn_from_plane(const float* x_plane, float* out_bmf, int B, int M, int F, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(x_plane && out_bmf, "from_plane: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && F > 0 && B <= 65535, "from_plane: bad shape");
+    const int Mp = plane_stride(M);
+    const size_t lds = (size_t)F * 65 * sizeof(float);
+    CG_REQUIRE(lds <= 64 * 1024, "from_plane: F=%d too large", F);
+    dim3 grid((M + 63) / 64, B);
+    hipLaunchKernelGGL(from_plane_kernel, grid, dim3(256), lds, stream, x_plane, out_bmf, M, Mp, F);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_feature_mean_fwd(const float* x, float* y, int B, int M, int F, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(x && y && B > 0 && M > 0 && F > 0 && B <= 65535, "feature_mean_fwd: bad argument");
+    dim3 grid((M + 255) / 256, B);
+    hipLaunchKernelGGL(feature_mean_fwd_kernel, grid, dim3(256), 0, stream, x, y, M, plane_stride(M), F);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_feature_mean_bwd(const float* dy, float* dx, int B, int M, int F, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(dy && dx && B > 0 && M > 0 && F > 0 && B <= 65535, "feature_mean_bwd: bad argument");
+    const int Mp = plane_stride(M);
+    dim3 grid((Mp + 255) / 256, B);
+    hipLaunchKernelGGL(feature_mean_bwd_kernel, grid, dim3(256), 0, stream, dy, dx, M, Mp, F);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1,
+                                 float beta2, float eps, float grad_scale, float l2, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(p && g && m && v && n >= 0, "adam_step: bad argument");
+    if (n == 0) return CHEBGCN_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, beta1, beta2,
+                       eps, grad_scale, l2);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}

@@ -1,0 +1,647 @@
+"""``cgcnn``: drop-in for ``lib_new/models_gcn.py`` of the reference (class ``cgcnn`` and
+the parts of ``base_model`` its callers use), on PyTorch-ROCm with the graph-convolution
+arithmetic in libchebgcn.so (gfx950).  Citations are to ``lib_new/models_gcn.py``.
+
+Same constructor keywords (:445-448), same string-selected layer methods
+(``filter='chebyshev5'``, ``brelu='b1relu'|'b2relu'``, ``pool='mpool1'|'apool1'``,
+:504-506), same layer signatures (``chebyshev5(x, L, Fout, K)`` on ``x[N, M, Fin]`` ->
+``[N, M, Fout]``, :587-617), same variable names and shapes (``conv{i}/weights``
+``[Fin*K, Fout]`` with row ``fin*K + k``, ``conv{i}/bias``, ``fc{i}/weights`` ...), same
+``fit`` / ``evaluate`` / ``predict`` call contract (:31-184).
+
+What is different by design: activations stay on the GPU in plane layout between layers
+(no transposes), a standard conv+bias+relu+pool layer runs as two fused kernels, the
+gradients are hand-written kernels instead of TF autodiff, parameters live in one flat
+buffer (one fused TF-form Adam launch, one RCCL all-reduce per bucket).
+"""
+import collections
+import contextlib
+import math
+import os
+import shutil
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as Fnn
+
+from . import ops
+from ._lib import BIAS_FILTER, BIAS_NONE, BIAS_VERTEX, POOL_AVG, POOL_MAX, plane_stride
+
+
+class _Spec:
+    __slots__ = ('name', 'shape', 'kind', 'regularized', 'fan_in', 'group', 'ref_shape')
+
+    def __init__(self, name, shape, kind, regularized, fan_in, group, ref_shape):
+        self.name, self.shape, self.kind, self.regularized = name, tuple(shape), kind, regularized
+        self.fan_in, self.group, self.ref_shape = fan_in, group, tuple(ref_shape)
+
+
+class base_model(object):
+    """Counterpart of ``base_model`` (:18-355): run-time interface + variable helpers."""
+
+    def __init__(self, config=None):
+        self.regularizers = []          # names of L2-regularised variables (:345, :353)
+        self.sess = None                # kept for signature compatibility; unused
+        self.config = config
+        dev = None
+        if isinstance(config, dict):
+            dev = config.get('device')
+        elif isinstance(config, (str, torch.device)):
+            dev = config
+        if dev is not None and torch.device(dev).type == 'meta':
+            pass        # shape-only model: variables are laid out, nothing can be computed
+        elif dev is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError('cgcnn needs a ROCm GPU (MI355X); no device is visible and '
+                                   'there is no CPU execution path')
+            dev = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(dev)
+        self._scope = []
+        self._specs = None              # filled during the build pass
+        self._params = {}
+        self._dp = None                 # optional data-parallel helper (dist.DataParallel)
+
+    # ---------------------------------------------------------------- run-time API
+
+    def stage(self, data):
+        """Copy a dataset ``[S, M, channel]`` (NumPy, any float dtype, or a torch tensor)
+        to the device once, as fp32 in the reference's row layout.  ``fit``/``predict``
+        accept the staged tensor directly; batches are then gathered on the GPU."""
+        if isinstance(data, torch.Tensor):
+            return data.to(self.device, torch.float32).contiguous()
+        if not isinstance(data, np.ndarray):
+            data = data.toarray()       # sparse matrices, like the reference (:42-46)
+        return torch.as_tensor(np.ascontiguousarray(data, np.float32)).to(self.device)
+
+    def _gather(self, data_dev, idx):
+        """``data[idx]`` gathered on the GPU straight into plane storage [B, channel, Mp]
+        (replaces the host gather + feed of :142-146)."""
+        S, M, C = data_dev.shape
+        out = ops.plane_empty(int(idx.numel()), C, M, self.device)
+        from . import _lib
+        _lib.check(_lib.lib().chebgcn_perm_data(ops._p(data_dev), None, ops._p(idx), ops._p(out), int(idx.numel()),
+                                                M, M, C, ops._stream()), 'perm_data')
+        return out
+
+    def predict(self, data, labels=None, sess=None):
+        """Batched prediction (:31-71).  The last batch is zero-padded to ``batch_size``
+        (inputs *and* labels) exactly like the reference, so the reported loss matches."""
+        data_dev = self.stage(data)
+        size = data_dev.shape[0]
+        predictions = np.empty(size)
+        loss = 0
+        was_training = self.training_mode
+        self.training_mode = False
+        try:
+            for begin in range(0, size, self.batch_size):
+                end = min(begin + self.batch_size, size)
+                idx = np.arange(begin, end)
+                x = self._gather(data_dev, torch.as_tensor(idx, dtype=torch.int32).to(self.device))
+                if end - begin < self.batch_size:
+                    pad = ops.plane_empty(self.batch_size, x.shape[1], data_dev.shape[1], self.device, zero=True)
+                    pad[:end - begin] = x
+                    x = pad
+                with torch.no_grad():
+                    logits = self._inference_storage(x, 1)
+                    batch_pred = self.prediction(logits)
+                    if labels is not None:
+                        batch_labels = np.zeros(self.batch_size, np.int64)
+                        batch_labels[:end - begin] = labels[begin:end]
+                        batch_loss = float(self.loss(logits, torch.as_tensor(batch_labels).to(self.device),
+                                                     self.regularization)[0])
+                        if np.isnan(batch_loss) or np.isinf(batch_loss):
+                            batch_loss = 0
+                        loss += batch_loss
+                predictions[begin:end] = batch_pred[:end - begin].cpu().numpy()
+        finally:
+            self.training_mode = was_training
+        if labels is not None:
+            return predictions, loss * self.batch_size / size
+        return predictions
+
+    def evaluate(self, data, labels, sess=None, target_name=None, isTrain=False):
+        """One evaluation pass (:73-110): (string, accuracy %, weighted F1 %, loss)."""
+        import sklearn.metrics
+        if not isTrain:
+            self._restore_latest()
+        t_process, t_wall = time.process_time(), time.time()
+        labels = np.asarray(labels)
+        predictions, loss = self.predict(data, labels, sess)
+        if target_name is not None:
+            try:
+                print(sklearn.metrics.classification_report(labels, predictions, labels=range(len(target_name)),
+                                                            target_names=target_name))
+                print('Confusion Matrix:')
+                print(sklearn.metrics.confusion_matrix(labels, predictions, labels=range(len(target_name))))
+            except Exception:
+                print('No corresponding assignment between true and predicted labels')
+        ncorrects = int(sum(predictions == labels))
+        accuracy = 100 * sklearn.metrics.accuracy_score(labels, predictions)
+        f1 = 100 * sklearn.metrics.f1_score(labels, predictions, average='weighted')
+        string = 'accuracy: {:.2f} ({:d} / {:d}), f1 (weighted): {:.2f}, loss: {:.2e}'.format(
+            accuracy, ncorrects, len(labels), f1, loss)
+        if sess is None:
+            string += '\ntime: {:.0f}s (wall {:.0f}s)'.format(time.process_time() - t_process, time.time() - t_wall)
+        return string, accuracy, f1, loss
+
+    def fit(self, train_data, train_labels, val_data, val_labels, best_checkpoint_dir=None):
+        """Mini-batch training loop (:112-184): ``int(num_epochs*S/batch)`` steps, samples
+        drawn without replacement from a shuffled deque (:137-140), evaluation on the
+        validation set every ``eval_frequency`` steps, top-3 checkpoints by validation
+        accuracy.  Returns (accuracies, losses, t_step)."""
+        t_process, t_wall = time.process_time(), time.time()
+        shutil.rmtree(self._get_path('checkpoints'), ignore_errors=True)
+        os.makedirs(self._get_path('checkpoints'), exist_ok=True)
+        self._init_variables()
+        train_dev, val_dev = self.stage(train_data), self.stage(val_data)
+        train_labels = np.asarray(train_labels)
+        labels_dev = torch.as_tensor(train_labels.astype(np.int64)).to(self.device)
+        accuracies, losses = [], []
+        best = []
+        indices = collections.deque()
+        n_train = train_dev.shape[0]
+        num_steps = int(self.num_epochs * n_train / self.batch_size)
+        print('training with {} steps in total with batch_size={} and epochs={} for training_set={}:'.format(
+            num_steps, self.batch_size, self.num_epochs, n_train))
+        for step in range(1, num_steps + 1):
+            if len(indices) < self.batch_size:
+                indices.extend(np.random.permutation(n_train))
+            idx = [indices.popleft() for _ in range(self.batch_size)]
+            idx_dev = torch.as_tensor(np.asarray(idx, np.int32)).to(self.device)
+            x = self._gather(train_dev, idx_dev)
+            learning_rate, loss_average = self.train_step(x, labels_dev[idx_dev.long()])
+            if step % self.eval_frequency == 0 or step == num_steps:
+                loss_average = float(loss_average)
+                if np.isnan(loss_average) or np.isinf(loss_average):
+                    loss_average = 0
+                epoch = step * self.batch_size / n_train
+                print('step {} / {} (epoch {:.2f} / {}):'.format(step, num_steps, epoch, self.num_epochs))
+                print('  learning_rate = {:.2e}, loss_average = {:.2e}'.format(learning_rate, loss_average))
+                string, accuracy, f1, loss = self.evaluate(val_dev, val_labels, self.sess, isTrain=True)
+                accuracies.append(accuracy)
+                losses.append(loss)
+                print('  validation {}'.format(string))
+                print('  time: {:.0f}s (wall {:.0f}s)'.format(time.process_time() - t_process, time.time() - t_wall))
+                self._save_best(accuracy, step, best)
+        print('validation accuracy: peak = {:.2f}, mean = {:.2f}'.format(max(accuracies), np.mean(accuracies[-10:])))
+        torch.cuda.synchronize(self.device)
+        t_step = (time.time() - t_wall) / num_steps
+        return accuracies, losses, t_step
+
+    def get_var(self, name):
+        """Value of a variable by its TF name, in the reference's shape (:186-191)."""
+        return self.variable(name).detach().cpu().numpy()
+
+    # ---------------------------------------------------------------- graph building
+
+    def build_graph(self, M_0, flag_input=True):
+        """Creates every variable by tracing ``_inference`` once on shape-only (meta)
+        tensors, then lays them out in one flat buffer (:195-222)."""
+        self._specs = []
+        x = torch.empty((self.batch_size,) + tuple(M_0), device='meta')
+        self._inference(x, 1.0)
+        specs, self._specs = self._specs, None
+        order = {'head': 0, 'convw': 1, 'convb': 2}
+        specs.sort(key=lambda s: order[s.group])        # stable: keeps creation order inside a group
+        self._spec_list = specs
+        sizes = [int(np.prod(s.shape)) for s in specs]
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n = int(offs[-1])
+        self._flat = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._grad = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._params, self._slices = {}, {}
+        for s, a, b in zip(specs, offs[:-1], offs[1:]):
+            p = torch.nn.Parameter(self._flat[a:b].view(s.shape))
+            p.grad = self._grad[a:b].view(s.shape)
+            self._params[s.name] = p
+            self._slices[s.name] = (int(a), int(b))
+        n_head = sum(z for s, z in zip(specs, sizes) if s.group == 'head')
+        n_reg = sum(z for s, z in zip(specs, sizes) if s.regularized)
+        if any(s.regularized for s in specs if s.group == 'convb') or not all(
+                s.regularized for s in specs if s.group != 'convb'):
+            raise AssertionError('flat layout assumes regularised variables come first')
+        self._n_head, self._n_reg, self._n_total = n_head, n_reg, n
+        self.regularizers = [s.name for s in specs if s.regularized]
+        self.global_step = 0
+        self._loss_ema = None
+        self.training_mode = False
+        self._init_variables()
+
+    def _init_variables(self):
+        """``tf.global_variables_initializer`` (:213, run at :123)."""
+        self.global_step = 0
+        self._loss_ema = None
+        if self.device.type == 'meta':
+            return
+        with torch.no_grad():
+            for s in self._spec_list:
+                p = self._params[s.name]
+                if s.kind == 'const':
+                    if len(s.shape) == 2 and s.group == 'convb':       # [F, Mp]: keep the pad at zero
+                        p.zero_()
+                        p[:, :s.ref_shape[1]] = 0.2
+                    else:
+                        p.fill_(0.2)
+                elif s.kind == 'normal':
+                    torch.nn.init.trunc_normal_(p, 0.0, 0.2, -0.4, 0.4)
+                else:   # 'he': variance_scaling_initializer(factor=2, FAN_IN, truncated normal)
+                    std = math.sqrt(1.3 * 2.0 / s.fan_in)
+                    torch.nn.init.trunc_normal_(p, 0.0, std, -2 * std, 2 * std)
+            self._adam_m.zero_()
+            self._adam_v.zero_()
+            self._grad.zero_()
+        self.global_step = 0
+        self._loss_ema = None
+
+    def variable(self, name):
+        """The variable called ``name`` in the reference's shape (a view, no copy)."""
+        p = self._params[name]
+        spec = next(s for s in self._spec_list if s.name == name)
+        if spec.group == 'convb':
+            if len(spec.shape) == 2:                               # storage [F, Mp] -> [1, M, F]
+                return p[:, :spec.ref_shape[1]].t().unsqueeze(0)
+            return p.view(spec.ref_shape)                           # [F] -> [1, 1, F]
+        return p
+
+    def set_variable(self, name, value):
+        with torch.no_grad():
+            v = torch.as_tensor(np.asarray(value, np.float32)).to(self.device)
+            self.variable(name).copy_(v.view(self.variable(name).shape))
+
+    def variables(self):
+        return [s.name for s in self._spec_list]
+
+    def inference(self, data, dropout):
+        """logits for ``data[N, M, channel]`` (device tensor, any layout) (:224-239)."""
+        return self._inference(data, dropout)
+
+    def probabilities(self, logits):
+        return torch.softmax(logits, dim=1)
+
+    def prediction(self, logits):
+        return torch.argmax(logits, dim=1)
+
+    def regularization_term(self):
+        """sum of tf.nn.l2_loss over the regularised variables (:262, :345, :353)."""
+        return 0.5 * self._flat[:self._n_reg].square().sum()
+
+    def loss(self, logits, labels, regularization):
+        """(loss, loss_average): mean softmax cross-entropy + regularization * sum l2_loss,
+        and its 0.9-EMA as reported by the reference (:253-276)."""
+        cross_entropy = Fnn.cross_entropy(logits, labels.long())
+        loss = cross_entropy + regularization * self.regularization_term()
+        return loss, loss
+
+    def training(self, loss, learning_rate, decay_steps, decay_rate=0.95, momentum=0.9):
+        """Reported learning rate of the current step (:278-313).  As in the reference the
+        decayed rate is only reported: the optimizer is Adam(0.001) whenever momentum != 0
+        (:291-296)."""
+        if decay_rate != 1 and decay_steps:
+            return learning_rate * decay_rate ** math.floor(self.global_step / decay_steps)
+        return learning_rate
+
+    def train_step(self, x_storage, labels):
+        """One optimisation step on a batch in plane storage ``[B, channel, Mp]``:
+        forward, loss, backward, (gradient all-reduce), TF-form Adam.  Returns
+        (reported learning rate, loss_average tensor)."""
+        self.training_mode = True
+        self._grad.zero_()
+        if self._dp is not None:
+            self._dp.begin_step()
+        logits = self._inference_storage(x_storage, self.dropout)
+        cross_entropy = Fnn.cross_entropy(logits, labels.long())
+        cross_entropy.backward()
+        grad_scale = 1.0
+        if self._dp is not None:
+            grad_scale = self._dp.finish_step()
+        self._apply_adam(grad_scale)
+        reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
+        self.global_step += 1
+        with torch.no_grad():
+            loss = cross_entropy.detach() + self.regularization * self.regularization_term()
+            # tf.train.ExponentialMovingAverage(0.9) over a Tensor: zero-initialised shadow,
+            # zero-debiased on read (:269-275)
+            self._loss_ema = 0.1 * loss if self._loss_ema is None else 0.9 * self._loss_ema + 0.1 * loss
+            loss_average = self._loss_ema / (1 - 0.9 ** self.global_step)
+        self.training_mode = False
+        return reported_lr, loss_average
+
+    def _apply_adam(self, grad_scale=1.0):
+        if self.momentum == 0:
+            # tf.train.GradientDescentOptimizer branch (:288-289)
+            lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
+            with torch.no_grad():
+                g = self._grad * grad_scale
+                g[:self._n_reg] += self.regularization * self._flat[:self._n_reg]
+                self._flat -= lr * g
+            return
+        t = self.global_step + 1
+        b1, b2, lr = 0.9, 0.999, 0.001
+        lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        r, n = self._n_reg, self._n_total
+        if r > 0:
+            ops.adam_step(self._flat[:r], self._grad[:r], self._adam_m[:r], self._adam_v[:r], lr_t, b1, b2, 1e-8,
+                          grad_scale, self.regularization)
+        if n > r:
+            ops.adam_step(self._flat[r:], self._grad[r:], self._adam_m[r:], self._adam_v[r:], lr_t, b1, b2, 1e-8,
+                          grad_scale, 0.0)
+
+    # ---------------------------------------------------------------- helpers
+
+    def _get_path(self, folder):
+        root = os.environ.get('CHEBGCN_HOME', os.getcwd())
+        return os.path.join(root, folder, self.dir_name)
+
+    def state_dict(self):
+        return {'flat': self._flat.detach().cpu(), 'adam_m': self._adam_m.cpu(), 'adam_v': self._adam_v.cpu(),
+                'global_step': self.global_step, 'names': self.variables()}
+
+    def load_state_dict(self, sd):
+        with torch.no_grad():
+            self._flat.copy_(sd['flat'].to(self.device))
+            self._adam_m.copy_(sd['adam_m'].to(self.device))
+            self._adam_v.copy_(sd['adam_v'].to(self.device))
+        self.global_step = int(sd['global_step'])
+
+    def _save_best(self, accuracy, step, best, num_to_keep=3):
+        """Keep the ``num_to_keep`` best checkpoints by validation accuracy
+        (checkmat.BestCheckpointSaver as used at :127, :175)."""
+        path = os.path.join(self._get_path('checkpoints'), 'model')
+        os.makedirs(path, exist_ok=True)
+        if len(best) >= num_to_keep and accuracy <= min(a for a, _ in best):
+            return
+        fname = os.path.join(path, 'best.ckpt-%d.pt' % step)
+        torch.save(self.state_dict(), fname)
+        best.append((accuracy, fname))
+        best.sort(key=lambda t: -t[0])
+        for _, old in best[num_to_keep:]:
+            if os.path.exists(old):
+                os.remove(old)
+        del best[num_to_keep:]
+        with open(os.path.join(path, 'best_checkpoints'), 'w') as f:
+            import json
+            json.dump({os.path.basename(p): a for a, p in best}, f)
+
+    def _restore_latest(self):
+        path = os.path.join(self._get_path('checkpoints'), 'model')
+        if not os.path.isdir(path):
+            return
+        files = [f for f in os.listdir(path) if f.endswith('.pt')]
+        if not files:
+            return
+        latest = max(files, key=lambda f: int(f.split('-')[-1].split('.')[0]))
+        self.load_state_dict(torch.load(os.path.join(path, latest)))
+
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        self._scope.append(name)
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def _var_name(self, leaf):
+        return '/'.join(self._scope + [leaf])
+
+    def _weight_initial(self):
+        return 'normal' if self.initial == 'normal' else 'he'
+
+    def _get_variable(self, leaf, shape, kind, regularization, group, ref_shape=None, fan_in=None):
+        name = self._var_name(leaf)
+        if self._specs is not None:                     # build pass: record and hand out a meta tensor
+            if any(s.name == name for s in self._specs):
+                raise ValueError('variable %s already exists' % name)
+            self._specs.append(_Spec(name, shape, kind, regularization, fan_in, group, ref_shape or shape))
+            return torch.empty(tuple(shape), device='meta')
+        p = self._params[name]
+        if tuple(p.shape) != tuple(shape):
+            raise ValueError('variable %s has shape %s, requested %s' % (name, tuple(p.shape), tuple(shape)))
+        return p
+
+    def _weight_variable(self, shape, regularization=True):
+        """``tf.get_variable('weights', ...)`` in the current scope (:340-347)."""
+        group = 'convw' if (self._scope and self._scope[0].startswith('conv')) else 'head'
+        return self._get_variable('weights', shape, self._weight_initial(), regularization, group,
+                                  fan_in=shape[-2] if len(shape) >= 2 else shape[0])
+
+    def _bias_variable(self, shape, regularization=True):
+        """``tf.get_variable('bias', ...)`` initialised to 0.2 (:349-355).  Conv biases are
+        stored filter-major ([F] / [F, Mp]) -- ``variable(name)`` gives the TF shape."""
+        shape = tuple(int(s) for s in shape)
+        if self._scope and self._scope[0].startswith('conv'):
+            if regularization:
+                raise ValueError('conv biases are not regularised in this layout')
+            if len(shape) == 3 and shape[0] == 1 and shape[1] == 1:
+                return self._get_variable('bias', (shape[2],), 'const', False, 'convb', ref_shape=shape)
+            if len(shape) == 3 and shape[0] == 1:
+                return self._get_variable('bias', (shape[2], plane_stride(shape[1])), 'const', False, 'convb',
+                                          ref_shape=shape)
+            raise ValueError('conv bias shape %s' % (shape,))
+        return self._get_variable('bias', shape, 'const', regularization, 'head')
+
+
+class cgcnn(base_model):
+    """Graph CNN with Chebyshev filters; see the reference's docstring (:405-444) for the
+    meaning of F, K, p, M and the training keywords."""
+
+    def __init__(self, config, L, F, K, p, M, filter='chebyshev5', brelu='b1relu', pool='mpool1', initial='normal',
+                 channel=1, num_epochs=20, learning_rate=0.1, decay_rate=0.95, decay_steps=None, momentum=0.9,
+                 regularization=0, dropout=0, batch_size=100, eval_frequency=200, dir_name='', verbose=True):
+        super().__init__(config)
+        # consistency checks of :451-460
+        if not (len(L) >= len(F) == len(K) == len(p)):
+            print(len(L))
+            print(len(F), len(K), len(p))
+        assert np.all(np.array(p) >= 1)
+        p_log2 = np.where(np.array(p) > 1, np.log2(p), 0)
+        assert np.all(np.mod(p_log2, 1) == 0)            # powers of 2
+        assert len(L) >= np.sum(p_log2)                   # enough coarsening levels
+        # one Laplacian per conv layer: the level advances by log2(p) (:462-469)
+        M_0 = L[0].shape[0]
+        j, self.L = 0, []
+        for pp in p:
+            self.L.append(L[j])
+            j += int(np.log2(pp)) if pp > 1 else 0
+        if verbose:
+            self._describe(M_0, F, K, p, M, brelu)
+        self.F, self.K, self.p, self.M = list(F), list(K), list(p), list(M)
+        self.num_epochs, self.learning_rate = num_epochs, learning_rate
+        self.decay_rate, self.decay_steps, self.momentum = decay_rate, decay_steps, momentum
+        self.regularization, self.dropout = regularization, dropout
+        self.batch_size, self.eval_frequency = batch_size, eval_frequency
+        self.dir_name = dir_name
+        self.filter = getattr(self, filter)
+        self.brelu = getattr(self, brelu)
+        self.pool = getattr(self, pool)
+        self.initial = initial
+        self.channel = channel
+        self.graphs = [ops.graph_for(Li, self.device) for Li in self.L] if self.device.type == 'cuda' else []
+        self.build_graph((M_0, channel))
+
+    def _describe(self, M_0, F, K, p, M, brelu):
+        L = self.L
+        print('NN architecture')
+        print('  input: M_0 = {}'.format(M_0))
+        for i in range(len(p)):
+            print('  layer {0}: cgconv{0}'.format(i + 1))
+            print('    representation: M_{0} * F_{1} / p_{1} = {2} * {3} / {4} = {5}'.format(
+                i, i + 1, L[i].shape[0], F[i], p[i], L[i].shape[0] * F[i] // p[i]))
+            F_last = F[i - 1] if i > 0 else 1
+            print('    weights: F_{0} * F_{1} * K_{1} = {2} * {3} * {4} = {5}'.format(
+                i, i + 1, F_last, F[i], K[i], F_last * F[i] * K[i]))
+            if brelu == 'b1relu':
+                print('    biases: F_{} = {}'.format(i + 1, F[i]))
+            elif brelu == 'b2relu':
+                print('    biases: M_{0} * F_{0} = {1} * {2} = {3}'.format(i + 1, L[i].shape[0], F[i], L[i].shape[0] * F[i]))
+        for i in range(len(M)):
+            name = 'logits (softmax)' if i == len(M) - 1 else 'fc{}'.format(i + 1)
+            print('  layer {}: {}'.format(len(p) + i + 1, name))
+            print('    representation: M_{} = {}'.format(len(p) + i + 1, M[i]))
+            M_last = M[i - 1] if i > 0 else M_0
+            print('    weights: M_{} * M_{} = {} * {} = {}'.format(len(p) + i, len(p) + i + 1, M_last, M[i], M_last * M[i]))
+            print('    biases: M_{} = {}'.format(len(p) + i + 1, M[i]))
+
+    # ------------------------------------------------------------------ layers
+
+    def _graph_of(self, L):
+        for Li, g in zip(self.L, self.graphs):
+            if Li is L:
+                return g
+        return ops.graph_for(L, self.device)
+
+    def chebyshev5(self, x, L, Fout, K):
+        """Chebyshev filtering of x[N, M, Fin] with a [Fin*K, Fout] filter bank (:587-617)."""
+        N, M, Fin = x.shape
+        W = self._weight_variable([int(Fin) * K, int(Fout)], regularization=True)
+        if x.is_meta:
+            return torch.empty((N, M, int(Fout)), device='meta')
+        y = ops.cheb_conv(ops.plane_storage(x), W, None, self._graph_of(L), K)
+        return ops.plane_view(y, M)
+
+    def _brelu(self, x, per_vertex):
+        N, M, F = x.shape
+        b = self._bias_variable([1, int(M) if per_vertex else 1, int(F)], regularization=False)
+        if x.is_meta:
+            return x
+        kind = BIAS_VERTEX if per_vertex else BIAS_FILTER
+        y = ops.BiasReluPool.apply(ops.plane_storage(x), b, int(M), 1, POOL_MAX, True, kind)
+        return ops.plane_view(y, M)
+
+    def b1relu(self, x):
+        """Bias and ReLU, one bias per filter (:619-623)."""
+        return self._brelu(x, False)
+
+    def b2relu(self, x):
+        """Bias and ReLU, one bias per vertex per filter (:625-629)."""
+        return self._brelu(x, True)
+
+    def _pool(self, x, p, kind):
+        if p <= 1:
+            return x
+        N, M, F = x.shape
+        if x.is_meta:
+            return torch.empty((N, M // p, F), device='meta')
+        y = ops.BiasReluPool.apply(ops.plane_storage(x), None, int(M), int(p), kind, False, BIAS_NONE)
+        return ops.plane_view(y, M // p)
+
+    def mpool1(self, x, p):
+        """Max pooling of size p over consecutive (tree-ordered) vertices (:631-639)."""
+        return self._pool(x, p, POOL_MAX)
+
+    def apool1(self, x, p):
+        """Average pooling of size p (:641-648)."""
+        return self._pool(x, p, POOL_AVG)
+
+    def fc(self, x, Mout, relu=True):
+        """Fully connected layer (:650-656); weights *and* bias are L2-regularised."""
+        N, Min = x.shape
+        W = self._weight_variable([int(Min), Mout], regularization=True)
+        b = self._bias_variable([Mout], regularization=True)
+        if x.is_meta:
+            return torch.empty((N, Mout), device='meta')
+        x = torch.addmm(b, x, W)
+        return torch.relu(x) if relu else x
+
+    # ------------------------------------------------------------------ network
+
+    def _fusable(self):
+        std = lambda m, names: getattr(m, '__func__', None) in [getattr(cgcnn, n) for n in names]
+        return (std(self.filter, ['chebyshev5']) and std(self.brelu, ['b1relu', 'b2relu'])
+                and std(self.pool, ['mpool1', 'apool1']))
+
+    def _inference(self, x, dropout):
+        """Layer loop + head (:658-682) on a logical [N, M, channel] tensor."""
+        if x.is_meta or not self._fusable():
+            for i in range(len(self.p)):
+                with self.variable_scope('conv{}'.format(i + 1)):
+                    x = self.filter(x, self.L[i], self.F[i], self.K[i])
+                    x = self.brelu(x)
+                    x = self.pool(x, self.p[i])
+            N, M, F = x.shape
+            h = torch.empty((N, M), device='meta') if x.is_meta else ops.FeatureMean.apply(ops.plane_storage(x), int(M))
+            return self._head(h, dropout)
+        return self._inference_storage(ops.plane_storage(x), dropout)
+
+    def _inference_storage(self, x, dropout):
+        """Fused fast path on plane storage ``[N, channel, Mp]``: every conv layer is
+        recurrence + (contraction, bias, ReLU, pooling) and writes straight into slab 0 of
+        the next layer's Chebyshev stack."""
+        if not self._fusable():
+            return self._inference(ops.plane_view(x, self.L[0].shape[0]), dropout)
+        nl = len(self.p)
+        B = x.shape[0]
+        per_vertex = getattr(self.brelu, '__func__', None) is cgcnn.b2relu
+        pool_kind = POOL_AVG if getattr(self.pool, '__func__', None) is cgcnn.apool1 else POOL_MAX
+        stack = None
+        for i in range(nl):
+            g = self.graphs[i]
+            W = self._params['conv%d/weights' % (i + 1)]
+            b = self._params['conv%d/bias' % (i + 1)]
+            out = next_stack = None
+            if i + 1 < nl and g.M // self.p[i] == self.graphs[i + 1].M:
+                next_stack = torch.empty((self.K[i + 1], B, self.F[i], self.graphs[i + 1].Mp), dtype=torch.float32,
+                                         device=x.device)
+                out = next_stack[0]
+            x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
+                              BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out)
+            stack = next_stack
+        M_last = self.graphs[-1].M // self.p[-1]
+        return self._head(ops.FeatureMean.apply(x, M_last), dropout)
+
+    def _head(self, x, dropout):
+        """reduce_mean output -> FC stack with dropout -> logits (:674-682)."""
+        for i, Mi in enumerate(self.M[:-1]):
+            with self.variable_scope('fc{}'.format(i + 1)):
+                x = self.fc(x, Mi)
+                if not x.is_meta and self.training_mode and dropout != 1:
+                    x = Fnn.dropout(x, p=1.0 - float(dropout), training=True)   # tf.nn.dropout(x, keep_prob)
+        with self.variable_scope('logits'):
+            x = self.fc(x, self.M[-1], relu=False)
+        return x
+
+
+class model_perf(object):
+    """Experiment harness: ``test`` = fit + evaluate on train and test (:936-958)."""
+
+    def __init__(s):
+        s.names, s.params = set(), {}
+        s.fit_accuracies, s.fit_losses, s.fit_time = {}, {}, {}
+        s.train_accuracy, s.train_f1, s.train_loss = {}, {}, {}
+        s.test_accuracy, s.test_f1, s.test_loss = {}, {}, {}
+
+    def test(s, model, name, params, train_data, train_labels, val_data, val_labels, test_data, test_labels,
+             target_name=None):
+        s.params[name] = params
+        s.fit_accuracies[name], s.fit_losses[name], s.fit_time[name] = model.fit(
+            train_data, train_labels, val_data, val_labels)
+        string, s.train_accuracy[name], s.train_f1[name], s.train_loss[name] = model.evaluate(
+            train_data, train_labels, target_name=target_name)
+        print('\ntrain {}\n'.format(string))
+        string, s.test_accuracy[name], s.test_f1[name], s.test_loss[name] = model.evaluate(
+            test_data, test_labels, target_name=target_name)
+        print('\ntest  {}\n'.format(string))
+        s.names.add(name)
+        return s

@@ -1,0 +1,390 @@
+"""PyTorch-ROCm face of libchebgcn.so: device graph handles, plane-layout helpers and the
+``torch.autograd.Function`` wrappers around the HIP kernels.  PyTorch supplies device
+memory, streams and autograd bookkeeping; every arithmetic op of the graph-convolution
+path runs in the library (there is no torch / CPU fallback -- a missing library or a
+failing call raises).
+
+Plane layout: the reference's activation ``x[N, M, F]`` (models_gcn.py:588) is kept as a
+contiguous *storage* tensor ``[N, F, Mp]`` (vertex axis fastest, ``Mp = plane_stride(M)``).
+``plane_view(storage, M)`` exposes it with the reference's logical shape ``[N, M, F]``
+without copying; ``plane_storage(x)`` goes back (zero-copy when ``x`` is such a view).
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+from . import graph as _graph
+from ._lib import BIAS_FILTER, BIAS_NONE, BIAS_VERTEX, POOL_AVG, POOL_MAX, plane_stride
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class KernelTimers:
+    """Optional per-launch HIP-event timing of the hot kernels (used by bench.py for the
+    roofline line).  Events are recorded on the stream the kernel is launched on; nothing
+    is synchronised until ``summary()``.  Disabled (``timers is None``) by default."""
+
+    def __init__(self):
+        self.records = {}           # name -> list of (start, end, algorithmic bytes, flops)
+
+    def launch(self, name, nbytes, flops, fn):
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        rc = fn()
+        end.record()
+        self.records.setdefault(name, []).append((start, end, nbytes, flops))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            out[name] = {'launches': len(recs), 'total_ms': float(sum(ms)), 'avg_ms': float(sum(ms) / len(ms)),
+                         'bytes': float(sum(r[2] for r in recs)), 'flops': float(sum(r[3] for r in recs))}
+        return out
+
+
+timers = None
+
+
+def _launch(name, nbytes, flops, fn):
+    """Run one C-ABI call, optionally bracketed by HIP events."""
+    if timers is None:
+        return fn()
+    return timers.launch(name, nbytes, flops, fn)
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.ChebgcnError('chebgcn ops need ROCm device tensors; got a %s tensor '
+                                    '(there is no CPU path)' % t.device)
+
+
+# ------------------------------------------------------------------------------------
+# device graph
+# ------------------------------------------------------------------------------------
+
+class Graph:
+    """Device image of one Laplacian: ``rescale_L(L, lmax=2)`` and its transpose, as the
+    constant sparse operand of the recurrence (models_gcn.py:590-596)."""
+
+    def __init__(self, L, device=None):
+        self.M = int(L.shape[0])
+        self.Mp = plane_stride(self.M)
+        indptr, indices, data = _graph.rescaled_laplacian_csr(L)
+        self.nnz = int(len(data))
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().chebgcn_graph_create(self.M, self.nnz, indptr.ctypes.data_as(C.c_void_p),
+                                                 indices.ctypes.data_as(C.c_void_p),
+                                                 data.ctypes.data_as(C.c_void_p), C.byref(handle))
+        _lib.check(rc, 'graph_create')
+        self.handle = handle
+        self._finalizer = weakref.finalize(self, _lib.lib().chebgcn_graph_destroy, handle)
+
+    def query(self, what):
+        v = C.c_int64()
+        _lib.check(_lib.lib().chebgcn_graph_query(self.handle, what, C.byref(v)), 'graph_query')
+        return v.value
+
+    @property
+    def on_chip(self):
+        return bool(self.query(3))
+
+
+_graph_cache = weakref.WeakValueDictionary()
+
+
+def graph_for(L, device=None):
+    """Cache of device graphs keyed by the identity of the SciPy matrix and the device."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (id(L), dev)
+    g = _graph_cache.get(key)
+    if g is None or g.M != L.shape[0]:
+        g = Graph(L, torch.device('cuda', dev))
+        _graph_cache[key] = g
+        # keep the graph alive as long as the matrix object is
+        try:
+            L._chebgcn_graphs = getattr(L, '_chebgcn_graphs', {})
+            L._chebgcn_graphs[dev] = g
+        except AttributeError:
+            pass
+    return g
+
+
+# ------------------------------------------------------------------------------------
+# plane layout helpers
+# ------------------------------------------------------------------------------------
+
+def plane_empty(B, F, M, device, zero=False):
+    Mp = plane_stride(M)
+    return (torch.zeros if zero else torch.empty)((B, F, Mp), dtype=torch.float32, device=device)
+
+
+def plane_view(storage, M):
+    """[B, F, Mp] storage -> logical [B, M, F] view (no copy)."""
+    return storage[:, :, :M].permute(0, 2, 1)
+
+
+def _is_plane_view(x):
+    if x.dim() != 3 or x.dtype != torch.float32:
+        return False
+    B, M, F = x.shape
+    Mp = plane_stride(M)
+    if x.stride() != (F * Mp, 1, Mp):
+        return False
+    need = (x.storage_offset() + B * F * Mp) * 4
+    return x.untyped_storage().nbytes() >= need
+
+
+def plane_storage(x):
+    """Logical [B, M, F] tensor -> contiguous [B, F, Mp] storage.  Zero-copy for tensors
+    produced by ``plane_view``; otherwise one layout-change kernel (to_plane)."""
+    _require_cuda(x)
+    B, M, F = x.shape
+    Mp = plane_stride(M)
+    if _is_plane_view(x):
+        return x.as_strided((B, F, Mp), (F * Mp, Mp, 1))
+    return ToPlane.apply(x)
+
+
+class ToPlane(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        B, M, F = x.shape
+        out = plane_empty(B, F, M, x.device)
+        _lib.check(_lib.lib().chebgcn_to_plane(_p(x), _p(out), B, M, F, _stream()), 'to_plane')
+        ctx.shape = (B, M, F)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, M, F = ctx.shape
+        g = g.contiguous()
+        out = torch.empty((B, M, F), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().chebgcn_from_plane(_p(g), _p(out), B, M, F, _stream()), 'from_plane')
+        return out
+
+
+def from_plane(storage, M):
+    """[B, F, Mp] storage -> contiguous [B, M, F] tensor in the reference layout."""
+    storage = storage.contiguous()
+    B, F, Mp = storage.shape
+    out = torch.empty((B, M, F), dtype=torch.float32, device=storage.device)
+    _lib.check(_lib.lib().chebgcn_from_plane(_p(storage), _p(out), B, M, F, _stream()), 'from_plane')
+    return out
+
+
+def perm_data(x, perm, sample=None, out=None):
+    """GPU ``coarsening.perm_data_3d`` (+ batch gather): x[S_total, N, F] (device, row
+    layout), perm int32 [M] on device, optional sample indices -> storage [S, F, Mp]."""
+    _require_cuda(x, perm, sample)
+    x = x.contiguous()
+    S_total, N, F = x.shape
+    M = int(perm.numel())
+    S = S_total if sample is None else int(sample.numel())
+    if out is None:
+        out = plane_empty(S, F, M, x.device)
+    _lib.check(_lib.lib().chebgcn_perm_data(_p(x), _p(perm), _p(sample), _p(out), S, N, M, F, _stream()), 'perm_data')
+    return out
+
+
+# ------------------------------------------------------------------------------------
+# the graph-convolution layer
+# ------------------------------------------------------------------------------------
+
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+class ChebConv(torch.autograd.Function):
+    """y = pool(act(sum_k T_k(L~) x W_k + bias)) on plane storage tensors.
+
+    forward : recurrence_fwd (models_gcn.py:598-610) + contract_fwd (:611-648)
+    backward: brelu_pool_bwd, contract_bwd_w, contract_bwd_x, recurrence_bwd
+    ``bufs`` is a ``Buffers`` holder (kept out of autograd's sight): ``bufs.stack`` is an
+    optional preallocated [K, B, Fin, Mp] buffer -- when ``x`` already is its slab 0 no copy
+    of T_0 is made; ``bufs.out`` optionally receives the result, e.g. slab 0 of the next
+    layer's stack.
+    """
+
+    @staticmethod
+    def forward(ctx, x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs):
+        _require_cuda(x, W, bias)
+        stack, out = (bufs.stack, bufs.out) if bufs is not None else (None, None)
+        lib = _lib.lib()
+        x = x if x.is_contiguous() else x.contiguous()
+        B, Fin, Mp = x.shape
+        M = graph.M
+        if Mp != graph.Mp:
+            raise ValueError('activation plane stride %d does not match the graph (%d vertices)' % (Mp, M))
+        FinK, Fout = W.shape
+        if FinK != Fin * K:
+            raise ValueError('weight rows %d != Fin*K = %d' % (FinK, Fin * K))
+        Wc = W.detach().contiguous()
+        if stack is None:
+            stack = torch.empty((K, B, Fin, Mp), dtype=torch.float32, device=x.device)
+        # algorithmic bytes: recurrence 4*M*Fin*K per window; the contraction's
+        # compulsory traffic 4*(M*Fin*K + M*Fout/pool) per window, flops 2*M*Fin*K*Fout
+        _lib.check(_launch('recurrence_fwd', 4.0 * M * Fin * K * B, 0.0, lambda: lib.chebgcn_recurrence_fwd(
+            graph.handle, _p(x), _p(stack), B, Fin, K, _stream())), 'recurrence_fwd')
+        Mo = M // pool
+        if out is None:
+            out = plane_empty(B, Fout, Mo, x.device)
+        else:
+            out = out.detach()                # fresh alias: an output, not an input, for autograd
+            if tuple(out.shape) != (B, Fout, plane_stride(Mo)) or not out.is_contiguous():
+                raise ValueError('out buffer has the wrong shape')
+        argmax = None
+        if pool > 1 and (pool_kind == POOL_MAX or relu):
+            argmax = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+        b = bias.detach() if bias is not None else None
+        if b is not None and not b.is_contiguous():
+            b = b.contiguous()
+        _lib.check(_launch('contract_fwd', 4.0 * B * (M * Fin * K + Mo * Fout), 2.0 * B * M * Fin * K * Fout,
+                           lambda: lib.chebgcn_contract_fwd(_p(stack), _p(Wc), _p(b), bias_kind, _p(out), _p(argmax), B, M,
+                                                            Fin, K, Fout, pool, pool_kind, int(relu), _stream())),
+                   'contract_fwd')
+        ctx.save_for_backward(stack, Wc, out, argmax)
+        ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.lib()
+        stack, Wc, out, argmax = ctx.saved_tensors
+        B, M, Fin, K, Fout, pool, pool_kind, relu, bias_kind = ctx.cfg
+        g = ctx.graph
+        gout = gout.contiguous()
+        dev = gout.device
+        dy = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev)
+        dbias = None
+        if bias_kind != BIAS_NONE and ctx.needs_input_grad[2]:
+            dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
+        Mo = M // pool
+        _lib.check(_launch('brelu_pool_bwd', 4.0 * B * Fout * (2 * Mo + M), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
+            _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bias_kind if dbias is not None else BIAS_NONE, B, M, Fout,
+            pool, pool_kind, relu, _stream())), 'brelu_pool_bwd')
+        dW = None
+        if ctx.needs_input_grad[1]:
+            nbytes = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
+            ws = _workspace(nbytes, dev)
+            dW = torch.empty((Fin * K, Fout), dtype=torch.float32, device=dev)
+            _lib.check(_launch('contract_bwd_w', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
+                               lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
+                                                                  K, Fout, _stream())), 'contract_bwd_w')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gstack = torch.empty((K, B, Fin, g.Mp), dtype=torch.float32, device=dev)
+            _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
+                               lambda: lib.chebgcn_contract_bwd_x(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
+                                                                  _stream())), 'contract_bwd_x')
+            dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
+            _lib.check(_launch('recurrence_bwd', 4.0 * B * M * Fin * (K + 1), 0.0, lambda: lib.chebgcn_recurrence_bwd(
+                g.handle, _p(gstack), _p(dx), B, Fin, K, _stream())), 'recurrence_bwd')
+        return dx, dW, dbias, None, None, None, None, None, None, None
+
+
+class Buffers:
+    """Preallocated stack / output buffers for ``cheb_conv`` (plain object, not a tensor)."""
+    __slots__ = ('stack', 'out')
+
+    def __init__(self, stack=None, out=None):
+        self.stack, self.out = stack, out
+
+
+def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None):
+    bufs = Buffers(stack, out) if (stack is not None or out is not None) else None
+    return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
+
+
+class BiasReluPool(torch.autograd.Function):
+    """Standalone bias + ReLU + pooling (b1relu / b2relu / mpool1 / apool1 called on their
+    own, models_gcn.py:619-648) on plane storage tensors."""
+
+    @staticmethod
+    def forward(ctx, x, bias, M, pool, pool_kind, relu, bias_kind):
+        _require_cuda(x, bias)
+        x = x if x.is_contiguous() else x.contiguous()
+        B, F, Mp = x.shape
+        out = plane_empty(B, F, M // pool, x.device)
+        argmax = None
+        if pool > 1 and (pool_kind == POOL_MAX or relu):
+            argmax = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+        b = bias.detach().contiguous() if bias is not None else None
+        _lib.check(_lib.lib().chebgcn_brelu_pool_fwd(_p(x), _p(b), bias_kind, _p(out), _p(argmax), B, M, F, pool,
+                                                     pool_kind, int(relu), _stream()), 'brelu_pool_fwd')
+        ctx.save_for_backward(out, argmax)
+        ctx.cfg = (B, M, F, pool, pool_kind, int(relu), bias_kind, Mp)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        out, argmax = ctx.saved_tensors
+        B, M, F, pool, pool_kind, relu, bias_kind, Mp = ctx.cfg
+        gout = gout.contiguous()
+        dy = torch.empty((B, F, Mp), dtype=torch.float32, device=gout.device)
+        dbias = None
+        if bias_kind != BIAS_NONE and ctx.needs_input_grad[1]:
+            dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=gout.device)
+        _lib.check(_lib.lib().chebgcn_brelu_pool_bwd(_p(gout), _p(out), _p(argmax), _p(dy), _p(dbias),
+                                                     bias_kind if dbias is not None else BIAS_NONE, B, M, F, pool,
+                                                     pool_kind, relu, _stream()), 'brelu_pool_bwd')
+        return dy, dbias, None, None, None, None, None
+
+
+class FeatureMean(torch.autograd.Function):
+    """tf.reduce_mean(x, -1) (models_gcn.py:673): storage [B, F, Mp] -> dense [B, M]."""
+
+    @staticmethod
+    def forward(ctx, x, M):
+        _require_cuda(x)
+        x = x if x.is_contiguous() else x.contiguous()
+        B, F, Mp = x.shape
+        y = torch.empty((B, M), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().chebgcn_feature_mean_fwd(_p(x), _p(y), B, M, F, _stream()), 'feature_mean_fwd')
+        ctx.cfg = (B, M, F, Mp)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, M, F, Mp = ctx.cfg
+        gy = gy.contiguous()
+        dx = torch.empty((B, F, Mp), dtype=torch.float32, device=gy.device)
+        _lib.check(_lib.lib().chebgcn_feature_mean_bwd(_p(gy), _p(dx), B, M, F, _stream()), 'feature_mean_bwd')
+        return dx, None
+
+
+def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
+    """In-place TF-form Adam on flat fp32 buffers (models_gcn.py:296)."""
+    _require_cuda(p, g, m, v)
+    n = p.numel()
+    if not (g.numel() == m.numel() == v.numel() == n):
+        raise ValueError('adam_step: size mismatch')
+    _lib.check(_lib.lib().chebgcn_adam_step(_p(p), _p(g), _p(m), _p(v), n, float(lr_t), float(beta1), float(beta2),
+                                            float(eps), float(grad_scale), float(l2), _stream()), 'adam_step')

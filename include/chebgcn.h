@@ -1,0 +1,167 @@
+/*
+ * chebgcn.h -- C ABI of libchebgcn.so: the MI355X (gfx950) implementation of the
+ * Chebyshev graph-convolution hot path of zhangyu2ustc/GCN_fmri_decoding.
+ *
+ * The reference has no FFI of its own: the path is a Python class
+ * (lib_new/models_gcn.py, class cgcnn) whose methods emit TensorFlow ops.  Each
+ * entry point below replaces the TF ops emitted by the cited reference lines;
+ * gcn_fmri_decoding_amd/ (Python, ctypes) binds them behind the reference's
+ * cgcnn / chebyshev5 / b1relu / b2relu / mpool1 API.  INTEGRATION.md shows the
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 on success or a negative
+ *    CHEBGCN_E* code, never throws; chebgcn_last_error() gives the message of
+ *    the last failure on the calling thread.
+ *  - all activation pointers are DEVICE pointers owned by the caller (PyTorch's
+ *    caching allocator in our host code); kernels are enqueued on `stream`
+ *    (a hipStream_t; NULL = the default stream) and the call returns without
+ *    synchronising.  Pointers marked "host" are host memory, read before return.
+ *  - activation layout is "plane": a logical [B, M, F] tensor of the reference
+ *    (B windows, M graph vertices, F features) is stored as [B][F][Mp] floats
+ *    with the vertex axis fastest and Mp = chebgcn_plane_stride(M) >= M.  The pad
+ *    [M, Mp) of every plane is scratch: kernels may write it and never read it
+ *    as data.
+ *  - a graph handle is immutable after creation and may be used concurrently.
+ */
+#ifndef CHEBGCN_H
+#define CHEBGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHEBGCN_VERSION 1
+
+enum {
+    CHEBGCN_OK = 0,
+    CHEBGCN_EINVAL = -1,       /* bad argument / shape */
+    CHEBGCN_EHIP = -2,         /* a HIP runtime call failed */
+    CHEBGCN_ENOMEM = -3,
+    CHEBGCN_EUNSUPPORTED = -4  /* valid but not implemented for this size */
+};
+
+enum { CHEBGCN_BIAS_NONE = 0, CHEBGCN_BIAS_FILTER = 1 /* b1relu: [F] */, CHEBGCN_BIAS_VERTEX = 2 /* b2relu: [F][Mp] */ };
+enum { CHEBGCN_POOL_MAX = 0, CHEBGCN_POOL_AVG = 1 };
+
+typedef struct chebgcn_graph chebgcn_graph;
+typedef void* chebgcn_stream;
+
+int chebgcn_version(void);
+const char* chebgcn_last_error(void);
+
+/* Padded plane length for M vertices (multiple of 32 floats = 128 B). */
+int chebgcn_plane_stride(int M);
+
+/* ---- graph: the constant operand of tf.sparse_tensor_dense_matmul ---------------
+ * Replaces models_gcn.py:593-596 (tf.SparseTensor + tf.sparse_reorder of the
+ * rescaled Laplacian).  Takes L~ = rescale_L(L, lmax=2) (lib_new/graph.py:146-152)
+ * as host CSR (row-major, any column order inside a row; summation follows the given
+ * order), builds device-side length-sorted sliced-ELL images of L~ and of L~^T (the
+ * adjoint used by the gradient of SparseTensorDenseMatMul).  The host arrays are
+ * copied; the caller keeps ownership. */
+int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr /*host [M+1]*/,
+                         const int32_t* colidx /*host [nnz]*/, const float* vals /*host [nnz]*/,
+                         chebgcn_graph** out);
+void chebgcn_graph_destroy(chebgcn_graph* g);
+/* what: 0 = M, 1 = nnz, 2 = plane stride Mp, 3 = 1 if the on-chip (LDS) recurrence
+ * kernel is used for this graph, 4 = padded ELL slots of L~, 5 = max row length. */
+int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* value);
+
+/* ---- Chebyshev recurrence, forward: models_gcn.py:598-610 -----------------------
+ * T_0 = x, T_1 = L~ T_0, T_k = 2 L~ T_{k-1} - T_{k-2}.
+ * x: [B][Fin][Mp]; stack: [K][B][Fin][Mp].  Slab 0 receives a copy of x unless
+ * x == stack (the producer already wrote T_0 in place). */
+int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, float* stack,
+                           int B, int Fin, int K, chebgcn_stream stream);
+
+/* ---- Chebyshev recurrence, adjoint: gradient of the above wrt x -----------------
+ * (TF autodiff of models_gcn.py:598-610, reached from :298-303.)
+ * c_{K-1} = G_{K-1}; c_j = G_j + 2 L~^T c_{j+1} - c_{j+2}; dx = G_0 + L~^T c_1 - c_2.
+ * gstack: [K][B][Fin][Mp] (read only); dx: [B][Fin][Mp]. */
+int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstack, float* dx,
+                           int B, int Fin, int K, chebgcn_stream stream);
+
+/* ---- dense contraction + bias + ReLU + pooling, forward -------------------------
+ * Replaces models_gcn.py:611-617 (transpose/reshape + tf.matmul with W[Fin*K, Fout],
+ * row index fin*K + k), :619-629 (b1relu / b2relu) and :631-648 (mpool1 / apool1).
+ * stack: [K][B][Fin][Mp(M)];  W: [Fin*K][Fout] row-major;  bias: [Fout] or
+ * [Fout][Mp(M)] or NULL;  out: [B][Fout][Mp(M/pool)];  argmax (may be NULL, only
+ * written for max pooling with pool > 1): [B][Fout][Mp(M/pool)] bytes, position of
+ * the first maximum inside each window.  relu != 0 applies max(.,0) before pooling.
+ * pool must be a power of two <= 128 and divide M. */
+int chebgcn_contract_fwd(const float* stack, const float* W, const float* bias, int bias_kind,
+                         float* out, uint8_t* argmax, int B, int M, int Fin, int K, int Fout,
+                         int pool, int pool_kind, int relu, chebgcn_stream stream);
+
+/* ---- bias + ReLU + pooling on their own (b1relu / b2relu / mpool1 / apool1 called
+ * separately, models_gcn.py:619-648); same conventions as the epilogue of contract_fwd.
+ * x: [B][F][Mp(M)] -> out: [B][F][Mp(M/pool)]. */
+int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bias_kind, float* out,
+                           uint8_t* argmax, int B, int M, int F, int pool, int pool_kind,
+                           int relu, chebgcn_stream stream);
+
+/* ---- backward of pooling + ReLU + bias (MaxPoolGrad, ReluGrad, bias reductions) ---
+ * dout, out: [B][F][Mp(M/pool)] (out = forward result); argmax as written by the
+ * forward; dy: [B][F][Mp(M)] receives d(loss)/d(pre-bias activation); dbias: [F] or
+ * [F][Mp(M)] (overwritten) or NULL. */
+int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const uint8_t* argmax,
+                           float* dy, float* dbias, int bias_kind, int B, int M, int F,
+                           int pool, int pool_kind, int relu, chebgcn_stream stream);
+
+/* ---- gradients of the contraction (MatMul grads) ---------------------------------
+ * dW[fin*K+k][o] = sum_{b,m} stack[k][b][fin][m] * dy[b][o][m]      (overwritten)
+ * gstack[k][b][fin][m] = sum_o dy[b][o][m] * W[fin*K+k][o]
+ * workspace: device scratch of at least chebgcn_contract_bwd_w_workspace() bytes. */
+size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K, int Fout);
+int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void* workspace,
+                           size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
+                           chebgcn_stream stream);
+int chebgcn_contract_bwd_x(const float* dy, const float* W, float* gstack, int B, int M,
+                           int Fin, int K, int Fout, chebgcn_stream stream);
+
+/* ---- layout / staging -----------------------------------------------------------
+ * perm_data: coarsening.perm_data_3d (lib_new/coarsening.py:244-265) fused with the
+ * fp32 cast and batch gather of fit() (models_gcn.py:138-146):
+ *   out[s][f][i] = perm[i] < N ? x[sample[s]][perm[i]][f] : 0,   i < M
+ * x: [S_total][N][F] row layout (device); perm: int32 [M] (device); sample: int32 [S]
+ * (device) or NULL for the identity; out: [S][F][Mp(M)].
+ * to_plane / from_plane convert between the reference's [B][M][F] and plane layout. */
+int chebgcn_perm_data(const float* x, const int32_t* perm, const int32_t* sample, float* out,
+                      int S, int N, int M, int F, chebgcn_stream stream);
+int chebgcn_to_plane(const float* x_bmf, float* out_plane, int B, int M, int F, chebgcn_stream stream);
+int chebgcn_from_plane(const float* x_plane, float* out_bmf, int B, int M, int F, chebgcn_stream stream);
+
+/* ---- head: tf.reduce_mean(x, -1) (models_gcn.py:673) and its gradient -----------
+ * x: [B][F][Mp(M)] -> y: [B][M] (dense);  dy: [B][M] -> dx: [B][F][Mp(M)]. */
+int chebgcn_feature_mean_fwd(const float* x, float* y, int B, int M, int F, chebgcn_stream stream);
+int chebgcn_feature_mean_bwd(const float* dy, float* dx, int B, int M, int F, chebgcn_stream stream);
+
+/* ---- optimizer: tf.train.AdamOptimizer step (models_gcn.py:296, TF form) ---------
+ * g' = grad_scale * g + l2 * p (per-segment l2 handled by the caller passing
+ * segments);  m += (1-b1)(g'-m);  v += (1-b2)(g'^2-v);  p -= lr_t * m / (sqrt(v)+eps)
+ * with lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int chebgcn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
+                      float beta1, float beta2, float eps, float grad_scale, float l2,
+                      chebgcn_stream stream);
+
+/* ---- host-side index maps (no GPU): lib_new/coarsening.py -----------------------
+ * metis_one_level (:120-166): one greedy matching pass, bit-exact incl. the
+ * reference's row-length quirk.  rr/cc: int64 [nnz] sorted by rr; vv/weights in the
+ * given precision; rid: int64 [N] visiting order; cluster_id: int32 [N] out.
+ * compute_perm (:168-215) for ONE level: children of `order` (length n_order) among
+ * the fine vertices with `parent` (length n_fine); out must hold 2*n_order. */
+int chebgcn_metis_one_level_f32(int64_t nnz, const int64_t* rr, const int64_t* cc, const float* vv,
+                                const int64_t* rid, const float* weights, int64_t N, int32_t* cluster_id);
+int chebgcn_metis_one_level_f64(int64_t nnz, const int64_t* rr, const int64_t* cc, const double* vv,
+                                const int64_t* rid, const double* weights, int64_t N, int32_t* cluster_id);
+int chebgcn_compute_perm_level(const int32_t* parent, int64_t n_fine, const int64_t* order,
+                               int64_t n_order, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHEBGCN_H */

@@ -1,0 +1,110 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol that
+include/chebgcn.h declares, argument validation works without a GPU, the product never
+imports the oracle, and the host-side model logic (variable names / shapes / flat layout)
+mirrors the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT, csr_from, load_golden
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'chebgcn.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(chebgcn_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gcn_fmri_decoding_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), 'libchebgcn.so does not export %s' % n
+    # the ctypes table binds exactly the declared set
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib().chebgcn_version() == 1
+    for M in (1, 31, 32, 33, 10466):
+        assert _lib.lib().chebgcn_plane_stride(M) == _lib.plane_stride(M) >= M
+    assert _lib.plane_stride(10466) == 10496
+
+
+def test_argument_validation_without_gpu():
+    from gcn_fmri_decoding_amd import _lib
+    lib = _lib.lib()
+    out = ctypes.c_void_p()
+    rc = lib.chebgcn_graph_create(0, 0, None, None, None, ctypes.byref(out))
+    assert rc == -1 and b'graph_create' in lib.chebgcn_last_error()
+    rp = np.array([0, 1, 3], np.int32)      # rowptr[M] != nnz
+    ci = np.array([0, 1], np.int32)
+    va = np.ones(2, np.float32)
+    rc = lib.chebgcn_graph_create(2, 2, rp.ctypes.data_as(ctypes.c_void_p), ci.ctypes.data_as(ctypes.c_void_p),
+                                  va.ctypes.data_as(ctypes.c_void_p), ctypes.byref(out))
+    assert rc == -1
+    assert lib.chebgcn_recurrence_fwd(None, None, None, 1, 1, 1, None) == -1
+    assert lib.chebgcn_contract_fwd(None, None, None, 0, None, None, 1, 1, 1, 1, 1, 1, 0, 0, None) == -1
+    assert lib.chebgcn_contract_bwd_w_workspace(0, 1, 1, 1, 1) == 0
+    with pytest.raises(_lib.ChebgcnError):
+        _lib.check(-1, 'x')
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'gcn_fmri_decoding_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+                assert 'oracle/' not in text and 'oracle.' not in text.replace('# oracle.', ''), f
+
+
+def test_cpu_tensor_is_rejected():
+    import torch
+    from gcn_fmri_decoding_amd import _lib, ops
+    with pytest.raises(_lib.ChebgcnError):
+        ops.plane_storage(torch.zeros(1, 4, 2))
+    from gcn_fmri_decoding_amd import models_gcn
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            models_gcn.cgcnn(None, [sp.identity(8, format='csr')], [2], [2], [1], [3], verbose=False)
+
+
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512'])
+def test_variable_layout_matches_reference(name):
+    """Shape-only build (device='meta'): variable names and TF shapes equal the reference's
+    (golden 'param:*' entries come from the reference's own _inference run)."""
+    from gcn_fmri_decoding_amd import models_gcn
+    z = load_golden(name)
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    net = models_gcn.cgcnn('meta', Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                           channel=int(z['channel']), brelu=str(z['brelu']), batch_size=4, verbose=False,
+                           regularization=5e-4)
+    want = {k[len('param:'):]: z[k].shape for k in z.files if k.startswith('param:')}
+    assert {k: tuple(net.variable(k).shape) for k in net.variables()} == want
+    # regularised: conv weights and every fc weight and bias; not the conv biases
+    assert set(net.regularizers) == {k for k in want if not (k.startswith('conv') and k.endswith('bias'))}
+    # flat layout: [head | conv weights | conv biases], regularised part first
+    groups = [s.group for s in net._spec_list]
+    assert groups == sorted(groups, key=['head', 'convw', 'convb'].index)
+    assert net._n_reg == sum(int(np.prod(s.shape)) for s in net._spec_list if s.regularized)
+    assert net._n_total == net._flat.numel()
+    # reported learning rate: staircase decay, optimizer itself fixed (models_gcn.py:283-296)
+    net.decay_steps, net.decay_rate, net.learning_rate = 10, 0.9, 0.001
+    net.global_step = 25
+    assert abs(net.training(None, 0.001, 10, 0.9, 0.9) - 0.001 * 0.9 ** 2) < 1e-12
+
+
+def test_constructor_checks_like_reference():
+    from gcn_fmri_decoding_amd import models_gcn
+    L = [sp.identity(16, format='csr', dtype=np.float32), sp.identity(8, format='csr', dtype=np.float32)]
+    with pytest.raises(AssertionError):     # pooling size not a power of two
+        models_gcn.cgcnn('meta', L, [2], [2], [3], [3], verbose=False)
+    with pytest.raises(AssertionError):     # not enough coarsening levels for p=8
+        models_gcn.cgcnn('meta', L, [2], [2], [8], [3], verbose=False)
+    net = models_gcn.cgcnn('meta', L, [2, 2], [2, 3], [2, 1], [3], verbose=False, batch_size=2)
+    assert [l.shape[0] for l in net.L] == [16, 8]

@@ -1,0 +1,398 @@
+"""Parity of the HIP path (through the C ABI of libchebgcn.so) with the CPU oracle and the
+golden vectors produced by the reference.  Needs an MI355X: run with ``-m gpu``.
+
+Tolerance: BASELINE.json's north star asks for <= 1e-5 relative fp32; we assert
+max|hip - ref| <= 1e-5 * max|ref| per tensor (REL below), bit-exactness for index maps.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import csr_from, load_golden
+from oracle import coarsening_ref as CR
+from oracle import graph_ref as GR
+from oracle import layers_ref as R
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def close(got, ref, rel=REL, what=''):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max() / scale
+    assert err <= rel, '%s: rel err %.3e > %.1e' % (what, err, rel)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gcn_fmri_decoding_amd import ops as o
+    return o
+
+
+def to_storage(ops, x_bmf, dev):
+    """numpy [B, M, F] -> plane storage tensor [B, F, Mp] with a NaN-poisoned pad (the pad
+    must never leak into results)."""
+    B, M, F = x_bmf.shape
+    st = torch.full((B, F, ops.plane_stride(M)), float('nan'), device=dev)
+    st[:, :, :M] = torch.as_tensor(np.ascontiguousarray(x_bmf.transpose(0, 2, 1))).to(dev)
+    return st
+
+
+def from_storage(st, M):
+    return st[:, :, :M].permute(0, 2, 1).cpu().numpy()
+
+
+def stack_to_ref(stack, M):
+    """[K, B, F, Mp] device -> oracle layout T[K, M, F, B]."""
+    return stack[:, :, :, :M].permute(0, 3, 2, 1).cpu().numpy()
+
+
+def levels(name='layers_n212'):
+    z = load_golden(name)
+    return [csr_from(z, 'L%d' % i) for i in range(4)]
+
+
+# ---------------------------------------------------------------------------------------
+# recurrence
+# ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('lvl,B,Fin,K', [(0, 1, 1, 2), (0, 3, 5, 5), (1, 2, 3, 9), (0, 2, 1, 25), (3, 5, 7, 4), (0, 4, 15, 1)])
+def test_recurrence_fwd_vs_oracle(ops, dev, lvl, B, Fin, K):
+    from gcn_fmri_decoding_amd import _lib
+    L = levels()[lvl]
+    M = L.shape[0]
+    g = ops.Graph(L, dev)
+    rs = np.random.RandomState(lvl * 100 + K)
+    x = rs.randn(B, M, Fin).astype(np.float32)
+    xs = to_storage(ops, x, dev)
+    stack = torch.full((K, B, Fin, g.Mp), float('nan'), device=dev)
+    _lib.check(_lib.lib().chebgcn_recurrence_fwd(g.handle, ops._p(xs), ops._p(stack), B, Fin, K, ops._stream()), 'fwd')
+    ref = R.cheb_stack(R.rescaled_laplacian(L, np.float32), x, K)        # [K, M, Fin, B]
+    close(stack_to_ref(stack, M), ref, what='stack')
+    # in-place form: x already is slab 0
+    stack2 = torch.empty((K, B, Fin, g.Mp), device=dev)
+    stack2[0] = xs
+    _lib.check(_lib.lib().chebgcn_recurrence_fwd(g.handle, ops._p(stack2), ops._p(stack2), B, Fin, K, ops._stream()), 'fwd')
+    assert torch.equal(stack2[:, :, :, :M], stack[:, :, :, :M])
+
+
+@pytest.mark.parametrize('lvl,B,Fin,K', [(0, 1, 1, 2), (0, 3, 5, 5), (1, 2, 3, 9), (2, 3, 2, 3), (0, 2, 2, 1)])
+def test_recurrence_bwd_vs_oracle(ops, dev, lvl, B, Fin, K):
+    from gcn_fmri_decoding_amd import _lib
+    L = levels()[lvl]
+    M = L.shape[0]
+    g = ops.Graph(L, dev)
+    rs = np.random.RandomState(7 + K)
+    G = rs.randn(K, M, Fin * B).astype(np.float32)                       # oracle layout [K, M, Fin*B]
+    Lt = sp.csr_matrix(R.rescaled_laplacian(L, np.float32).T)
+    ref = G.copy()
+    for k in range(K - 1, 1, -1):
+        ref[k - 1] += 2 * Lt.dot(ref[k])
+        ref[k - 2] -= ref[k]
+    if K > 1:
+        ref[0] += Lt.dot(ref[1])
+    gs = torch.full((K, B, Fin, g.Mp), float('nan'), device=dev)
+    gs[:, :, :, :M] = torch.as_tensor(G.reshape(K, M, Fin, B).transpose(0, 3, 2, 1).copy()).to(dev)
+    dx = torch.full((B, Fin, g.Mp), float('nan'), device=dev)
+    _lib.check(_lib.lib().chebgcn_recurrence_bwd(g.handle, ops._p(gs), ops._p(dx), B, Fin, K, ops._stream()), 'bwd')
+    got = dx[:, :, :M].permute(2, 1, 0).cpu().numpy().reshape(M, Fin * B)
+    close(got, ref[0], what='dx')
+
+
+def test_recurrence_adjoint_identity(ops, dev):
+    """<stack(x), G> == <x, adjoint(G)> at the benchmark size (size-independent property)."""
+    from gcn_fmri_decoding_amd import _lib, graph
+    Ls, perm, _ = graph.synthetic_graph(10000, k=8, levels=1)
+    g = ops.Graph(Ls[0], dev)
+    assert g.M == 10466 and g.on_chip
+    B, Fin, K = 4, 6, 5
+    torch.manual_seed(0)
+    x = torch.randn(B, Fin, g.Mp, device=dev)
+    x[:, :, g.M:] = 0
+    G = torch.randn(K, B, Fin, g.Mp, device=dev)
+    G[:, :, :, g.M:] = 0
+    stack = torch.empty_like(G)
+    dx = torch.empty_like(x)
+    lib = _lib.lib()
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, ops._p(x), ops._p(stack), B, Fin, K, ops._stream()), 'fwd')
+    _lib.check(lib.chebgcn_recurrence_bwd(g.handle, ops._p(G), ops._p(dx), B, Fin, K, ops._stream()), 'bwd')
+    lhs = (stack[:, :, :, :g.M].double() * G[:, :, :, :g.M].double()).sum().item()
+    rhs = (x[:, :, :g.M].double() * dx[:, :, :g.M].double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    # against the oracle on two planes of the full-size graph
+    Lr = R.rescaled_laplacian(Ls[0], np.float32)
+    xp = x[1, 2:4, :g.M].cpu().numpy().T.copy()                          # [M, 2]
+    ref = GR.chebyshev(Lr, xp, K)                                          # [K, M, 2]
+    got = stack[:, 1, 2:4, :g.M].permute(0, 2, 1).cpu().numpy()
+    close(got, ref, what='full-size stack')
+    # linearity
+    y = torch.randn_like(x)
+    y[:, :, g.M:] = 0
+    s2 = torch.empty_like(G)
+    s3 = torch.empty_like(G)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, ops._p(y), ops._p(s2), B, Fin, K, ops._stream()), 'fwd')
+    z = (2.0 * x - y).contiguous()
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, ops._p(z), ops._p(s3), B, Fin, K, ops._stream()), 'fwd')
+    lin = 2.0 * stack - s2
+    err = (s3 - lin)[:, :, :, :g.M].abs().max().item() / lin[:, :, :, :g.M].abs().max().item()
+    assert err <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# one layer, forward and backward, against the oracle / reference vectors
+# ---------------------------------------------------------------------------------------
+
+def test_chebyshev5_layer_vs_reference_vectors(ops, dev):
+    """chebyshev5 (+ b1relu / b2relu + mpool1 / apool1) on the golden inputs: compared with
+    the reference's own layer methods (executed under the TF stand-in)."""
+    z = load_golden('layers_n212')
+    Ls = levels()
+    for tag in 'abcde':
+        x, W = z['cheb_%s_x' % tag], z['cheb_%s_W' % tag]
+        K, lvl = int(z['cheb_%s_K' % tag]), int(z['cheb_%s_lvl' % tag])
+        L = Ls[lvl]
+        M = L.shape[0]
+        g = ops.Graph(L, dev)
+        xs = to_storage(ops, x, dev)
+        Wd = torch.as_tensor(W).to(dev)
+        y = ops.cheb_conv(xs, Wd, None, g, K)
+        close(from_storage(y, M), z['cheb_%s_y' % tag], what='cheb ' + tag)
+        b1 = torch.as_tensor(z['cheb_%s_b1' % tag].reshape(-1)).to(dev)
+        b2 = torch.zeros((W.shape[1], g.Mp), device=dev)
+        b2[:, :M] = torch.as_tensor(z['cheb_%s_b2' % tag][0].T.copy()).to(dev)
+        y1 = ops.cheb_conv(xs, Wd, b1, g, K, relu=True, bias_kind=ops.BIAS_FILTER)
+        close(from_storage(y1, M), z['cheb_%s_y1' % tag], what='b1relu ' + tag)
+        for p in (1, 2, 4):
+            ymp = ops.cheb_conv(xs, Wd, b2, g, K, pool=p, pool_kind=ops.POOL_MAX, relu=True, bias_kind=ops.BIAS_VERTEX)
+            close(from_storage(ymp, M // p), z['cheb_%s_mp%d' % (tag, p)], what='mpool %s %d' % (tag, p))
+            yap = ops.cheb_conv(xs, Wd, b2, g, K, pool=p, pool_kind=ops.POOL_AVG, relu=True, bias_kind=ops.BIAS_VERTEX)
+            close(from_storage(yap, M // p), z['cheb_%s_ap%d' % (tag, p)], what='apool %s %d' % (tag, p))
+            # unfused kernels give the same numbers
+            y2 = ops.cheb_conv(xs, Wd, None, g, K)
+            yu = ops.BiasReluPool.apply(y2, b2, M, p, ops.POOL_MAX, True, ops.BIAS_VERTEX)
+            assert torch.equal(yu[:, :, :M // p], ymp[:, :, :M // p])
+
+
+@pytest.mark.parametrize('lvl,B,Fin,Fout,K,p,pool_kind,bias', [
+    (0, 3, 5, 8, 5, 1, 0, 2), (0, 2, 3, 40, 3, 2, 0, 1), (1, 2, 4, 33, 2, 4, 0, 2), (0, 2, 2, 4, 1, 1, 0, 1),
+    (0, 2, 6, 70, 4, 2, 1, 2), (0, 3, 3, 5, 3, 8, 0, 2), (0, 1, 33, 32, 2, 1, 0, 0), (1, 2, 4, 6, 3, 2, 1, 1)])
+def test_layer_gradients_vs_oracle(ops, dev, lvl, B, Fin, Fout, K, p, pool_kind, bias):
+    L = levels()[lvl]
+    M = L.shape[0]
+    g = ops.Graph(L, dev)
+    rs = np.random.RandomState(11 * lvl + Fout)
+    x = rs.randn(B, M, Fin).astype(np.float32)
+    W = (rs.randn(Fin * K, Fout) * 0.3).astype(np.float32)
+    if bias == 1:
+        b = (rs.randn(1, 1, Fout) * 0.5).astype(np.float32)
+    elif bias == 2:
+        b = (rs.randn(1, M, Fout) * 0.5).astype(np.float32)
+    else:
+        b = np.zeros((1, 1, Fout), np.float32)
+    relu = bias != 0
+    # oracle
+    y, T = R.chebyshev5_fwd(x, L, W, K, return_stack=True)
+    a = R.brelu_fwd(y, b) if relu else y + b
+    if pool_kind == 0:
+        o, arg = R.mpool1_fwd(a, p)
+    else:
+        o, arg = R.apool1_fwd(a, p), None
+    do = rs.randn(*o.shape).astype(np.float32)
+    da = R.mpool1_bwd(do, arg, p, M) if pool_kind == 0 else (np.repeat(do, p, axis=1) / p if p > 1 else do)
+    if relu:
+        dy, db = R.brelu_bwd(da, a, b.shape)
+    else:
+        dy, db = da, None
+    dx_ref, dW_ref = R.chebyshev5_bwd(dy.astype(np.float32), L, W, K, T)
+    # HIP
+    xs = to_storage(ops, x, dev).requires_grad_(True)
+    Wd = torch.as_tensor(W).to(dev).requires_grad_(True)
+    if bias == 1:
+        bd = torch.as_tensor(b.reshape(-1)).to(dev).requires_grad_(True)
+        kind = ops.BIAS_FILTER
+    elif bias == 2:
+        bd = torch.zeros((Fout, g.Mp), device=dev)
+        bd[:, :M] = torch.as_tensor(b[0].T.copy()).to(dev)
+        bd.requires_grad_(True)
+        kind = ops.BIAS_VERTEX
+    else:
+        bd, kind = None, ops.BIAS_NONE
+    out = ops.cheb_conv(xs, Wd, bd, g, K, pool=p, pool_kind=pool_kind, relu=relu, bias_kind=kind)
+    close(from_storage(out.detach(), M // p), o, what='out')
+    gout = torch.full(out.shape, float('nan'), device=dev)
+    gout[:, :, :M // p] = torch.as_tensor(np.ascontiguousarray(do.transpose(0, 2, 1))).to(dev)
+    out.backward(gout)
+    close(from_storage(xs.grad, M), dx_ref, what='dx', rel=2e-5)
+    close(Wd.grad.cpu().numpy(), dW_ref, what='dW', rel=2e-5)
+    if bias == 1:
+        close(bd.grad.cpu().numpy(), db.reshape(-1), what='db1', rel=2e-5)
+    elif bias == 2:
+        close(bd.grad[:, :M].t().cpu().numpy(), db[0], what='db2')
+        assert float(bd.grad[:, M:].abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------
+# staging, head, optimizer
+# ---------------------------------------------------------------------------------------
+
+def test_perm_data_bit_exact(ops, dev):
+    z = load_golden('coarsen_n212')
+    x3, perm = z['pd_x3'], z['perm']
+    ref = z['pd_y3']                                                      # float64 [S, M, F]
+    xd = torch.as_tensor(x3).to(dev)
+    pd = torch.as_tensor(perm.astype(np.int32)).to(dev)
+    out = ops.perm_data(xd, pd)
+    M = len(perm)
+    assert np.array_equal(from_storage(out, M).astype(np.float64), ref)
+    assert float(out[:, :, M:].abs().sum()) == 0.0
+    smp = torch.as_tensor(np.array([2, 0, 2], np.int32)).to(dev)
+    out2 = ops.perm_data(xd, pd, smp)
+    assert np.array_equal(from_storage(out2, M).astype(np.float64), ref[[2, 0, 2]])
+    # layout round trip
+    back = ops.from_plane(out, M)
+    assert np.array_equal(back.cpu().numpy().astype(np.float64), ref)
+    assert torch.equal(ops.plane_storage(back)[:, :, :M], out[:, :, :M])
+    assert ops.plane_storage(ops.plane_view(out, M)).data_ptr() == out.data_ptr()
+
+
+def test_feature_mean_and_adam(ops, dev):
+    rs = np.random.RandomState(3)
+    x = rs.randn(3, 50, 7).astype(np.float32)
+    xs = to_storage(ops, x, dev).requires_grad_(True)
+    y = ops.FeatureMean.apply(xs, 50)
+    close(y.detach().cpu().numpy(), x.mean(-1), what='mean')
+    gy = rs.randn(3, 50).astype(np.float32)
+    y.backward(torch.as_tensor(gy).to(dev))
+    close(from_storage(xs.grad, 50), np.repeat(gy[:, :, None] / 7, 7, axis=2), what='dmean')
+    # Adam (TF form) with L2 folded into the gradient
+    p0 = rs.randn(1000).astype(np.float32)
+    params, state = {'w': p0.copy()}, {}
+    p = torch.as_tensor(p0.copy()).to(dev)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for t in range(1, 4):
+        g = rs.randn(1000).astype(np.float32)
+        R.adam_tf_step(params, {'w': 0.5 * g + 5e-4 * params['w']}, state)
+        lr_t = 0.001 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam_step(p, torch.as_tensor(g).to(dev), m, v, lr_t, grad_scale=0.5, l2=5e-4)
+        close(p.cpu().numpy(), params['w'], what='adam step %d' % t)
+
+
+# ---------------------------------------------------------------------------------------
+# whole network through the cgcnn drop-in
+# ---------------------------------------------------------------------------------------
+
+def build_model(z, dev, **kw):
+    from gcn_fmri_decoding_amd import models_gcn
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    net = models_gcn.cgcnn({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                           channel=int(z['channel']), brelu=str(z['brelu']), batch_size=int(z['x'].shape[0]),
+                           verbose=False, **kw)
+    params = {k[len('param:'):]: z[k] for k in z.files if k.startswith('param:')}
+    for k, v in params.items():
+        net.set_variable(k, v)
+    return net, Ls, params
+
+
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512'])
+def test_inference_vs_reference_vectors(ops, dev, name):
+    z = load_golden(name)
+    net, Ls, params = build_model(z, dev)
+    assert {k: tuple(net.variable(k).shape) for k in net.variables()} == {k: v.shape for k, v in params.items()}
+    x = torch.as_tensor(z['x']).to(dev)
+    with torch.no_grad():
+        logits = net.inference(x, 1)
+    close(logits.cpu().numpy(), z['logits'], rel=2e-5, what='logits')
+    # string-dispatched, unfused layer methods (a subclass overriding one of them switches
+    # the fused fast path off) give the same logits
+    from gcn_fmri_decoding_amd import models_gcn
+
+    class Unfused(models_gcn.cgcnn):
+        def mpool1(self, x, p):
+            return super().mpool1(x, p)
+
+    net2 = Unfused({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                   channel=int(z['channel']), brelu=str(z['brelu']), batch_size=int(z['x'].shape[0]), verbose=False)
+    assert net._fusable() and not net2._fusable()
+    for k, v in params.items():
+        net2.set_variable(k, v)
+    with torch.no_grad():
+        logits2 = net2.inference(x, 1)
+    close(logits2.cpu().numpy(), logits.cpu().numpy(), rel=1e-6, what='unfused logits')
+
+
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212'])
+def test_train_step_vs_oracle(ops, dev, name):
+    """Gradients of the full network and three TF-form Adam steps against the oracle."""
+    z = load_golden(name)
+    reg = 5e-4
+    net, Ls, params = build_model(z, dev, regularization=reg, dropout=1)
+    onet = R.Net(Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(), channel=int(z['channel']),
+                 brelu=str(z['brelu']), regularization=reg)
+    params = {k: v.copy() for k, v in params.items()}
+    x = z['x']
+    labels = np.arange(x.shape[0]) % int(z['M'][-1])
+    xs = to_storage(ops, x, dev)
+    ld = torch.as_tensor(labels).to(dev)
+    state = {}
+    for step in range(3):
+        logits, cache = onet.forward(params, x)
+        loss, dlogits = onet.loss(params, logits, labels)
+        grads = onet.backward(params, cache, dlogits)
+        _, loss_avg = net.train_step(xs, ld)
+        if step == 0:
+            for k in params:                                   # net._grad holds d(CE); add the L2 part
+                gk = net._params[k].grad
+                ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
+                got = net_grad_in_ref_shape(net, k)
+                close(got, ref, rel=5e-5, what='grad ' + k)
+            assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
+        R.adam_tf_step(params, grads, state)
+        for k in params:
+            close(net.get_var(k), params[k], rel=2e-5, what='step %d %s' % (step, k))
+
+
+def net_grad_in_ref_shape(net, name):
+    spec = next(s for s in net._spec_list if s.name == name)
+    g = net._params[name].grad
+    if spec.group == 'convb':
+        if len(spec.shape) == 2:
+            return g[:, :spec.ref_shape[1]].t().unsqueeze(0).cpu().numpy()
+        return g.view(spec.ref_shape).cpu().numpy()
+    return g.cpu().numpy()
+
+
+def test_predict_evaluate_fit_smoke(ops, dev, tmp_path, monkeypatch):
+    """fit / evaluate / predict call contract (models_gcn.py:31-184) on a tiny problem."""
+    monkeypatch.setenv('CHEBGCN_HOME', str(tmp_path))
+    z = load_golden('inference_pool_n212')
+    net, Ls, _ = build_model(z, dev, num_epochs=3, eval_frequency=2, dir_name='t', dropout=0.5, regularization=5e-4)
+    M0 = Ls[0].shape[0]
+    rs = np.random.RandomState(0)
+    S = 3 * 7 + 1
+    data = rs.randn(S, M0, int(z['channel']))                    # float64 like perm_data_3d output
+    labels = rs.randint(0, int(z['M'][-1]), S)
+    np.random.seed(0)
+    acc, losses, t_step = net.fit(data, labels, data[:5], labels[:5])
+    assert len(acc) == len(losses) and t_step > 0 and net.global_step == int(3 * S / 3)
+    pred = net.predict(data)
+    assert pred.shape == (S,)
+    pred2, loss = net.predict(data, labels)
+    assert np.array_equal(pred, pred2) and np.isfinite(loss)
+    string, accuracy, f1, loss2 = net.evaluate(data, labels)
+    assert 0 <= accuracy <= 100 and 'accuracy' in string
+
+
+def test_missing_gpu_path_fails_loudly(ops):
+    from gcn_fmri_decoding_amd import _lib
+    with pytest.raises(_lib.ChebgcnError):
+        ops.cheb_conv(torch.zeros(1, 1, 32), torch.zeros(1, 1), None, None, 1)
