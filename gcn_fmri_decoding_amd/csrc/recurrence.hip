@@ -9,159 +9,297 @@
 // under the recurrence, so a workgroup owns TWO planes (one float2 per vertex) and
 // runs all K-1 steps for them on chip:
 //   * T_{k-1} of both planes lives in LDS (8 B per vertex; the gather source),
-//   * T_{k-2} and the freshly computed T_k of the rows a thread owns live in VGPRs,
+//   * T_{k-2}, overwritten in place by the freshly computed T_k, of the rows a thread owns
+//     lives in VGPRs,
 //   * HBM sees each plane exactly once per slab: x is read once, every T_k written once
 //     (compulsory traffic 4*M*Fin*K bytes per window instead of 4*M*Fin*(3K-4) for a
 //     kernel-per-step SpMM).
 // The operator comes as a length-sorted sliced ELL (graph.hip): the 64 rows handled by
 // one wave have (nearly) equal length, so the slot loop has a wave-uniform trip count
-// and no divergence; column/value loads are coalesced 128 B / 256 B per wave.
+// and no divergence; column/value loads are coalesced 128 B / 256 B per wave.  All
+// operator entries of a group are requested before the first LDS gather so that one L2
+// round trip covers the whole group.
 // Because rows are handed to lanes in length order, results are scattered back into the
 // LDS image and streamed out linearly, which keeps every HBM access fully coalesced.
+// Software pipeline (one workgroup per CU, so nothing else hides latency):
+//   * the linear copy-out of T_{k-1} (LDS -> HBM) is interleaved with the gather of step k,
+//     each piece issued right after a group's operator loads so that later waits on those
+//     loads never cover the stores;
+//   * in the adjoint, the G_j planes needed after the gather are requested the same way;
+//   * the next plane pair's input is requested before the final copy-out of the current one.
 #include "common.h"
 
 namespace chebgcn {
 
+int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
+
 struct EllView {
-    const int32_t* goff;
-    const uint16_t* col16;
-    const float* val;
-    const int32_t* rowid;
-    int ngroups;
+    const int2* ginfo;
+    const uint2* colq;
+    const float4* valq;
+    const uint16_t* rowslot;
+    const uint16_t* nodeslot;
+    int ngroups, zero_slot;
 };
 
-static inline EllView view(const Ell& e) { return EllView{e.goff, e.col16, e.val, e.rowid, e.ngroups}; }
+static inline EllView view(const Ell& e) {
+    return EllView{e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
+}
 
-// One workgroup = all rows x 2 planes.  NJ = row slices per thread (ceil(ngroups*64 / blockDim)).
-template <int NJ, bool ADJ>
-__global__ void __launch_bounds__(1024)
+constexpr int QMAX = 3;      // quads (4 operator entries each) requested ahead per group
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// i-th 16-bit slot id of a packed quad
+__device__ __forceinline__ unsigned slot_of(uint2 c, int i) {
+    const unsigned w = (i & 2) ? c.y : c.x;
+    return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+__device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// operator entries of one 64-row group, as requested from L2
+struct Ops {
+    uint2 c[QMAX];
+    float4 v[QMAX];
+    int len;                 // even length of the group (wave-uniform), 0 if the group does not exist
+    int qoff;
+};
+
+// One workgroup = all rows x 2 planes.  NJ = row slices per thread (ceil(ngroups*64 / blockDim)),
+// NQ = 16-byte linear pieces per thread and plane (ceil(Mp/4 / blockDim) <= ceil(NJ/4)).
+template <int NJ, int NTHR, bool ADJ>
+__global__ void __launch_bounds__(NTHR)
 cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst,
-                   int M, int Mp, int nplanes, int K, size_t slab, int copy_t0) {
-    extern __shared__ __attribute__((aligned(16))) float2 T[];   // [Mp + 4]; T[M..] == 0
+                   int M, int Mp, int nplanes, int K, size_t slab, int flags, int lds_entries) {
+    extern __shared__ __attribute__((aligned(16))) float2 T[];   // [lds_entries] slot-indexed image, then tables
+    constexpr int NQ = (NJ + 3) / 4;
+    const int copy_t0 = flags & 1;
+    // ablation bits for tools/kbench.py (always 0 in production):
+    // 1 = no global stores, 2 = no gather, 16 = no global loads, 32 = stagger start (x (abl>>6)&7)
+    const int abl = flags >> 8;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int nthr = blockDim.x;
+    constexpr int nthr = NTHR;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwaves = nthr >> 6;
-    const int Mq = Mp >> 2;                                       // float4 groups per plane
+    constexpr int nwaves = NTHR >> 6;
+    const int Mq = Mp >> 2;                                       // float4 pieces per plane
     const int npairs = (nplanes + 1) >> 1;
+    const float2 zero2 = make_float2(0.f, 0.f);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    int row[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        int g = j * nwaves + wave;
-        row[j] = (g < e.ngroups) ? e.rowid[g * 64 + lane] : -1;
+    // Index tables, copied into LDS once per workgroup (they would cost ~12 VGPRs otherwise):
+    //   rs[g*64 + lane] = LDS slot of the row that lane owns in group g (0xFFFF = none)
+    //   nsq[q]          = LDS slots of vertices 4q..4q+3 (4 x 16 bit; 0xFFFF = pad)
+    uint16_t* rs = reinterpret_cast<uint16_t*>(T + lds_entries);
+    uint2* nsq = reinterpret_cast<uint2*>(rs + e.ngroups * 64);
+    for (int i = tid; i < e.ngroups * 32; i += nthr)
+        reinterpret_cast<unsigned*>(rs)[i] = reinterpret_cast<const unsigned*>(e.rowslot)[i];
+    for (int q = tid; q < Mq; q += nthr) nsq[q] = reinterpret_cast<const uint2*>(e.nodeslot)[q];
+    if (tid == 0) T[e.zero_slot] = zero2;     // never written again
+    __syncthreads();
+    // De-correlate the CUs of an XCD (blockIdx % 8 selects the XCD): every workgroup streams the
+    // same operator image from L2; started in lock-step they all hit the same L2 channel at the
+    // same time.  A one-off stagger spreads them over one step's worth of time.
+    if (abl & 32) {
+        const int k = (blockIdx.x >> 3) & 31;
+        const int reps = k * (1 + ((abl >> 6) & 7));      // x ~0.3 us each
+        for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
     }
 
-    for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    // linear staging registers: next pair's input (both modes), G_j of the adjoint
+    float4 pa[NQ], pb[NQ];
+
+    auto fetch = [&](const float* a, const float* b) {           // request 2 planes, linear
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int q = tid + u * nthr;
+            pa[u] = zero4;
+            pb[u] = zero4;
+            if (q < Mq && !(abl & 16)) {
+                pa[u] = ldg4(a + 4 * q);
+                pb[u] = ldg4(b + 4 * q);
+            }
+        }
+    };
+    auto copy_out_piece = [&](int u, float* o0, float* o1, bool has1) {   // LDS -> 2 planes
+        const int q = tid + u * nthr;
+        if (q < Mq && !(abl & 1)) {
+            float2 t[4];
+            const uint2 nq = nsq[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned sl = slot_of(nq, i);
+                t[i] = (sl != 0xFFFFu) ? T[sl] : zero2;
+            }
+            stg4(o0 + 4 * q, make_float4(t[0].x, t[1].x, t[2].x, t[3].x));
+            if (has1) stg4(o1 + 4 * q, make_float4(t[0].y, t[1].y, t[2].y, t[3].y));
+        }
+    };
+    auto load_ops = [&](Ops& o, int g) {
+        o.len = 0;
+        o.qoff = 0;
+        if (g < e.ngroups && !(abl & 2)) {
+            const int2 gi = e.ginfo[g];
+            o.qoff = gi.x;
+            o.len = gi.y;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+                if (4 * q < gi.y) {
+                    o.c[q] = e.colq[(size_t)(gi.x + q) * 64 + lane];
+                    o.v[q] = e.valq[(size_t)(gi.x + q) * 64 + lane];
+                }
+        }
+    };
+    auto pair_fma = [&](float2& acc, uint2 c, float4 v, int i) {   // entries i, i+1 of a quad
+        const float2 t0 = T[slot_of(c, i)], t1 = T[slot_of(c, i + 1)];
+        const float v0 = comp(v, i), v1 = comp(v, i + 1);
+        acc.x = fmaf(v0, t0.x, acc.x); acc.y = fmaf(v0, t0.y, acc.y);
+        acc.x = fmaf(v1, t1.x, acc.x); acc.y = fmaf(v1, t1.y, acc.y);
+    };
+    auto consume = [&](const Ops& o) -> float2 {
+        float2 acc = zero2;
+        const int len = o.len;
+        if (len >= 8) {                                   // the common case: one batch of eight
+            float2 t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = T[slot_of(o.c[i >> 2], i & 3)];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float vv = comp(o.v[i >> 2], i & 3);
+                acc.x = fmaf(vv, t[i].x, acc.x); acc.y = fmaf(vv, t[i].y, acc.y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i += 2)
+                if (i < len) pair_fma(acc, o.c[i >> 2], o.v[i >> 2], i & 3);
+        }
+#pragma unroll
+        for (int i = 8; i < 4 * QMAX; i += 2)
+            if (i < len) pair_fma(acc, o.c[i >> 2], o.v[i >> 2], i & 3);
+        for (int q = QMAX; 4 * q < len; ++q) {            // rows longer than 4*QMAX entries (rare)
+            const uint2 c = e.colq[(size_t)(o.qoff + q) * 64 + lane];
+            const float4 v = e.valq[(size_t)(o.qoff + q) * 64 + lane];
+            pair_fma(acc, c, v, 0);
+            if (4 * q + 2 < len) pair_fma(acc, c, v, 2);
+        }
+        return acc;
+    };
+
+    int pair = blockIdx.x;
+    if (pair < npairs) {
+        const size_t base = ADJ ? (size_t)(K - 1) * slab : 0;
+        const int p0 = 2 * pair, p1 = (p0 + 1 < nplanes) ? p0 + 1 : p0;
+        fetch(src + base + (size_t)p0 * Mp, src + base + (size_t)p1 * Mp);
+    }
+    for (; pair < npairs; pair += gridDim.x) {
         const int p0 = 2 * pair;
         const bool has1 = (p0 + 1) < nplanes;
         const int p1 = has1 ? p0 + 1 : p0;
-        // fwd: src = x;  adj: src = gstack, start from slab K-1
-        const float* s0 = src + (ADJ ? (size_t)(K - 1) * slab : 0) + (size_t)p0 * Mp;
-        const float* s1 = src + (ADJ ? (size_t)(K - 1) * slab : 0) + (size_t)p1 * Mp;
 
-        __syncthreads();                      // previous pair's LDS reads are done
-        for (int q = tid; q < Mq + 1; q += nthr) {
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        // ---- staged input -> LDS image ----------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int q = tid + u * nthr;
             if (q < Mq) {
-                a = *reinterpret_cast<const float4*>(s0 + 4 * q);
-                b = *reinterpret_cast<const float4*>(s1 + 4 * q);
-            }
-            const int i = 4 * q;
-            T[i + 0] = (i + 0 < M) ? make_float2(a.x, b.x) : make_float2(0.f, 0.f);
-            T[i + 1] = (i + 1 < M) ? make_float2(a.y, b.y) : make_float2(0.f, 0.f);
-            T[i + 2] = (i + 2 < M) ? make_float2(a.z, b.z) : make_float2(0.f, 0.f);
-            T[i + 3] = (i + 3 < M) ? make_float2(a.w, b.w) : make_float2(0.f, 0.f);
-            if (!ADJ && copy_t0 && q < Mq) {
-                *reinterpret_cast<float4*>(dst + (size_t)p0 * Mp + 4 * q) = a;
-                if (has1) *reinterpret_cast<float4*>(dst + (size_t)p1 * Mp + 4 * q) = b;
+                const float4 a = pa[u], b = pb[u];
+                const uint2 nq = nsq[q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned sl = slot_of(nq, i);
+                    if (sl != 0xFFFFu) T[sl] = make_float2(comp(a, i), comp(b, i));
+                }
             }
         }
         __syncthreads();
 
-        float2 tm2[NJ], tnew[NJ];
+        float2 st[NJ];                        // T_{k-2} of the own rows, replaced by T_k in place
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) tm2[j] = make_float2(0.f, 0.f);
+        for (int j = 0; j < NJ; ++j) st[j] = zero2;
 
         for (int step = 1; step < K; ++step) {
             const float f = ADJ ? (step == K - 1 ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
-            // ---- gather: acc = (L T_{k-1})[own rows] -------------------------------------
+            // linear traffic interleaved with this step's gather
+            const bool do_out = !ADJ && (step > 1 || copy_t0);    // forward: write T_{step-1}
+            float* o0 = dst + (size_t)(step - 1) * slab + (size_t)p0 * Mp;
+            float* o1 = dst + (size_t)(step - 1) * slab + (size_t)p1 * Mp;
+            const float* g0 = src + (size_t)(K - 1 - step) * slab + (size_t)p0 * Mp;   // adjoint: G_j
+            const float* g1 = src + (size_t)(K - 1 - step) * slab + (size_t)p1 * Mp;
+
+            // ---- gather: st <- f * (L T_{k-1})[own rows] - st ---------------------------------
+            // the operator entries of group j+1 are requested before group j is consumed
+            Ops ops[2];
+            load_ops(ops[0], wave);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int g = j * nwaves + wave;            // wave-uniform
-                float2 acc = make_float2(0.f, 0.f);
-                if (g < e.ngroups) {
-                    const int off = e.goff[g];
-                    const int len = e.goff[g + 1] - off;
-                    const uint16_t* cp = e.col16 + (size_t)off * 64 + lane;
-                    const float* vp = e.val + (size_t)off * 64 + lane;
-                    int s = 0;
-                    for (; s + 4 <= len; s += 4) {
-                        const int c0 = cp[(s + 0) * 64], c1 = cp[(s + 1) * 64];
-                        const int c2 = cp[(s + 2) * 64], c3 = cp[(s + 3) * 64];
-                        const float v0 = vp[(s + 0) * 64], v1 = vp[(s + 1) * 64];
-                        const float v2 = vp[(s + 2) * 64], v3 = vp[(s + 3) * 64];
-                        const float2 t0 = T[c0], t1 = T[c1], t2 = T[c2], t3 = T[c3];
-                        acc.x = fmaf(v0, t0.x, acc.x); acc.y = fmaf(v0, t0.y, acc.y);
-                        acc.x = fmaf(v1, t1.x, acc.x); acc.y = fmaf(v1, t1.y, acc.y);
-                        acc.x = fmaf(v2, t2.x, acc.x); acc.y = fmaf(v2, t2.y, acc.y);
-                        acc.x = fmaf(v3, t3.x, acc.x); acc.y = fmaf(v3, t3.y, acc.y);
-                    }
-                    for (; s < len; ++s) {
-                        const int c0 = cp[s * 64];
-                        const float v0 = vp[s * 64];
-                        const float2 t0 = T[c0];
-                        acc.x = fmaf(v0, t0.x, acc.x); acc.y = fmaf(v0, t0.y, acc.y);
+                if (j + 1 < NJ) load_ops(ops[(j + 1) & 1], (j + 1) * nwaves + wave);
+                if ((j & 3) == 0 && (j >> 2) < NQ) {       // one linear piece per four groups
+                    const int u = j >> 2;
+                    if (ADJ) {
+                        const int q = tid + u * nthr;
+                        pa[u] = zero4;
+                        pb[u] = zero4;
+                        if (q < Mq && !(abl & 16)) {
+                            pa[u] = ldg4(g0 + 4 * q);
+                            pb[u] = ldg4(g1 + 4 * q);
+                        }
+                    } else if (do_out) {
+                        copy_out_piece(u, o0, o1, has1);
                     }
                 }
-                tnew[j].x = fmaf(f, acc.x, -tm2[j].x);
-                tnew[j].y = fmaf(f, acc.y, -tm2[j].y);
+                const float2 acc = consume(ops[j & 1]);
+                st[j].x = fmaf(f, acc.x, -st[j].x);
+                st[j].y = fmaf(f, acc.y, -st[j].y);
+                __builtin_amdgcn_sched_barrier(0);          // keep the prefetch distance at one group
             }
-            __syncthreads();                  // every gather of this step has read LDS
+            __syncthreads();                  // every gather (and copy-out read) of this step is done
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (row[j] >= 0) {
-                    tm2[j] = T[row[j]];
-                    T[row[j]] = tnew[j];
+                const int g = j * nwaves + wave;
+                const unsigned r = (g < e.ngroups) ? rs[g * 64 + lane] : 0xFFFFu;
+                if (r != 0xFFFFu) {
+                    const float2 old = T[r];
+                    T[r] = st[j];
+                    st[j] = old;
                 }
             }
             __syncthreads();
-            if (!ADJ) {
-                // ---- stream T_k out, linear and coalesced ---------------------------------
-                float* o0 = dst + (size_t)step * slab + (size_t)p0 * Mp;
-                float* o1 = dst + (size_t)step * slab + (size_t)p1 * Mp;
-                for (int q = tid; q < Mq; q += nthr) {
-                    const float2 t0 = T[4 * q], t1 = T[4 * q + 1], t2 = T[4 * q + 2], t3 = T[4 * q + 3];
-                    *reinterpret_cast<float4*>(o0 + 4 * q) = make_float4(t0.x, t1.x, t2.x, t3.x);
-                    if (has1) *reinterpret_cast<float4*>(o1 + 4 * q) = make_float4(t0.y, t1.y, t2.y, t3.y);
-                }
-            } else {
-                // ---- c_j += G_j, linear and coalesced -------------------------------------
-                const float* g0 = src + (size_t)(K - 1 - step) * slab + (size_t)p0 * Mp;
-                const float* g1 = src + (size_t)(K - 1 - step) * slab + (size_t)p1 * Mp;
-                for (int q = tid; q < Mq; q += nthr) {
-                    const float4 a = *reinterpret_cast<const float4*>(g0 + 4 * q);
-                    const float4 b = *reinterpret_cast<const float4*>(g1 + 4 * q);
-                    const int i = 4 * q;
-                    if (i + 0 < M) { float2 t = T[i + 0]; T[i + 0] = make_float2(t.x + a.x, t.y + b.x); }
-                    if (i + 1 < M) { float2 t = T[i + 1]; T[i + 1] = make_float2(t.x + a.y, t.y + b.y); }
-                    if (i + 2 < M) { float2 t = T[i + 2]; T[i + 2] = make_float2(t.x + a.z, t.y + b.z); }
-                    if (i + 3 < M) { float2 t = T[i + 3]; T[i + 3] = make_float2(t.x + a.w, t.y + b.w); }
+            if (ADJ) {
+                // ---- c_j += G_j, linear --------------------------------------------------------
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const int q = tid + u * nthr;
+                    if (q < Mq) {
+                        const float4 a = pa[u], b = pb[u];
+                        const uint2 nq = nsq[q];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned sl = slot_of(nq, i);
+                            if (sl != 0xFFFFu) {
+                                const float2 t = T[sl];
+                                T[sl] = make_float2(t.x + comp(a, i), t.y + comp(b, i));
+                            }
+                        }
+                    }
                 }
                 __syncthreads();
             }
         }
-        if (ADJ) {
-            float* o0 = dst + (size_t)p0 * Mp;
-            float* o1 = dst + (size_t)p1 * Mp;
-            for (int q = tid; q < Mq; q += nthr) {
-                const float2 t0 = T[4 * q], t1 = T[4 * q + 1], t2 = T[4 * q + 2], t3 = T[4 * q + 3];
-                *reinterpret_cast<float4*>(o0 + 4 * q) = make_float4(t0.x, t1.x, t2.x, t3.x);
-                if (has1) *reinterpret_cast<float4*>(o1 + 4 * q) = make_float4(t0.y, t1.y, t2.y, t3.y);
-            }
+
+        // ---- request the next pair's input, then stream the last image out -----------------
+        const int npair = pair + gridDim.x;
+        if (npair < npairs) {
+            const size_t base = ADJ ? (size_t)(K - 1) * slab : 0;
+            const int q0 = 2 * npair, q1 = (q0 + 1 < nplanes) ? q0 + 1 : q0;
+            fetch(src + base + (size_t)q0 * Mp, src + base + (size_t)q1 * Mp);
         }
+        {
+            float* o0 = dst + (ADJ ? 0 : (size_t)(K - 1) * slab) + (size_t)p0 * Mp;
+            float* o1 = dst + (ADJ ? 0 : (size_t)(K - 1) * slab) + (size_t)p1 * Mp;
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) copy_out_piece(u, o0, o1, has1);
+        }
+        __syncthreads();                      // LDS reads done before the image is overwritten
     }
 }
 
@@ -183,36 +321,43 @@ cheb_step_global_kernel(const int32_t* __restrict__ rowptr, const int32_t* __res
     out[plane + r] = v;
 }
 
-template <int NJ, bool ADJ>
+template <int NJ, int NTHR, bool ADJ>
 static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst,
-                         int nplanes, int K, int copy_t0, int nthr, hipStream_t stream) {
-    const size_t lds = (size_t)(g->Mp + 4) * sizeof(float2);
-    auto kern = cheb_onchip_kernel<NJ, ADJ>;
+                         int nplanes, int K, int copy_t0, hipStream_t stream) {
+    const size_t lds = (size_t)ell.lds_entries * sizeof(float2) + (size_t)ell.ngroups * 64 * 2 + (size_t)(g->Mp / 4) * 8;
+    auto kern = cheb_onchip_kernel<NJ, NTHR, ADJ>;
     CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : per_cu;
-    if (per_cu > 2048 / nthr) per_cu = 2048 / nthr;
+    if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
     if (per_cu > 8) per_cu = 8;
     const int npairs = (nplanes + 1) / 2;
     int grid = g->num_cus * per_cu;
     if (grid > npairs) grid = npairs;
     const size_t slab = (size_t)nplanes * g->Mp;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(nthr), lds, stream, view(ell), src, dst, g->M, g->Mp,
-                       nplanes, K, slab, copy_t0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, stream, view(ell), src, dst, g->M, g->Mp,
+                       nplanes, K, slab, copy_t0 | (g_ablate << 8), ell.lds_entries);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
 
+// Workgroup shape: as many waves as the register budget allows.  Per thread the kernel keeps
+// 2 VGPRs per row slice (NJ) and 8 per linear piece (NQ = ceil(NJ/4)) next to ~80 for the
+// operator prefetch and temporaries; 1024 / 768 / 512 threads may use 128 / 168 / 256 VGPRs.
 template <bool ADJ>
 static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K,
                            int copy_t0, hipStream_t stream) {
     const Ell& ell = ADJ ? g->adj : g->fwd;
-    const int nthr = g->M <= 2048 ? 256 : (g->M <= 4096 ? 512 : 1024);
-    const int nj = (ell.ngroups * 64 + nthr - 1) / nthr;
-#define CG_CASE(N) if (nj <= N) return launch_onchip<N, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, nthr, stream)
-    CG_CASE(1); CG_CASE(2); CG_CASE(4); CG_CASE(6); CG_CASE(8); CG_CASE(12); CG_CASE(16); CG_CASE(20);
-#undef CG_CASE
-    return fail(CHEBGCN_EUNSUPPORTED, "recurrence: %d row slices per thread", nj);
+    const int rows = ell.ngroups * 64;
+    const int Mq = g->Mp / 4;
+    auto fits = [&](int nj, int nthr) { return nj * nthr >= rows && ((nj + 3) / 4) * nthr >= Mq; };
+#define CG_TRY(NJ, NTHR) if (fits(NJ, NTHR)) return launch_onchip<NJ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
+    CG_TRY(1, 256); CG_TRY(2, 256); CG_TRY(4, 256); CG_TRY(8, 256);      // M <= 2048
+    CG_TRY(8, 512); CG_TRY(8, 1024);                                        // M <= 8192
+    CG_TRY(11, 768); CG_TRY(14, 768);                                       // M <= 10752
+    CG_TRY(24, 512); CG_TRY(32, 512); CG_TRY(40, 512);                      // M <= 20480
+#undef CG_TRY
+    return fail(CHEBGCN_EUNSUPPORTED, "recurrence: no kernel shape for %d rows", rows);
 }
 
 static int step_global(const chebgcn_graph* g, const Ell& ell, const float* src, const float* sub,
@@ -227,6 +372,12 @@ static int step_global(const chebgcn_graph* g, const Ell& ell, const float* src,
 }  // namespace chebgcn
 
 using namespace chebgcn;
+
+// Undeclared tuning hook for tools/kbench.py (not part of the ABI in include/chebgcn.h).
+extern "C" int chebgcn_tune(int key, int value) {
+    if (key == 0) { g_ablate = value; return 0; }
+    return -1;
+}
 
 extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, float* stack, int B,
                                       int Fin, int K, chebgcn_stream stream_) {

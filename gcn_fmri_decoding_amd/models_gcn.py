@@ -317,11 +317,12 @@ class base_model(object):
         grad_scale = 1.0
         if self._dp is not None:
             grad_scale = self._dp.finish_step()
+        with torch.no_grad():       # the loss of this step is evaluated on the pre-update variables
+            loss = cross_entropy.detach() + self.regularization * self.regularization_term()
         self._apply_adam(grad_scale)
         reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
         self.global_step += 1
         with torch.no_grad():
-            loss = cross_entropy.detach() + self.regularization * self.regularization_term()
             # tf.train.ExponentialMovingAverage(0.9) over a Tensor: zero-initialised shadow,
             # zero-debiased on read (:269-275)
             self._loss_ema = 0.1 * loss if self._loss_ema is None else 0.9 * self._loss_ema + 0.1 * loss

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark of libchebgcn.so on the benchmark graph (M = 10466).
+
+    python tools/kbench.py [--B 64 256] [--fin 32] [--fout 32] [--K 5] [--iters 20]
+                           [--kernels recurrence_fwd ...] [--ablate 0 1 2 ...]
+
+Times each C-ABI entry point with HIP events on the launch stream and prints achieved
+algorithmic GB/s (SURVEY.md 8d byte counts) and the fraction of the 8 TB/s HBM roofline.
+``--ablate`` sets the undeclared chebgcn_tune(0, bits) knob of the recurrence kernel
+(1 no stores, 2 no gather, 4 synthetic operator, 8 no LDS reads, 16 no loads).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--B', type=int, nargs='+', default=[64, 256])
+    ap.add_argument('--fin', type=int, default=32)
+    ap.add_argument('--fout', type=int, default=32)
+    ap.add_argument('--K', type=int, default=5)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_bwd', 'contract_fwd',
+                                                     'contract_bwd_w', 'contract_bwd_x', 'brelu_pool_bwd'])
+    ap.add_argument('--ablate', type=int, nargs='+', default=[0])
+    ap.add_argument('--json', default=None)
+    args = ap.parse_args()
+
+    import torch
+    import bench
+    from gcn_fmri_decoding_amd import _lib, ops
+    dev = torch.device('cuda:0')
+    Ls, perm = bench.load_graph(10000, 1, 0, 1, None)
+    g = ops.Graph(Ls[0], dev)
+    lib = _lib.lib()
+    M, Mp = g.M, g.Mp
+    results = []
+
+    def timeit(fn, iters):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for s, e in evs:
+            s.record()
+            fn()
+            e.record()
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in evs)
+        return ms[len(ms) // 2], ms[0]
+
+    for B in args.B:
+        Fin, Fout, K = args.fin, args.fout, args.K
+        torch.manual_seed(0)
+        x = torch.randn(B, Fin, Mp, device=dev)
+        stack = torch.randn(K, B, Fin, Mp, device=dev)
+        gstack = torch.randn(K, B, Fin, Mp, device=dev)
+        dx = torch.empty(B, Fin, Mp, device=dev)
+        W = torch.randn(Fin * K, Fout, device=dev) * 0.1
+        bias = torch.randn(Fout, Mp, device=dev)
+        out = torch.empty(B, Fout, Mp, device=dev)
+        dy = torch.randn(B, Fout, Mp, device=dev)
+        dbias = torch.empty(Fout, Mp, device=dev)
+        dW = torch.empty(Fin * K, Fout, device=dev)
+        ws = torch.empty(lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout), dtype=torch.uint8, device=dev)
+        st = ops._stream()
+        P = ops._p
+        calls = {
+            'recurrence_fwd': (lambda: lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, st),
+                               4.0 * M * Fin * K * B, 0.0),
+            'recurrence_bwd': (lambda: lib.chebgcn_recurrence_bwd(g.handle, P(gstack), P(dx), B, Fin, K, st),
+                               4.0 * M * Fin * (K + 1) * B, 0.0),
+            'contract_fwd': (lambda: lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), 2, P(out), None, B, M, Fin, K, Fout,
+                                                              1, 0, 1, st),
+                             4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_bwd_w': (lambda: lib.chebgcn_contract_bwd_w(P(stack), P(dy), P(dW), P(ws), ws.numel(), B, M, Fin, K,
+                                                                  Fout, st),
+                               4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_bwd_x': (lambda: lib.chebgcn_contract_bwd_x(P(dy), P(W), P(gstack), B, M, Fin, K, Fout, st),
+                               4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'brelu_pool_bwd': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), P(out), None, P(dx) if Fin == Fout else P(out),
+                                                                  P(dbias), 2, B, M, Fout, 1, 0, 1, st),
+                               4.0 * B * Fout * 3 * M, 0.0),
+        }
+        for name in args.kernels:
+            fn, nbytes, flops = calls[name]
+            abls = args.ablate if name.startswith('recurrence') else [0]
+            for abl in abls:
+                lib.chebgcn_tune(0, abl)
+                med, best = timeit(lambda: _lib.check(fn(), name), args.iters)
+                lib.chebgcn_tune(0, 0)
+                r = {'kernel': name, 'B': B, 'Fin': Fin, 'Fout': Fout, 'K': K, 'ablate': abl, 'median_ms': med,
+                     'min_ms': best, 'GBps': nbytes / med / 1e6, 'frac_hbm': nbytes / med / 1e6 / 8000.0,
+                     'TFLOPs': flops / med / 1e9}
+                results.append(r)
+                print('%-16s B=%-4d abl=%-2d  %8.3f ms (min %7.3f)  %7.0f GB/s  %5.1f%% of 8 TB/s  %6.1f TFLOP/s'
+                      % (name, B, abl, med, best, r['GBps'], 100 * r['frac_hbm'], r['TFLOPs']), flush=True)
+    if args.json:
+        with open(args.json, 'w') as f:
+            json.dump(results, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
