@@ -17,28 +17,29 @@ namespace chebgcn {
 inline int plane_stride(int M) { return (M + 31) & ~31; }
 
 // Length-sorted sliced ELL image of one sparse operator (device memory), laid out for the
-// on-chip recurrence kernel.
-//  * Rows are ranked by descending length; rank r lives in group r/64, lane r%64.
-//  * Vertices are renumbered into LDS *slots* by a bank-aware colouring (graph.hip): slot =
-//    colour + 32*index, so vertices gathered by the same half-wave instruction tend to sit in
-//    different LDS bank pairs.  `nodeslot` maps vertex -> slot for the linear passes.
-//  * Group g owns quads [ginfo[g].x, +ceil(len/4)); a quad is 4 consecutive entries of each
-//    of the 64 rows: colq[quad*64 + lane] = 4 packed 16-bit slot ids, valq[...] = 4 values.
-//    ginfo[g].y = the group's length rounded up to even.  Padding entries have val = 0 and
-//    point at `zero_slot`, an LDS entry that always holds 0.
+// on-chip recurrence kernel (recurrence.hip).
+//  * `planes` (P) = planes a workgroup carries through the recurrence at once: 4 when the
+//    LDS image of the ACTIVE vertices fits with 16 B per vertex, else 2 (8 B per vertex).
+//    A vertex is active when its row or its column of the operator is non-empty; with P = 4
+//    only active vertices get an LDS slot (isolated ones obey T_k = -T_{k-2} and are patched
+//    in by the streaming code), with P = 2 every vertex has slot = vertex id.
+//  * Ranked rows (all rows for P = 2, active rows for P = 4) are sorted by descending length;
+//    rank r lives in group r/64, lane r%64.  Group g owns entry slots [goff[g], goff[g+1]),
+//    an even count; entry (s, lane) is at (goff[g] + s)*64 + lane.  Padding entries have
+//    val = 0 and col = zero_slot, an LDS entry that always holds 0.
 struct Ell {
+    int planes = 2;
     int ngroups = 0;
     int max_len = 0;
-    int64_t nquads = 0;
-    int lds_entries = 0;          // float2 entries of the LDS image (incl. zero slot; multiple of 4)
+    int nranked = 0;              // rows handled by the gather
+    int lds_entries = 0;          // P-float entries of the LDS image incl. the zero slot
     int zero_slot = 0;
-    int2* ginfo = nullptr;        // [ngroups] {quad offset, even length}
-    uint2* colq = nullptr;        // [nquads*64]
-    float4* valq = nullptr;       // [nquads*64]
-    uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> slot of that row, 0xFFFF for padding ranks
-    uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> slot, 0xFFFF for i >= M
-    double est_cycles = 0;        // modelled LDS cycles per half-wave gather (1 = conflict free)
-    double est_cycles_naive = 0;  // same with the identity numbering, for reference
+    int64_t nslots = 0;           // sum of group lengths
+    int32_t* goff = nullptr;      // [ngroups+1]
+    uint16_t* col = nullptr;      // [nslots*64]  LDS slot ids
+    float* val = nullptr;         // [nslots*64]
+    uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> LDS slot of that row, 0xFFFF for padding ranks
+    uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> LDS slot, 0xFFFF = none (isolated / pad)
     // plain CSR for the out-of-LDS fallback
     int32_t* rowptr = nullptr;    // [M+1]
     int32_t* col32 = nullptr;     // [nnz]

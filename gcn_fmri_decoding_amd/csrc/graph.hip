@@ -1,5 +1,5 @@
-// Graph handle: uploads the rescaled Laplacian L~ and its transpose as length-sorted,
-// bank-coloured sliced-ELL images (for the on-chip recurrence) plus plain CSR (fallback).
+// Graph handle: uploads the rescaled Laplacian L~ and its transpose as length-sorted
+// sliced-ELL images (for the on-chip recurrence) plus plain CSR (fallback path).
 // Replaces the constant tf.SparseTensor of lib_new/models_gcn.py:593-596.
 #include <algorithm>
 #include <new>
@@ -33,187 +33,81 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 static void free_ell(Ell& e) {
-    void* ptrs[] = {e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
+    void* ptrs[] = {e.goff, e.col, e.val, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
     for (void* p : ptrs) (void)hipFree(p);
     e = Ell();
 }
 
-constexpr int kColours = 32;              // ds_read_b64: 32 bank pairs per half-wave group
 constexpr int kLdsBytes = 160 * 1024;     // LDS per workgroup on gfx950
-constexpr int kMaxEntries = kLdsBytes / 8;
+int g_prefer_planes = 2;                  // chebgcn_tune(1, planes); see graph_create
 
-// Can the LDS image of an M-vertex graph fit at all (perfectly balanced colouring)?
-static bool image_can_fit(int M) {
-    const int P = (M + kColours - 1) / kColours;
-    return M < 65535 && (kColours * P + 4) <= kMaxEntries;
-}
-
-// ---------------------------------------------------------------------------------------
-// Bank-aware vertex colouring.
-// A half-wave ds_read_b64 gather costs one LDS cycle per distinct address on its busiest
-// bank pair; the bank pair of slot s is s % 32.  Every (group, entry, half-wave) defines a set
-// of up to 32 vertices read together; we pick colour[v] in [0, 32) to minimise same-colour
-// pairs inside the sets (a smooth proxy for the max), subject to a per-colour capacity so
-// that the image (32 * max population entries) still fits the 160 KiB LDS.  Deterministic.
-// ---------------------------------------------------------------------------------------
-struct Colouring {
-    std::vector<int> colour;     // per vertex
-    double cycles = 0, cycles_naive = 0;
-};
-
-static double mean_max(const std::vector<std::vector<int>>& sets, const std::vector<char>& has_pad,
-                       const std::vector<int>& colour) {
-    if (sets.empty()) return 1.0;
-    double total = 0;
-    int cnt[kColours];
-    for (size_t s = 0; s < sets.size(); ++s) {
-        memset(cnt, 0, sizeof(cnt));
-        if (has_pad[s]) cnt[0] = 1;                    // the zero slot lives on bank pair 0
-        int mx = has_pad[s] ? 1 : 0;
-        for (int v : sets[s]) mx = std::max(mx, ++cnt[colour[v]]);
-        total += std::max(mx, 1);
-    }
-    return total / sets.size();
-}
-
-static Colouring colour_vertices(int M, const std::vector<std::vector<int>>& sets, const std::vector<char>& has_pad) {
-    Colouring out;
-    out.colour.resize(M);
-    for (int v = 0; v < M; ++v) out.colour[v] = v % kColours;
-    out.cycles_naive = mean_max(sets, has_pad, out.colour);
-    const int even = (M + kColours - 1) / kColours;
-    const int cap = std::min((kMaxEntries - 4) / kColours, std::max(even * 3 / 2, even + 1));
-    std::vector<std::vector<int>> member(M);
-    for (size_t s = 0; s < sets.size(); ++s)
-        for (int v : sets[s]) member[v].push_back((int)s);
-    std::vector<int> cnt(sets.size() * kColours, 0), pop(kColours, 0);
-    for (size_t s = 0; s < sets.size(); ++s) {
-        if (has_pad[s]) cnt[s * kColours] += 1;
-        for (int v : sets[s]) cnt[s * kColours + out.colour[v]] += 1;
-    }
-    for (int v = 0; v < M; ++v) pop[out.colour[v]]++;
-    std::vector<int> order(M);
-    std::iota(order.begin(), order.end(), 0);
-    uint64_t rng = 0x9E3779B97F4A7C15ull;
-    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
-    for (int sweep = 0; sweep < 8; ++sweep) {
-        for (int i = M - 1; i > 0; --i) std::swap(order[i], order[next() % (uint64_t)(i + 1)]);
-        int moved = 0;
-        for (int v : order) {
-            if (member[v].empty()) continue;
-            const int cur = out.colour[v];
-            int score[kColours] = {0};
-            for (int s : member[v]) {
-                const int* c = &cnt[(size_t)s * kColours];
-                for (int k = 0; k < kColours; ++k) score[k] += c[k];
-            }
-            score[cur] -= (int)member[v].size();      // do not count v itself
-            int best = cur;
-            for (int k = 0; k < kColours; ++k) {
-                if (k == cur || pop[k] >= cap) continue;
-                if (score[k] < score[best] || (best != cur && score[k] == score[best] && pop[k] < pop[best])) best = k;
-            }
-            if (best != cur) {
-                for (int s : member[v]) { cnt[(size_t)s * kColours + cur]--; cnt[(size_t)s * kColours + best]++; }
-                pop[cur]--; pop[best]++;
-                out.colour[v] = best;
-                ++moved;
-            }
-        }
-        if (moved == 0) break;
-    }
-    // vertices that are never gathered go to the emptiest colours
-    for (int v = 0; v < M; ++v)
-        if (member[v].empty()) {
-            pop[out.colour[v]]--;
-            const int best = (int)(std::min_element(pop.begin(), pop.end()) - pop.begin());
-            pop[best]++;
-            out.colour[v] = best;
-        }
-    out.cycles = mean_max(sets, has_pad, out.colour);
-    return out;
+// Planes per workgroup for an image of n vertices (+1 zero slot, rounded to 4 entries):
+// 4 if 16 B per vertex fit the LDS, else 2 if 8 B fit, else 0 (no on-chip path).
+static int planes_for(int n) {
+    const size_t entries = ((size_t)n + 1 + 3) & ~(size_t)3;
+    if (n >= 65535) return 0;
+    if (entries * 16 <= (size_t)kLdsBytes) return 4;
+    if (entries * 8 <= (size_t)kLdsBytes) return 2;
+    return 0;
 }
 
 // CSR (host) -> device Ell.  Entry order inside a row is preserved, so the on-chip kernel
 // sums a row in the order the caller gave (ascending column after tf.sparse_reorder in the
-// reference).
-static int build_ell(int M, int Mp, bool on_chip, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,
-                     const std::vector<float>& val, Ell* out) {
+// reference).  `active[v]` marks vertices whose row or column is non-empty.
+static int build_ell(int M, int Mp, int planes, const std::vector<char>& active, const std::vector<int32_t>& rowptr,
+                     const std::vector<int32_t>& col, const std::vector<float>& val, Ell* out) {
     int rc;
     if ((rc = upload(&out->rowptr, rowptr))) return rc;
     if ((rc = upload(&out->col32, col))) return rc;
     if ((rc = upload(&out->cval, val))) return rc;
-    if (!on_chip) return CHEBGCN_OK;
+    out->planes = planes;
+    if (planes == 0) return CHEBGCN_OK;
 
     auto rlen = [&](int r) { return rowptr[r + 1] - rowptr[r]; };
-    std::vector<int32_t> order(M);
-    std::iota(order.begin(), order.end(), 0);
+    // LDS slots: P = 4 keeps only the active vertices (compacted, in vertex order); P = 2 keeps
+    // all of them with slot = vertex id
+    std::vector<uint16_t> nodeslot((size_t)Mp + 4, 0xFFFF);
+    std::vector<int32_t> order;
+    int nslot = 0;
+    for (int v = 0; v < M; ++v)
+        if (planes == 2 || active[v]) {
+            nodeslot[v] = (uint16_t)nslot++;
+            order.push_back(v);
+        }
+    const int zero_slot = nslot;
+    const int lds_entries = (nslot + 1 + 3) & ~3;
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rlen(a) > rlen(b); });
-    const int ngroups = (M + 63) / 64;
-    std::vector<int2> ginfo(ngroups);
+    const int nranked = (int)order.size();
+    const int ngroups = (nranked + 63) / 64;
+    std::vector<int32_t> goff(ngroups + 1, 0);
     int max_len = 0;
-    int64_t nquads = 0;
     for (int g = 0; g < ngroups; ++g) {
         const int len = rlen(order[g * 64]);              // longest row of the group
         max_len = std::max(max_len, len);
-        ginfo[g] = make_int2((int)nquads, (len + 1) & ~1);
-        nquads += (len + 3) / 4;
+        goff[g + 1] = goff[g] + ((len + 1) & ~1);         // even: the kernel gathers in pairs
     }
-    // gather sets for the colouring
-    std::vector<std::vector<int>> sets;
-    std::vector<char> has_pad;
-    for (int g = 0; g < ngroups; ++g) {
-        const int len = rlen(order[g * 64]);
-        for (int s = 0; s < ((len + 1) & ~1); ++s)
-            for (int h = 0; h < 2; ++h) {
-                std::vector<int> nodes;
-                bool pad = false;
-                for (int lane = 32 * h; lane < 32 * h + 32; ++lane) {
-                    const int r = g * 64 + lane;
-                    if (r < M && s < rlen(order[r])) nodes.push_back(col[rowptr[order[r]] + s]);
-                    else pad = true;
-                }
-                std::sort(nodes.begin(), nodes.end());
-                nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
-                sets.push_back(std::move(nodes));
-                has_pad.push_back(pad);
-            }
-    }
-    Colouring cl = colour_vertices(M, sets, has_pad);
-    // slots: colour + 32 * index (index = rank of the vertex inside its colour)
-    std::vector<int> pop(kColours, 0);
-    std::vector<uint16_t> nodeslot((size_t)Mp + 4, 0xFFFF);
-    for (int v = 0; v < M; ++v) nodeslot[v] = (uint16_t)(cl.colour[v] + kColours * pop[cl.colour[v]]++);
-    const int P = *std::max_element(pop.begin(), pop.end());
-    const int zero_slot = kColours * P;                    // bank pair 0, one past the last index
-    const int lds_entries = (zero_slot + 1 + 3) & ~3;
-    if (lds_entries > kMaxEntries) return fail(CHEBGCN_EUNSUPPORTED, "graph_create: LDS image needs %d entries", lds_entries);
-
-    const uint32_t zz = (uint32_t)zero_slot | ((uint32_t)zero_slot << 16);
-    std::vector<uint2> colq((size_t)nquads * 64, make_uint2(zz, zz));
-    std::vector<float4> valq((size_t)nquads * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    const int64_t nslots = goff[ngroups];
+    std::vector<uint16_t> ecol((size_t)nslots * 64, (uint16_t)zero_slot);
+    std::vector<float> eval((size_t)nslots * 64, 0.0f);
     std::vector<uint16_t> rowslot((size_t)ngroups * 64, 0xFFFF);
-    for (int r = 0; r < M; ++r) {
+    for (int r = 0; r < nranked; ++r) {
         const int row = order[r], g = r / 64, lane = r % 64;
         rowslot[r] = nodeslot[row];
+        const size_t base = (size_t)goff[g] * 64 + lane;
         for (int e = rowptr[row], s = 0; e < rowptr[row + 1]; ++e, ++s) {
-            const size_t at = ((size_t)ginfo[g].x + s / 4) * 64 + lane;
-            const uint32_t slot = nodeslot[col[e]];
-            uint32_t* w = (s & 2) ? &colq[at].y : &colq[at].x;
-            *w = (s & 1) ? ((*w & 0x0000FFFFu) | (slot << 16)) : ((*w & 0xFFFF0000u) | slot);
-            (&valq[at].x)[s & 3] = val[e];
+            ecol[base + (size_t)s * 64] = nodeslot[col[e]];   // a gathered vertex is active by definition
+            eval[base + (size_t)s * 64] = val[e];
         }
     }
     out->ngroups = ngroups;
     out->max_len = max_len;
-    out->nquads = nquads;
+    out->nranked = nranked;
     out->lds_entries = lds_entries;
     out->zero_slot = zero_slot;
-    out->est_cycles = cl.cycles;
-    out->est_cycles_naive = cl.cycles_naive;
-    if ((rc = upload(&out->ginfo, ginfo))) return rc;
-    if ((rc = upload(&out->colq, colq))) return rc;
-    if ((rc = upload(&out->valq, valq))) return rc;
+    out->nslots = nslots;
+    if ((rc = upload(&out->goff, goff))) return rc;
+    if ((rc = upload(&out->col, ecol))) return rc;
+    if ((rc = upload(&out->val, eval))) return rc;
     if ((rc = upload(&out->rowslot, rowslot))) return rc;
     if ((rc = upload(&out->nodeslot, nodeslot))) return rc;
     return CHEBGCN_OK;
@@ -253,6 +147,12 @@ extern "C" int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr, c
                 tva[dst] = va[e];
             }
     }
+    std::vector<char> active(M, 0);
+    int nactive = 0;
+    for (int v = 0; v < M; ++v) {
+        active[v] = (rp[v + 1] > rp[v]) || (trp[v + 1] > trp[v]);
+        nactive += active[v];
+    }
     chebgcn_graph* g = new (std::nothrow) chebgcn_graph();
     if (!g) return fail(CHEBGCN_ENOMEM, "graph_create: out of host memory");
     g->M = M;
@@ -264,9 +164,17 @@ extern "C" int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr, c
         return fail(CHEBGCN_EHIP, "graph_create: no HIP device");
     }
     g->num_cus = prop.multiProcessorCount;
-    g->lds_ok = (image_can_fit(M) && (size_t)kLdsBytes <= (size_t)prop.maxSharedMemoryPerMultiProcessor) ? 1 : 0;
-    int rc = build_ell(M, g->Mp, g->lds_ok != 0, rp, ci, va, &g->fwd);
-    if (rc == CHEBGCN_OK) rc = build_ell(M, g->Mp, g->lds_ok != 0, trp, tci, tva, &g->adj);
+    int planes = 0;
+    if ((size_t)kLdsBytes <= (size_t)prop.maxSharedMemoryPerMultiProcessor) {
+        // 2 planes per workgroup keep every vertex on chip; 4 planes (only the active vertices
+        // on chip) halve the operator stream per plane but measured slower on MI355X at
+        // M ~ 10k (fewer waves, register spills), so they are opt-in: chebgcn_tune(1, 4)
+        planes = planes_for(M) >= 2 ? 2 : 0;
+        if (g_prefer_planes == 4 && planes_for(nactive) == 4) planes = 4;
+    }
+    g->lds_ok = planes != 0;
+    int rc = build_ell(M, g->Mp, planes, active, rp, ci, va, &g->fwd);
+    if (rc == CHEBGCN_OK) rc = build_ell(M, g->Mp, planes, active, trp, tci, tva, &g->adj);
     if (rc != CHEBGCN_OK) {
         chebgcn_graph_destroy(g);
         return rc;
@@ -289,11 +197,11 @@ extern "C" int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* va
         case 1: *value = g->nnz; break;
         case 2: *value = g->Mp; break;
         case 3: *value = g->lds_ok; break;
-        case 4: *value = g->fwd.nquads * 4; break;
+        case 4: *value = g->fwd.nslots; break;
         case 5: *value = g->fwd.max_len; break;
-        case 6: *value = (int64_t)(g->fwd.est_cycles * 1000); break;         // milli-cycles per half-wave gather
-        case 7: *value = (int64_t)(g->fwd.est_cycles_naive * 1000); break;
-        case 8: *value = (int64_t)g->fwd.lds_entries * 8; break;             // LDS bytes of the image
+        case 6: *value = g->fwd.planes; break;                               // planes per workgroup (0, 2, 4)
+        case 7: *value = g->fwd.nranked; break;                              // rows in the LDS image
+        case 8: *value = (int64_t)g->fwd.lds_entries * 4 * g->fwd.planes; break;   // LDS bytes of the image
         default: return fail(CHEBGCN_EINVAL, "graph_query: unknown item %d", what);
     }
     return CHEBGCN_OK;

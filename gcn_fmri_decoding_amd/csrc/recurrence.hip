@@ -5,261 +5,303 @@
 //                                              dx = G_0 + L^T c_1 - c_2
 //
 // Data layout: planes.  A plane is one (window, feature) column of the reference's
-// x0[M, Fin*N] matrix: Mp contiguous floats, vertex-fastest.  Planes are independent
-// under the recurrence, so a workgroup owns TWO planes (one float2 per vertex) and
+// x0[M, Fin*N] matrix: Mp contiguous floats, vertex-fastest.  Planes are independent under
+// the recurrence, so a workgroup owns P planes (P = 4 or 2, one P-float entry per vertex) and
 // runs all K-1 steps for them on chip:
-//   * T_{k-1} of both planes lives in LDS (8 B per vertex; the gather source),
+//   * T_{k-1} of the P planes lives in LDS (the gather source),
 //   * T_{k-2}, overwritten in place by the freshly computed T_k, of the rows a thread owns
 //     lives in VGPRs,
 //   * HBM sees each plane exactly once per slab: x is read once, every T_k written once
 //     (compulsory traffic 4*M*Fin*K bytes per window instead of 4*M*Fin*(3K-4) for a
 //     kernel-per-step SpMM).
-// The operator comes as a length-sorted sliced ELL (graph.hip): the 64 rows handled by
-// one wave have (nearly) equal length, so the slot loop has a wave-uniform trip count
-// and no divergence; column/value loads are coalesced 128 B / 256 B per wave.  All
-// operator entries of a group are requested before the first LDS gather so that one L2
-// round trip covers the whole group.
-// Because rows are handed to lanes in length order, results are scattered back into the
-// LDS image and streamed out linearly, which keeps every HBM access fully coalesced.
+// What bounds it: every workgroup re-streams the operator (6 B per entry: 16-bit LDS slot +
+// fp32 value) from L2 once per step -- measured, that stream (not HBM, not LDS) set the pace
+// with 2 planes per workgroup.  More planes per workgroup amortise it, hence P = 4 whenever
+// 16 B per *active* vertex fit the 160 KiB LDS (graph.hip); vertices whose operator row and
+// column are both empty ("fake" vertices added by the coarsening) have no LDS slot: they obey
+// T_k = -T_{k-2} and are patched in while streaming.
+// The operator comes as a length-sorted sliced ELL (graph.hip): the 64 rows handled by one
+// wave have (nearly) equal length, so the entry loop has a wave-uniform trip count and no
+// divergence; column/value loads are coalesced 128 B / 256 B per wave, all of a group's
+// entries are requested before the first LDS gather (one L2 round trip per group), and the
+// gathers are issued in batches of four.
+// Because rows are handed to lanes in length order, results are scattered back into the LDS
+// image and streamed out linearly, which keeps every HBM access fully coalesced.
 // Software pipeline (one workgroup per CU, so nothing else hides latency):
 //   * the linear copy-out of T_{k-1} (LDS -> HBM) is interleaved with the gather of step k,
 //     each piece issued right after a group's operator loads so that later waits on those
 //     loads never cover the stores;
-//   * in the adjoint, the G_j planes needed after the gather are requested the same way;
-//   * the next plane pair's input is requested before the final copy-out of the current one.
+//   * workgroups of one XCD start staggered so that they are in different phases.
 #include "common.h"
 
 namespace chebgcn {
 
 int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
+extern int g_prefer_planes;
 
 struct EllView {
-    const int2* ginfo;
-    const uint2* colq;
-    const float4* valq;
+    const int32_t* goff;
+    const uint16_t* col;
+    const float* val;
     const uint16_t* rowslot;
     const uint16_t* nodeslot;
     int ngroups, zero_slot;
 };
 
 static inline EllView view(const Ell& e) {
-    return EllView{e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
+    return EllView{e.goff, e.col, e.val, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
 }
 
-constexpr int QMAX = 3;      // quads (4 operator entries each) requested ahead per group
+constexpr int RMAX = 12;     // operator entries of a group requested at once (longer rows: extra trips)
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-// i-th 16-bit slot id of a packed quad
-__device__ __forceinline__ unsigned slot_of(uint2 c, int i) {
+__device__ __forceinline__ unsigned slot_of(uint2 c, int i) {        // i-th 16-bit id of a packed quad
     const unsigned w = (i & 2) ? c.y : c.x;
     return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
 }
 __device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ void set_comp(float4& v, int i, float x) {
+    if (i == 0) v.x = x; else if (i == 1) v.y = x; else if (i == 2) v.z = x; else v.w = x;
+}
 
-// operator entries of one 64-row group, as requested from L2
-struct Ops {
-    uint2 c[QMAX];
-    float4 v[QMAX];
-    int len;                 // even length of the group (wave-uniform), 0 if the group does not exist
-    int qoff;
-};
+template <int P> struct Ent { float x[P]; };       // one LDS entry: P planes of one vertex
 
-// One workgroup = all rows x 2 planes.  NJ = row slices per thread (ceil(ngroups*64 / blockDim)),
-// NQ = 16-byte linear pieces per thread and plane (ceil(Mp/4 / blockDim) <= ceil(NJ/4)).
-template <int NJ, int NTHR, bool ADJ>
+template <int P>
+__device__ __forceinline__ Ent<P> lds_get(const float* T, unsigned slot) {
+    Ent<P> r;
+    if constexpr (P == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(T + slot * 4);
+        r.x[0] = t.x; r.x[1] = t.y; r.x[2] = t.z; r.x[3] = t.w;
+    } else {
+        const float2 t = *reinterpret_cast<const float2*>(T + slot * 2);
+        r.x[0] = t.x; r.x[1] = t.y;
+    }
+    return r;
+}
+template <int P>
+__device__ __forceinline__ void lds_put(float* T, unsigned slot, const Ent<P>& v) {
+    if constexpr (P == 4) *reinterpret_cast<float4*>(T + slot * 4) = make_float4(v.x[0], v.x[1], v.x[2], v.x[3]);
+    else *reinterpret_cast<float2*>(T + slot * 2) = make_float2(v.x[0], v.x[1]);
+}
+
+// One workgroup = all ranked rows x P planes.  NJ = row slices per thread
+// (ceil(ngroups*64 / NTHR)), NQ = 16-byte linear pieces per thread and plane (ceil(Mp/4 / NTHR) <= NJ).
+template <int P, int NJ, int NQ, int NTHR, bool ADJ>
 __global__ void __launch_bounds__(NTHR)
 cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst,
-                   int M, int Mp, int nplanes, int K, size_t slab, int flags, int lds_entries) {
-    extern __shared__ __attribute__((aligned(16))) float2 T[];   // [lds_entries] slot-indexed image, then tables
-    constexpr int NQ = (NJ + 3) / 4;
+                   int M, int Mp, int nplanes, int K, size_t slab, int flags) {
+    extern __shared__ __attribute__((aligned(16))) float T[];    // [lds_entries][P], slot-indexed
+    constexpr int QS = NJ / NQ > 0 ? NJ / NQ : 1;   // a linear piece every QS groups
+    constexpr int nthr = NTHR;
+    constexpr int nwaves = NTHR >> 6;
     const int copy_t0 = flags & 1;
     // ablation bits for tools/kbench.py (always 0 in production):
-    // 1 = no global stores, 2 = no gather, 16 = no global loads, 32 = stagger start (x (abl>>6)&7)
+    // 1 = no global stores, 2 = no gather, 16 = no global loads, 32 = no start stagger
     const int abl = flags >> 8;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr int nthr = NTHR;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int nwaves = NTHR >> 6;
     const int Mq = Mp >> 2;                                       // float4 pieces per plane
-    const int npairs = (nplanes + 1) >> 1;
-    const float2 zero2 = make_float2(0.f, 0.f);
+    const int ngrp = (nplanes + P - 1) / P;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // Index tables, copied into LDS once per workgroup (they would cost ~12 VGPRs otherwise):
-    //   rs[g*64 + lane] = LDS slot of the row that lane owns in group g (0xFFFF = none)
-    //   nsq[q]          = LDS slots of vertices 4q..4q+3 (4 x 16 bit; 0xFFFF = pad)
-    uint16_t* rs = reinterpret_cast<uint16_t*>(T + lds_entries);
-    uint2* nsq = reinterpret_cast<uint2*>(rs + e.ngroups * 64);
-    for (int i = tid; i < e.ngroups * 32; i += nthr)
-        reinterpret_cast<unsigned*>(rs)[i] = reinterpret_cast<const unsigned*>(e.rowslot)[i];
-    for (int q = tid; q < Mq; q += nthr) nsq[q] = reinterpret_cast<const uint2*>(e.nodeslot)[q];
-    if (tid == 0) T[e.zero_slot] = zero2;     // never written again
-    __syncthreads();
-    // De-correlate the CUs of an XCD (blockIdx % 8 selects the XCD): every workgroup streams the
-    // same operator image from L2; started in lock-step they all hit the same L2 channel at the
-    // same time.  A one-off stagger spreads them over one step's worth of time.
-    if (abl & 32) {
-        const int k = (blockIdx.x >> 3) & 31;
-        const int reps = k * (1 + ((abl >> 6) & 7));      // x ~0.3 us each
+    // LDS slot of the own row of every slice, two 16-bit ids per register (0xFFFF = none)
+    constexpr int NJ2 = (NJ + 1) / 2;
+    unsigned rowreg[NJ2];
+#pragma unroll
+    for (int j2 = 0; j2 < NJ2; ++j2) {
+        unsigned r = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int g = (2 * j2 + h) * nwaves + wave;
+            const unsigned id = (2 * j2 + h < NJ && g < e.ngroups) ? e.rowslot[g * 64 + lane] : 0xFFFFu;
+            r |= id << (16 * h);
+        }
+        rowreg[j2] = r;
+    }
+    // LDS slots of the vertices of the linear pieces this thread moves (4 ids per piece)
+    uint2 nsreg[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int q = tid + u * nthr;
+        nsreg[u] = (q < Mq) ? reinterpret_cast<const uint2*>(e.nodeslot)[q] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+    if (tid < P) T[e.zero_slot * P + tid] = 0.f;      // never written again
+    // One-off stagger of the workgroups of an XCD (blockIdx % 8 selects the XCD): started in
+    // lock-step, all CUs would stream from L2, gather from LDS and write to HBM at the same
+    // times; spread over roughly one step they overlap each other's phases instead.
+    if (!(abl & 32)) {
+        const int reps = 2 * ((blockIdx.x >> 3) & 31);
         for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
     }
 
-    // linear staging registers: next pair's input (both modes), G_j of the adjoint
-    float4 pa[NQ], pb[NQ];
+    auto plane_of = [&](int grp, int p) { const int i = grp * P + p; return i < nplanes ? i : nplanes - 1; };
 
-    auto fetch = [&](const float* a, const float* b) {           // request 2 planes, linear
+    // linear staging registers: next group's input, G_j of the adjoint
+    float4 pre[NQ][P];
+    auto fetch = [&](const float* base, int grp) {                // request P planes, linear
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int q = tid + u * nthr;
-            pa[u] = zero4;
-            pb[u] = zero4;
+#pragma unroll
+            for (int p = 0; p < P; ++p) pre[u][p] = zero4;
             if (q < Mq && !(abl & 16)) {
-                pa[u] = ldg4(a + 4 * q);
-                pb[u] = ldg4(b + 4 * q);
+#pragma unroll
+                for (int p = 0; p < P; ++p) pre[u][p] = ldg4(base + (size_t)plane_of(grp, p) * Mp + 4 * q);
             }
         }
     };
-    auto copy_out_piece = [&](int u, float* o0, float* o1, bool has1) {   // LDS -> 2 planes
+    // LDS -> P planes of slab `out`; isolated vertices get sign * xiso (forward) ------------
+    auto copy_out_piece = [&](int u, float* out, int grp, float iso_sign, const float* xiso) {
         const int q = tid + u * nthr;
         if (q < Mq && !(abl & 1)) {
-            float2 t[4];
-            const uint2 nq = nsq[q];
+            float4 o[P];
+            unsigned iso = 0;
+            const uint2 nq = nsreg[u];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned sl = slot_of(nq, i);
-                t[i] = (sl != 0xFFFFu) ? T[sl] : zero2;
-            }
-            stg4(o0 + 4 * q, make_float4(t[0].x, t[1].x, t[2].x, t[3].x));
-            if (has1) stg4(o1 + 4 * q, make_float4(t[0].y, t[1].y, t[2].y, t[3].y));
-        }
-    };
-    auto load_ops = [&](Ops& o, int g) {
-        o.len = 0;
-        o.qoff = 0;
-        if (g < e.ngroups && !(abl & 2)) {
-            const int2 gi = e.ginfo[g];
-            o.qoff = gi.x;
-            o.len = gi.y;
+                if (sl != 0xFFFFu) {
+                    const Ent<P> t = lds_get<P>(T, sl);
 #pragma unroll
-            for (int q = 0; q < QMAX; ++q)
-                if (4 * q < gi.y) {
-                    o.c[q] = e.colq[(size_t)(gi.x + q) * 64 + lane];
-                    o.v[q] = e.valq[(size_t)(gi.x + q) * 64 + lane];
+                    for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
+                } else {
+                    if (4 * q + i < M) iso |= 1u << i;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) set_comp(o[p], i, 0.f);
                 }
-        }
-    };
-    auto pair_fma = [&](float2& acc, uint2 c, float4 v, int i) {   // entries i, i+1 of a quad
-        const float2 t0 = T[slot_of(c, i)], t1 = T[slot_of(c, i + 1)];
-        const float v0 = comp(v, i), v1 = comp(v, i + 1);
-        acc.x = fmaf(v0, t0.x, acc.x); acc.y = fmaf(v0, t0.y, acc.y);
-        acc.x = fmaf(v1, t1.x, acc.x); acc.y = fmaf(v1, t1.y, acc.y);
-    };
-    auto consume = [&](const Ops& o) -> float2 {
-        float2 acc = zero2;
-        const int len = o.len;
-        if (len >= 8) {                                   // the common case: one batch of eight
-            float2 t[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = T[slot_of(o.c[i >> 2], i & 3)];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float vv = comp(o.v[i >> 2], i & 3);
-                acc.x = fmaf(vv, t[i].x, acc.x); acc.y = fmaf(vv, t[i].y, acc.y);
             }
-        } else {
+            if (P == 4 && iso != 0 && iso_sign != 0.f) {
 #pragma unroll
-            for (int i = 0; i < 8; i += 2)
-                if (i < len) pair_fma(acc, o.c[i >> 2], o.v[i >> 2], i & 3);
-        }
+                for (int p = 0; p < P; ++p) {
+                    const float4 x = ldg4(xiso + (size_t)plane_of(grp, p) * Mp + 4 * q);
 #pragma unroll
-        for (int i = 8; i < 4 * QMAX; i += 2)
-            if (i < len) pair_fma(acc, o.c[i >> 2], o.v[i >> 2], i & 3);
-        for (int q = QMAX; 4 * q < len; ++q) {            // rows longer than 4*QMAX entries (rare)
-            const uint2 c = e.colq[(size_t)(o.qoff + q) * 64 + lane];
-            const float4 v = e.valq[(size_t)(o.qoff + q) * 64 + lane];
-            pair_fma(acc, c, v, 0);
-            if (4 * q + 2 < len) pair_fma(acc, c, v, 2);
+                    for (int i = 0; i < 4; ++i)
+                        if (iso & (1u << i)) set_comp(o[p], i, iso_sign * comp(x, i));
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (grp * P + p < nplanes) stg4(out + (size_t)(grp * P + p) * Mp + 4 * q, o[p]);
         }
-        return acc;
     };
 
-    int pair = blockIdx.x;
-    if (pair < npairs) {
-        const size_t base = ADJ ? (size_t)(K - 1) * slab : 0;
-        const int p0 = 2 * pair, p1 = (p0 + 1 < nplanes) ? p0 + 1 : p0;
-        fetch(src + base + (size_t)p0 * Mp, src + base + (size_t)p1 * Mp);
-    }
-    for (; pair < npairs; pair += gridDim.x) {
-        const int p0 = 2 * pair;
-        const bool has1 = (p0 + 1) < nplanes;
-        const int p1 = has1 ? p0 + 1 : p0;
-
-        // ---- staged input -> LDS image ----------------------------------------------------------
+    int grp = blockIdx.x;
+    const size_t in_base = ADJ ? (size_t)(K - 1) * slab : 0;
+    __syncthreads();
+    for (; grp < ngrp; grp += gridDim.x) {
+        // ---- input planes -> LDS image ----------------------------------------------------------
+        fetch(src + in_base, grp);
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int q = tid + u * nthr;
             if (q < Mq) {
-                const float4 a = pa[u], b = pb[u];
-                const uint2 nq = nsq[q];
+                const uint2 nq = nsreg[u];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const unsigned sl = slot_of(nq, i);
-                    if (sl != 0xFFFFu) T[sl] = make_float2(comp(a, i), comp(b, i));
+                    if (sl != 0xFFFFu) {
+                        Ent<P> t;
+#pragma unroll
+                        for (int p = 0; p < P; ++p) t.x[p] = comp(pre[u][p], i);
+                        lds_put<P>(T, sl, t);
+                    }
                 }
             }
         }
         __syncthreads();
 
-        float2 st[NJ];                        // T_{k-2} of the own rows, replaced by T_k in place
+        Ent<P> st[NJ];                        // T_{k-2} of the own rows, replaced by T_k in place
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) st[j] = zero2;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int p = 0; p < P; ++p) st[j].x[p] = 0.f;
 
         for (int step = 1; step < K; ++step) {
             const float f = ADJ ? (step == K - 1 ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
-            // linear traffic interleaved with this step's gather
-            const bool do_out = !ADJ && (step > 1 || copy_t0);    // forward: write T_{step-1}
-            float* o0 = dst + (size_t)(step - 1) * slab + (size_t)p0 * Mp;
-            float* o1 = dst + (size_t)(step - 1) * slab + (size_t)p1 * Mp;
-            const float* g0 = src + (size_t)(K - 1 - step) * slab + (size_t)p0 * Mp;   // adjoint: G_j
-            const float* g1 = src + (size_t)(K - 1 - step) * slab + (size_t)p1 * Mp;
+            // forward: slab step-1 is written out while this step gathers; an isolated vertex has
+            // T_k = 0 for odd k and (-1)^(k/2) x for even k
+            const bool do_out = !ADJ && (step > 1 || copy_t0);
+            float* out_slab = dst + (size_t)(step - 1) * slab;
+            const int ko = step - 1;
+            const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);
 
             // ---- gather: st <- f * (L T_{k-1})[own rows] - st ---------------------------------
-            // the operator entries of group j+1 are requested before group j is consumed
-            Ops ops[2];
-            load_ops(ops[0], wave);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (j + 1 < NJ) load_ops(ops[(j + 1) & 1], (j + 1) * nwaves + wave);
-                if ((j & 3) == 0 && (j >> 2) < NQ) {       // one linear piece per four groups
-                    const int u = j >> 2;
-                    if (ADJ) {
-                        const int q = tid + u * nthr;
-                        pa[u] = zero4;
-                        pb[u] = zero4;
-                        if (q < Mq && !(abl & 16)) {
-                            pa[u] = ldg4(g0 + 4 * q);
-                            pb[u] = ldg4(g1 + 4 * q);
-                        }
-                    } else if (do_out) {
-                        copy_out_piece(u, o0, o1, has1);
+                const int g = j * nwaves + wave;            // wave-uniform
+                float acc[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = 0.f;
+                int len = 0;
+                const uint16_t* cp = e.col;
+                const float* vp = e.val;
+                if (g < e.ngroups && !(abl & 2)) {
+                    const int off = e.goff[g];
+                    len = e.goff[g + 1] - off;
+                    cp += (size_t)off * 64 + lane;
+                    vp += (size_t)off * 64 + lane;
+                }
+                // group lengths are even; request all entries (up to RMAX) first
+                unsigned c[RMAX];
+                float v[RMAX];
+                if (len >= 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { c[u] = cp[u * 64]; v[u] = vp[u * 64]; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2)
+                        if (u < len) { c[u] = cp[u * 64]; v[u] = vp[u * 64]; c[u + 1] = cp[(u + 1) * 64]; v[u + 1] = vp[(u + 1) * 64]; }
+                }
+#pragma unroll
+                for (int u = 8; u < RMAX; u += 2)
+                    if (u < len) { c[u] = cp[u * 64]; v[u] = vp[u * 64]; c[u + 1] = cp[(u + 1) * 64]; v[u + 1] = vp[(u + 1) * 64]; }
+                if (!ADJ && do_out && (j % QS) == 0 && (j / QS) < NQ)       // one linear piece every QS groups
+                    copy_out_piece(j / QS, out_slab, grp, iso_sign, src);
+                // gather from LDS in batches of four entries
+#pragma unroll
+                for (int b = 0; b < RMAX; b += 4) {
+                    if (b + 4 <= len) {
+                        Ent<P> t[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, c[b + i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int p = 0; p < P; ++p) acc[p] = fmaf(v[b + i], t[i].x[p], acc[p]);
+                    } else if (b + 2 <= len) {
+                        Ent<P> t[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) t[i] = lds_get<P>(T, c[b + i]);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int p = 0; p < P; ++p) acc[p] = fmaf(v[b + i], t[i].x[p], acc[p]);
                     }
                 }
-                const float2 acc = consume(ops[j & 1]);
-                st[j].x = fmaf(f, acc.x, -st[j].x);
-                st[j].y = fmaf(f, acc.y, -st[j].y);
-                __builtin_amdgcn_sched_barrier(0);          // keep the prefetch distance at one group
+                for (int s = RMAX; s < len; s += 2) {       // rows longer than RMAX (rare)
+                    const unsigned c0 = cp[s * 64], c1 = cp[(s + 1) * 64];
+                    const float v0 = vp[s * 64], v1 = vp[(s + 1) * 64];
+                    const Ent<P> t0 = lds_get<P>(T, c0), t1 = lds_get<P>(T, c1);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = fmaf(v1, t1.x[p], fmaf(v0, t0.x[p], acc[p]));
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p) st[j].x[p] = fmaf(f, acc[p], -st[j].x[p]);
+            }
+            if (ADJ) {
+                // request G_j now; it is added after the rotate (two barriers later)
+                fetch(src + (size_t)(K - 1 - step) * slab, grp);
             }
             __syncthreads();                  // every gather (and copy-out read) of this step is done
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int g = j * nwaves + wave;
-                const unsigned r = (g < e.ngroups) ? rs[g * 64 + lane] : 0xFFFFu;
+                const unsigned r = (rowreg[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
                 if (r != 0xFFFFu) {
-                    const float2 old = T[r];
-                    T[r] = st[j];
+                    const Ent<P> old = lds_get<P>(T, r);
+                    lds_put<P>(T, r, st[j]);
                     st[j] = old;
                 }
             }
@@ -270,14 +312,15 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 for (int u = 0; u < NQ; ++u) {
                     const int q = tid + u * nthr;
                     if (q < Mq) {
-                        const float4 a = pa[u], b = pb[u];
-                        const uint2 nq = nsq[q];
+                        const uint2 nq = nsreg[u];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const unsigned sl = slot_of(nq, i);
                             if (sl != 0xFFFFu) {
-                                const float2 t = T[sl];
-                                T[sl] = make_float2(t.x + comp(a, i), t.y + comp(b, i));
+                                Ent<P> t = lds_get<P>(T, sl);
+#pragma unroll
+                                for (int p = 0; p < P; ++p) t.x[p] += comp(pre[u][p], i);
+                                lds_put<P>(T, sl, t);
                             }
                         }
                     }
@@ -286,18 +329,51 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             }
         }
 
-        // ---- request the next pair's input, then stream the last image out -----------------
-        const int npair = pair + gridDim.x;
-        if (npair < npairs) {
-            const size_t base = ADJ ? (size_t)(K - 1) * slab : 0;
-            const int q0 = 2 * npair, q1 = (q0 + 1 < nplanes) ? q0 + 1 : q0;
-            fetch(src + base + (size_t)q0 * Mp, src + base + (size_t)q1 * Mp);
-        }
-        {
-            float* o0 = dst + (ADJ ? 0 : (size_t)(K - 1) * slab) + (size_t)p0 * Mp;
-            float* o1 = dst + (ADJ ? 0 : (size_t)(K - 1) * slab) + (size_t)p1 * Mp;
+        // ---- stream the last image out ---------------------------------------------------------
+        if (!ADJ) {
+            const int ko = K - 1;
+            const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);
 #pragma unroll
-            for (int u = 0; u < NQ; ++u) copy_out_piece(u, o0, o1, has1);
+            for (int u = 0; u < NQ; ++u) copy_out_piece(u, dst + (size_t)ko * slab, grp, iso_sign, src);
+        } else {
+            // dx; an isolated vertex has dx = G_0 - G_2 + G_4 - ...
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int q = tid + u * nthr;
+                if (q < Mq && !(abl & 1)) {
+                    float4 o[P];
+                    unsigned iso = 0;
+                    const uint2 nq = nsreg[u];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned sl = slot_of(nq, i);
+                        if (sl != 0xFFFFu) {
+                            const Ent<P> t = lds_get<P>(T, sl);
+#pragma unroll
+                            for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
+                        } else {
+                            if (4 * q + i < M) iso |= 1u << i;
+#pragma unroll
+                            for (int p = 0; p < P; ++p) set_comp(o[p], i, 0.f);
+                        }
+                    }
+                    if (P == 4 && iso != 0) {
+                        float sgn = 1.f;
+                        for (int m = 0; m < K; m += 2, sgn = -sgn) {
+#pragma unroll
+                            for (int p = 0; p < P; ++p) {
+                                const float4 x = ldg4(src + (size_t)m * slab + (size_t)plane_of(grp, p) * Mp + 4 * q);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (iso & (1u << i)) set_comp(o[p], i, comp(o[p], i) + sgn * comp(x, i));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        if (grp * P + p < nplanes) stg4(dst + (size_t)(grp * P + p) * Mp + 4 * q, o[p]);
+                }
+            }
         }
         __syncthreads();                      // LDS reads done before the image is overwritten
     }
@@ -321,43 +397,47 @@ cheb_step_global_kernel(const int32_t* __restrict__ rowptr, const int32_t* __res
     out[plane + r] = v;
 }
 
-template <int NJ, int NTHR, bool ADJ>
+template <int P, int NJ, int NQ, int NTHR, bool ADJ>
 static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst,
                          int nplanes, int K, int copy_t0, hipStream_t stream) {
-    const size_t lds = (size_t)ell.lds_entries * sizeof(float2) + (size_t)ell.ngroups * 64 * 2 + (size_t)(g->Mp / 4) * 8;
-    auto kern = cheb_onchip_kernel<NJ, NTHR, ADJ>;
+    const size_t lds = (size_t)ell.lds_entries * P * sizeof(float);
+    static_assert(NQ <= NJ, "a linear piece is issued per group at most");
+    auto kern = cheb_onchip_kernel<P, NJ, NQ, NTHR, ADJ>;
     CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : per_cu;
     if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
     if (per_cu > 8) per_cu = 8;
-    const int npairs = (nplanes + 1) / 2;
+    const int ngrp = (nplanes + P - 1) / P;
     int grid = g->num_cus * per_cu;
-    if (grid > npairs) grid = npairs;
+    if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, stream, view(ell), src, dst, g->M, g->Mp,
-                       nplanes, K, slab, copy_t0 | (g_ablate << 8), ell.lds_entries);
+                       nplanes, K, slab, copy_t0 | (g_ablate << 8));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
 
 // Workgroup shape: as many waves as the register budget allows.  Per thread the kernel keeps
-// 2 VGPRs per row slice (NJ) and 8 per linear piece (NQ = ceil(NJ/4)) next to ~80 for the
-// operator prefetch and temporaries; 1024 / 768 / 512 threads may use 128 / 168 / 256 VGPRs.
-template <bool ADJ>
+// P VGPRs per row slice (NJ) and 4P per linear piece (NQ = ceil(NJ/4)) next to ~70 for the
+// operator entries and temporaries; 1024 / 768 / 512 threads may use 128 / 168 / 256 VGPRs.
+template <int P, bool ADJ>
 static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K,
                            int copy_t0, hipStream_t stream) {
     const Ell& ell = ADJ ? g->adj : g->fwd;
     const int rows = ell.ngroups * 64;
     const int Mq = g->Mp / 4;
-    auto fits = [&](int nj, int nthr) { return nj * nthr >= rows && ((nj + 3) / 4) * nthr >= Mq; };
-#define CG_TRY(NJ, NTHR) if (fits(NJ, NTHR)) return launch_onchip<NJ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
-    CG_TRY(1, 256); CG_TRY(2, 256); CG_TRY(4, 256); CG_TRY(8, 256);      // M <= 2048
-    CG_TRY(8, 512); CG_TRY(8, 1024);                                        // M <= 8192
-    CG_TRY(11, 768); CG_TRY(14, 768);                                       // M <= 10752
-    CG_TRY(24, 512); CG_TRY(32, 512); CG_TRY(40, 512);                      // M <= 20480
+    auto fits = [&](int nj, int nq, int nthr) { return nj * nthr >= rows && nq * nthr >= Mq; };
+#define CG_TRY(NJ, NQ, NTHR) if (fits(NJ, NQ, NTHR)) return launch_onchip<P, NJ, NQ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
+    CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
+    if (P == 4) {
+        CG_TRY(8, 3, 512); CG_TRY(12, 4, 512); CG_TRY(16, 5, 512); CG_TRY(20, 6, 512);      // <= 10240 rows (LDS limit)
+    } else {
+        CG_TRY(8, 3, 512); CG_TRY(8, 3, 768); CG_TRY(11, 4, 768); CG_TRY(14, 4, 768);        // <= 10752
+        CG_TRY(24, 7, 512); CG_TRY(32, 9, 512); CG_TRY(40, 11, 512);                         // <= 20480
+    }
 #undef CG_TRY
-    return fail(CHEBGCN_EUNSUPPORTED, "recurrence: no kernel shape for %d rows", rows);
+    return fail(CHEBGCN_EUNSUPPORTED, "recurrence: no kernel shape for %d rows x %d planes", rows, P);
 }
 
 static int step_global(const chebgcn_graph* g, const Ell& ell, const float* src, const float* sub,
@@ -376,6 +456,7 @@ using namespace chebgcn;
 // Undeclared tuning hook for tools/kbench.py (not part of the ABI in include/chebgcn.h).
 extern "C" int chebgcn_tune(int key, int value) {
     if (key == 0) { g_ablate = value; return 0; }
+    if (key == 1 && (value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards
     return -1;
 }
 
@@ -397,7 +478,8 @@ extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, fl
                              stack + k * slab, nplanes, 2.f, stream);
         return rc;
     }
-    return dispatch_onchip<false>(g, x, stack, nplanes, K, copy_t0, stream);
+    if (g->fwd.planes == 4) return dispatch_onchip<4, false>(g, x, stack, nplanes, K, copy_t0, stream);
+    return dispatch_onchip<2, false>(g, x, stack, nplanes, K, copy_t0, stream);
 }
 
 extern "C" int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstack, float* dx, int B,
@@ -412,7 +494,10 @@ extern "C" int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstac
         CG_HIP(hipMemcpyAsync(dx, gstack, slab * sizeof(float), hipMemcpyDeviceToDevice, stream));
         return CHEBGCN_OK;
     }
-    if (g->lds_ok) return dispatch_onchip<true>(g, gstack, dx, nplanes, K, 0, stream);
+    if (g->lds_ok) {
+        if (g->adj.planes == 4) return dispatch_onchip<4, true>(g, gstack, dx, nplanes, K, 0, stream);
+        return dispatch_onchip<2, true>(g, gstack, dx, nplanes, K, 0, stream);
+    }
     // fallback: Clenshaw with two scratch slabs; c_{j} = G_j + f L^T c_{j+1} - c_{j+2}
     float* scratch = nullptr;
     CG_HIP(hipMallocAsync((void**)&scratch, 2 * slab * sizeof(float), stream));

@@ -396,3 +396,73 @@ def test_missing_gpu_path_fails_loudly(ops):
     from gcn_fmri_decoding_amd import _lib
     with pytest.raises(_lib.ChebgcnError):
         ops.cheb_conv(torch.zeros(1, 1, 32), torch.zeros(1, 1), None, None, 1)
+
+
+# ---------------------------------------------------------------------------------------
+# alternative kernel shapes: 4 planes per workgroup (opt-in) and the out-of-LDS fallback
+# ---------------------------------------------------------------------------------------
+
+def _run_fwd_bwd(ops, g, x, G, K):
+    from gcn_fmri_decoding_amd import _lib
+    lib = _lib.lib()
+    B, Fin = x.shape[0], x.shape[1]
+    stack = torch.full((K, B, Fin, g.Mp), float('nan'), device=x.device)
+    dx = torch.full((B, Fin, g.Mp), float('nan'), device=x.device)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, ops._p(x), ops._p(stack), B, Fin, K, ops._stream()), 'fwd')
+    _lib.check(lib.chebgcn_recurrence_bwd(g.handle, ops._p(G), ops._p(dx), B, Fin, K, ops._stream()), 'bwd')
+    return stack, dx
+
+
+@pytest.mark.parametrize('lvl,B,Fin,K', [(0, 3, 3, 5), (1, 2, 5, 6), (3, 1, 1, 2)])
+def test_four_plane_kernel_matches_two_plane(ops, dev, lvl, B, Fin, K):
+    """chebgcn_tune(1, 4): only active vertices on chip, isolated ("fake") vertices patched
+    in by the streaming code.  Same summation order as the default kernel, so the two agree
+    to the last few ulps."""
+    from gcn_fmri_decoding_amd import _lib
+    L = levels()[lvl]
+    M = L.shape[0]
+    torch.manual_seed(lvl)
+    g2 = ops.Graph(L, dev)
+    assert g2.query(6) == 2
+    _lib.lib().chebgcn_tune(1, 4)
+    try:
+        g4 = ops.Graph(L, dev)
+    finally:
+        _lib.lib().chebgcn_tune(1, 2)
+    assert g4.query(6) == 4 and g4.query(7) <= M
+    x = torch.randn(B, Fin, g2.Mp, device=dev)
+    G = torch.randn(K, B, Fin, g2.Mp, device=dev)
+    s2, d2 = _run_fwd_bwd(ops, g2, x, G, K)
+    s4, d4 = _run_fwd_bwd(ops, g4, x, G, K)
+    close(s4[:, :, :, :M].cpu().numpy(), s2[:, :, :, :M].cpu().numpy(), rel=1e-6, what='4-plane vs 2-plane stack')
+    close(d4[:, :, :M].cpu().numpy(), d2[:, :, :M].cpu().numpy(), rel=1e-6, what='4-plane vs 2-plane dx')
+    ref = R.cheb_stack(R.rescaled_laplacian(L, np.float32), from_storage(x, M), K)
+    close(stack_to_ref(s4, M), ref, what='4-plane stack')
+
+
+def test_out_of_lds_fallback(ops, dev):
+    """A graph too large for the LDS image (M > 20480) takes the kernel-per-step path."""
+    rs = np.random.RandomState(5)
+    M, deg = 21000, 6
+    rows = np.repeat(np.arange(M), deg)
+    cols = rs.randint(0, M, M * deg)
+    W = sp.coo_matrix((rs.rand(M * deg).astype(np.float32), (rows, cols)), shape=(M, M)).tocsr()
+    W = W + W.T
+    W.setdiag(0)
+    W.eliminate_zeros()
+    from gcn_fmri_decoding_amd import graph
+    L = graph.laplacian(W.astype(np.float32), normalized=True)
+    g = ops.Graph(L, dev)
+    assert not g.on_chip
+    B, Fin, K = 2, 3, 4
+    torch.manual_seed(1)
+    x = torch.randn(B, Fin, g.Mp, device=dev)
+    x[:, :, M:] = 0
+    G = torch.randn(K, B, Fin, g.Mp, device=dev)
+    G[:, :, :, M:] = 0
+    stack, dx = _run_fwd_bwd(ops, g, x, G, K)
+    ref = R.cheb_stack(R.rescaled_laplacian(L, np.float32), from_storage(x, M), K)
+    close(stack_to_ref(stack, M), ref, what='fallback stack')
+    lhs = (stack[:, :, :, :M].double() * G[:, :, :, :M].double()).sum().item()
+    rhs = (x[:, :, :M].double() * dx[:, :, :M].double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
