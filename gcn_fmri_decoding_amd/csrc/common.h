@@ -15,6 +15,7 @@ namespace chebgcn {
     } while (0)
 
 inline int plane_stride(int M) { return (M + 31) & ~31; }
+constexpr int kQuadPad = 4;
 
 // Length-sorted sliced ELL image of one sparse operator (device memory), laid out for the
 // on-chip recurrence kernel (recurrence.hip).
@@ -24,9 +25,12 @@ inline int plane_stride(int M) { return (M + 31) & ~31; }
 //    only active vertices get an LDS slot (isolated ones obey T_k = -T_{k-2} and are patched
 //    in by the streaming code), with P = 2 every vertex has slot = vertex id.
 //  * Ranked rows (all rows for P = 2, active rows for P = 4) are sorted by descending length;
-//    rank r lives in group r/64, lane r%64.  Group g owns entry slots [goff[g], goff[g+1]),
-//    an even count; entry (s, lane) is at (goff[g] + s)*64 + lane.  Padding entries have
-//    val = 0 and col = zero_slot, an LDS entry that always holds 0.
+//    rank r lives in group r/64, lane r%64.  Group g owns quads [ginfo[g].x, +ceil(len/4)); a
+//    quad holds 4 consecutive entries of each of the 64 rows: colq[quad*64 + lane] = 4 packed
+//    16-bit LDS slot ids, valq[quad*64 + lane] = 4 values; ginfo[g].y = the group's length
+//    rounded up to even.  Padding entries have val = 0 and point at zero_slot, an LDS entry
+//    that always holds 0.  kQuadPad spare quads follow the last group so that the kernel may
+//    always request a fixed number of quads per group.
 struct Ell {
     int planes = 2;
     int ngroups = 0;
@@ -34,10 +38,11 @@ struct Ell {
     int nranked = 0;              // rows handled by the gather
     int lds_entries = 0;          // P-float entries of the LDS image incl. the zero slot
     int zero_slot = 0;
-    int64_t nslots = 0;           // sum of group lengths
-    int32_t* goff = nullptr;      // [ngroups+1]
-    uint16_t* col = nullptr;      // [nslots*64]  LDS slot ids
-    float* val = nullptr;         // [nslots*64]
+    int64_t nslots = 0;           // sum of (even) group lengths
+    int64_t nquads = 0;
+    int2* ginfo = nullptr;        // [ngroups] {quad offset, even length}
+    uint2* colq = nullptr;        // [(nquads + kQuadPad)*64]
+    float4* valq = nullptr;       // [(nquads + kQuadPad)*64]
     uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> LDS slot of that row, 0xFFFF for padding ranks
     uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> LDS slot, 0xFFFF = none (isolated / pad)
     // plain CSR for the out-of-LDS fallback

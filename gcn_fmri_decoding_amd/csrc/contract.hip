@@ -284,19 +284,30 @@ struct BwdWArgs {
     size_t slab;
 };
 
-constexpr int BW_Q = 8;          // float4 pieces per lane per chunk (64 vertices)
+// One chunk = 64 consecutive vertices of one window.  Its operand rows -- RT*32 stack planes
+// and 32 dy planes, 256 B each -- are brought into LDS by LDS-DMA (global_load_lds, 16 B per
+// lane: every wave instruction moves four full rows, fully coalesced, no VGPR round trip).
+// LDS image: row pitch 256 B, the 16-byte piece p of row r sits at position p ^ (r & 15); the
+// DMA writes linearly, so the swizzle is applied to the SOURCE address (cdna guide rule 21),
+// and the MFMA operand reads (lane = row, ds_read_b128) are bank-conflict free.
+// A wave owns 16 of the 64 vertices for all RT row tiles; lane (i, h) feeds the MFMA with the
+// float4 pieces 2q+h (q = 0, 1) of its row -- the pairing of vertices inside one MFMA is
+// irrelevant for a reduction.  The four waves are reduced through LDS in a fixed order and
+// every workgroup leaves one partial; reduce_partials sums them deterministically.
+constexpr int BW_ROW = 64;       // floats per LDS row (one chunk)
 
 template <int RT>
 __global__ void __launch_bounds__(256)
 contract_bwd_w_kernel(BwdWArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][RT*16*64]
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [(RT+1)*32][64]
+    constexpr int NROWS = (RT + 1) * 32;
+    constexpr int NDMA = NROWS / 4;                     // wave instructions per chunk (4 rows each)
+    constexpr int PER_WAVE = (NDMA + 3) / 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int tile0 = blockIdx.y * RT;                  // first row tile of this group
     const int fo0 = blockIdx.z * 32;                    // column tile
-    const int fo = fo0 + c;
-    const bool fo_ok = fo < a.Fout;
 
     f32x16 acc[RT];
 #pragma unroll
@@ -304,96 +315,136 @@ contract_bwd_w_kernel(BwdWArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
-    // plane offsets of the RT A rows owned by this lane (row = tile*32 + c)
-    size_t aoff[RT];
+    // rows this lane fetches: instruction n covers rows 4n..4n+3, lane l -> row 4n + l/16, piece l%16
+    size_t roff[PER_WAVE];                              // plane offset (without the window part)
+    int rwin[PER_WAVE];                                 // per-window stride of that row's tensor
+    int rpiece[PER_WAVE];                               // source piece after the swizzle
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+        const int n = wave + 4 * u;
+        const int row = 4 * n + (lane >> 4);
+        rpiece[u] = (lane & 15) ^ (row & 15);
+        if (row < RT * 32) {
+            int kk = (tile0 + row / 32) * 32 + (row & 31);
+            if (kk >= a.FinK) kk = 0;                   // masked later (A rows beyond Fin*K)
+            const int fin = kk / a.K, k = kk - fin * a.K;
+            roff[u] = (size_t)k * a.slab + (size_t)fin * a.Mp;
+            rwin[u] = a.Fin;
+        } else {
+            int fo = fo0 + (row - RT * 32);
+            if (fo >= a.Fout) fo = 0;
+            roff[u] = (size_t)fo * a.Mp;
+            rwin[u] = -a.Fout;                          // negative: the row comes from dy
+        }
+    }
     bool a_ok[RT];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const int kk = (tile0 + t) * 32 + c;
-        a_ok[t] = kk < a.FinK;
-        const int kc = a_ok[t] ? kk : 0;
-        const int fin = kc / a.K, k = kc - fin * a.K;
-        aoff[t] = (size_t)k * a.slab + (size_t)fin * a.Mp;
-    }
+    for (int t = 0; t < RT; ++t) a_ok[t] = (tile0 + t) * 32 + c < a.FinK;
+    const bool b_ok = fo0 + c < a.Fout;
 
     const int total = a.B * a.nchunks_m;
-    const int nwaves_total = gridDim.x * 4;
-    for (int ch = blockIdx.x * 4 + wave; ch < total; ch += nwaves_total) {
+    for (int ch = blockIdx.x; ch < total; ch += gridDim.x) {
         const int b = ch / a.nchunks_m;
         const int m0 = (ch - b * a.nchunks_m) * 64;
-        const int nb = m0 + 4 * h;                     // + 8q
-        const float* dyp = a.dy + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mp;
-        float4 bv[BW_Q];
+        __syncthreads();                                // previous chunk's operand reads are done
 #pragma unroll
-        for (int q = 0; q < BW_Q; ++q) {
-            const int n = nb + 8 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (fo_ok && n < a.Mp) v = ld_stream(dyp + n);
-            v.x = (n + 0 < a.M) ? v.x : 0.f;
-            v.y = (n + 1 < a.M) ? v.y : 0.f;
-            v.z = (n + 2 < a.M) ? v.z : 0.f;
-            v.w = (n + 3 < a.M) ? v.w : 0.f;
+        for (int u = 0; u < PER_WAVE; ++u) {
+            const int n = wave + 4 * u;
+            if (n < NDMA) {
+                int m = m0 + 4 * rpiece[u];
+                if (m >= a.Mp) m = 0;                   // beyond the plane: any valid address, masked below
+                const float* src = (rwin[u] > 0 ? a.stack + (size_t)b * a.Fin * a.Mp : a.dy + (size_t)b * a.Fout * a.Mp)
+                                   + roff[u] + m;
+                __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 0);
+            }
+        }
+        __syncthreads();                                // DMA landed (the barrier's release waits vmcnt(0))
+
+        // operand pieces of this lane: row = its plane, pieces 4*wave + 2q + h
+        float4 bv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int piece = 4 * wave + 2 * q + h;
+            const int row = RT * 32 + c;
+            float4 v = *reinterpret_cast<const float4*>(lds + row * BW_ROW + 4 * (piece ^ (row & 15)));
+            const int n = m0 + 4 * piece;
+            v.x = (b_ok && n + 0 < a.M) ? v.x : 0.f;
+            v.y = (b_ok && n + 1 < a.M) ? v.y : 0.f;
+            v.z = (b_ok && n + 2 < a.M) ? v.z : 0.f;
+            v.w = (b_ok && n + 3 < a.M) ? v.w : 0.f;
             bv[q] = v;
         }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            const float* ap = a.stack + aoff[t] + (size_t)b * a.Fin * a.Mp;
-            float4 av[BW_Q];
 #pragma unroll
-            for (int q = 0; q < BW_Q; ++q) {
-                const int n = nb + 8 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a_ok[t] && n < a.Mp) v = ld_stream(ap + n);
-                v.x = (n + 0 < a.M) ? v.x : 0.f;
-                v.y = (n + 1 < a.M) ? v.y : 0.f;
-                v.z = (n + 2 < a.M) ? v.z : 0.f;
-                v.w = (n + 3 < a.M) ? v.w : 0.f;
-                av[q] = v;
-            }
-#pragma unroll
-            for (int q = 0; q < BW_Q; ++q) {
-                acc[t] = mfma(av[q].x, bv[q].x, acc[t]);
-                acc[t] = mfma(av[q].y, bv[q].y, acc[t]);
-                acc[t] = mfma(av[q].z, bv[q].z, acc[t]);
-                acc[t] = mfma(av[q].w, bv[q].w, acc[t]);
+            for (int q = 0; q < 2; ++q) {
+                const int piece = 4 * wave + 2 * q + h;
+                const int row = t * 32 + c;
+                float4 v = *reinterpret_cast<const float4*>(lds + row * BW_ROW + 4 * (piece ^ (row & 15)));
+                const int n = m0 + 4 * piece;
+                v.x = (a_ok[t] && n + 0 < a.M) ? v.x : 0.f;
+                v.y = (a_ok[t] && n + 1 < a.M) ? v.y : 0.f;
+                v.z = (a_ok[t] && n + 2 < a.M) ? v.z : 0.f;
+                v.w = (a_ok[t] && n + 3 < a.M) ? v.w : 0.f;
+                acc[t] = mfma(v.x, bv[q].x, acc[t]);
+                acc[t] = mfma(v.y, bv[q].y, acc[t]);
+                acc[t] = mfma(v.z, bv[q].z, acc[t]);
+                acc[t] = mfma(v.w, bv[q].w, acc[t]);
             }
         }
     }
 
-    // ---- workgroup reduction (fixed order: wave 0 + 1 + 2 + 3) ----------------------------
-    float* mine = red + (size_t)wave * (RT * 16 * 64);
+    // ---- workgroup reduction in LDS (fixed order: wave 0, then +1, +2, +3) ----------------
+    constexpr int per = RT * 16 * 64;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) mine[(t * 16 + j) * 64 + lane] = acc[t][j];
+                for (int j = 0; j < 16; ++j) {
+                    float* p = lds + (t * 16 + j) * 64 + lane;
+                    *p = (w == 0) ? acc[t][j] : *p + acc[t][j];
+                }
+        }
+    }
     __syncthreads();
-    const int per = RT * 16 * 64;
     float* dst = a.partial + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * per;
-    for (int o = threadIdx.x; o < per; o += 256)
-        dst[o] = ((red[o] + red[per + o]) + red[2 * per + o]) + red[3 * per + o];
+    for (int o = threadIdx.x; o < per; o += 256) dst[o] = lds[o];
 }
 
-// partial: [Z][Y][X][RT*16*64] raw accumulator images -> dW[kk][o]
+// partial: [Z][Y][X][RT*16*64] raw accumulator images.  Stage 1: block (row, y*S + s, z) sums
+// the partials x = s, s+S, ... of one 64-lane accumulator row into stage[z][y][s][row][lane].
+constexpr int BW_SPLIT = 8;
 __global__ void __launch_bounds__(256)
-reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ dW, int nx, int ny,
-                       int rt, int FinK, int Fout) {
+reduce_partials_stage1(const float* __restrict__ partial, float* __restrict__ stage, int nx, int ny, int rt) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int per = rt * 16 * 64;
-    const int row = blockIdx.x;                          // (t*16 + j) within the group image
-    const int y = blockIdx.y, z = blockIdx.z;
+    const int row = blockIdx.x;
+    const int y = blockIdx.y / BW_SPLIT, sp = blockIdx.y % BW_SPLIT, z = blockIdx.z;
     const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
     float s = 0.f;
-    for (int x = part; x < nx; x += 4) s += base[(size_t)x * per];
+    for (int x = sp + BW_SPLIT * part; x < nx; x += 4 * BW_SPLIT) s += base[(size_t)x * per];
     red[part][lane] = s;
     __syncthreads();
-    if (part == 0) {
-        s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-        const int t = row >> 4, j = row & 15, h = lane >> 5;
-        const int kk = (y * rt + t) * 32 + acc_row(j, h);
-        const int fo = z * 32 + (lane & 31);
-        if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = s;
-    }
+    if (part == 0)
+        stage[((((size_t)z * ny + y) * BW_SPLIT + sp) * rt * 16 + row) * 64 + lane] =
+            ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// Stage 2: sum the BW_SPLIT stage rows and scatter from the accumulator layout to dW[kk][o].
+__global__ void __launch_bounds__(64)
+reduce_partials_stage2(const float* __restrict__ stage, float* __restrict__ dW, int ny, int rt, int FinK, int Fout) {
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+    float s = 0.f;
+    for (int sp = 0; sp < BW_SPLIT; ++sp)
+        s += stage[((((size_t)z * ny + y) * BW_SPLIT + sp) * rt * 16 + row) * 64 + lane];
+    const int t = row >> 4, j = row & 15, h = lane >> 5;
+    const int kk = (y * rt + t) * 32 + acc_row(j, h);
+    const int fo = z * 32 + (lane & 31);
+    if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = s;
 }
 
 static int bw_rt(int ntiles) { return ntiles < 5 ? ntiles : 5; }
@@ -406,8 +457,8 @@ static int bw_grid_x(int B, int M) {
                   ? prop.multiProcessorCount : 256;
     }
     int total = B * ((M + 63) / 64);
-    int gx = cus * 2;
-    if (gx * 4 > total) gx = (total + 3) / 4;
+    int gx = cus * 3;                          // 48 KB of LDS per workgroup -> three per CU
+    if (gx > total) gx = total;
     return gx < 1 ? 1 : gx;
 }
 
@@ -471,7 +522,7 @@ extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K,
     if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
     const int ntiles = (Fin * K + 31) / 32, rt = bw_rt(ntiles);
     const int gy = (ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
-    return (size_t)gx * gy * gz * rt * 16 * 64 * sizeof(float);
+    return ((size_t)gx + BW_SPLIT) * gy * gz * rt * 16 * 64 * sizeof(float);   // partials + stage
 }
 
 extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void* workspace,
@@ -491,7 +542,7 @@ extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float
     const int rt = bw_rt(a.ntiles);
     const int gy = (a.ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
     dim3 grid(gx, gy, gz);
-    const size_t lds = (size_t)4 * rt * 16 * 64 * sizeof(float);
+    const size_t lds = (size_t)(rt + 1) * 32 * BW_ROW * sizeof(float);
 #define CG_BW(N)                                                                                        \
     case N:                                                                                             \
         CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_kernel<N>),             \
@@ -504,9 +555,11 @@ extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float
     }
 #undef CG_BW
     CG_HIP(hipGetLastError());
-    dim3 rgrid(rt * 16, gy, gz);
-    hipLaunchKernelGGL(reduce_partials_kernel, rgrid, dim3(256), 0, stream, (const float*)workspace, dW, gx, gy,
-                       rt, a.FinK, Fout);
+    float* stage = (float*)workspace + (size_t)gx * gy * gz * rt * 16 * 64;
+    hipLaunchKernelGGL(reduce_partials_stage1, dim3(rt * 16, gy * BW_SPLIT, gz), dim3(256), 0, stream,
+                       (const float*)workspace, stage, gx, gy, rt);
+    hipLaunchKernelGGL(reduce_partials_stage2, dim3(rt * 16, gy, gz), dim3(64), 0, stream, (const float*)stage, dW,
+                       gy, rt, a.FinK, Fout);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -33,7 +33,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 static void free_ell(Ell& e) {
-    void* ptrs[] = {e.goff, e.col, e.val, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
+    void* ptrs[] = {e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
     for (void* p : ptrs) (void)hipFree(p);
     e = Ell();
 }
@@ -79,24 +79,29 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rlen(a) > rlen(b); });
     const int nranked = (int)order.size();
     const int ngroups = (nranked + 63) / 64;
-    std::vector<int32_t> goff(ngroups + 1, 0);
+    std::vector<int2> ginfo(ngroups);
     int max_len = 0;
+    int64_t nquads = 0, nslots = 0;
     for (int g = 0; g < ngroups; ++g) {
         const int len = rlen(order[g * 64]);              // longest row of the group
         max_len = std::max(max_len, len);
-        goff[g + 1] = goff[g] + ((len + 1) & ~1);         // even: the kernel gathers in pairs
+        ginfo[g] = make_int2((int)nquads, (len + 1) & ~1);   // even: the kernel gathers in pairs
+        nquads += (len + 3) / 4;
+        nslots += (len + 1) & ~1;
     }
-    const int64_t nslots = goff[ngroups];
-    std::vector<uint16_t> ecol((size_t)nslots * 64, (uint16_t)zero_slot);
-    std::vector<float> eval((size_t)nslots * 64, 0.0f);
+    const uint32_t zz = (uint32_t)zero_slot | ((uint32_t)zero_slot << 16);
+    std::vector<uint2> colq((size_t)(nquads + kQuadPad) * 64, make_uint2(zz, zz));
+    std::vector<float4> valq((size_t)(nquads + kQuadPad) * 64, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<uint16_t> rowslot((size_t)ngroups * 64, 0xFFFF);
     for (int r = 0; r < nranked; ++r) {
         const int row = order[r], g = r / 64, lane = r % 64;
         rowslot[r] = nodeslot[row];
-        const size_t base = (size_t)goff[g] * 64 + lane;
-        for (int e = rowptr[row], s = 0; e < rowptr[row + 1]; ++e, ++s) {
-            ecol[base + (size_t)s * 64] = nodeslot[col[e]];   // a gathered vertex is active by definition
-            eval[base + (size_t)s * 64] = val[e];
+        for (int e = rowptr[row], s2 = 0; e < rowptr[row + 1]; ++e, ++s2) {
+            const size_t at = ((size_t)ginfo[g].x + s2 / 4) * 64 + lane;
+            const uint32_t slot = nodeslot[col[e]];          // a gathered vertex is active by definition
+            uint32_t* w = (s2 & 2) ? &colq[at].y : &colq[at].x;
+            *w = (s2 & 1) ? ((*w & 0x0000FFFFu) | (slot << 16)) : ((*w & 0xFFFF0000u) | slot);
+            (&valq[at].x)[s2 & 3] = val[e];
         }
     }
     out->ngroups = ngroups;
@@ -105,9 +110,10 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     out->lds_entries = lds_entries;
     out->zero_slot = zero_slot;
     out->nslots = nslots;
-    if ((rc = upload(&out->goff, goff))) return rc;
-    if ((rc = upload(&out->col, ecol))) return rc;
-    if ((rc = upload(&out->val, eval))) return rc;
+    out->nquads = nquads;
+    if ((rc = upload(&out->ginfo, ginfo))) return rc;
+    if ((rc = upload(&out->colq, colq))) return rc;
+    if ((rc = upload(&out->valq, valq))) return rc;
     if ((rc = upload(&out->rowslot, rowslot))) return rc;
     if ((rc = upload(&out->nodeslot, nodeslot))) return rc;
     return CHEBGCN_OK;

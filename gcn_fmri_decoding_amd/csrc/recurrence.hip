@@ -40,19 +40,26 @@ int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 i
 extern int g_prefer_planes;
 
 struct EllView {
-    const int32_t* goff;
-    const uint16_t* col;
-    const float* val;
+    const int2* ginfo;
+    const uint2* colq;
+    const float4* valq;
     const uint16_t* rowslot;
     const uint16_t* nodeslot;
     int ngroups, zero_slot;
 };
 
 static inline EllView view(const Ell& e) {
-    return EllView{e.goff, e.col, e.val, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
+    return EllView{e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
 }
 
-constexpr int RMAX = 12;     // operator entries of a group requested at once (longer rows: extra trips)
+constexpr int QMAX = 3;      // quads (4 operator entries each) requested per group, always, one group ahead
+static_assert(QMAX <= kQuadPad, "the operator arrays are padded for the unconditional requests");
+
+// operator entries of one 64-row group as requested from L2
+struct Ops {
+    uint2 c[QMAX];
+    float4 v[QMAX];
+};
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -228,64 +235,63 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);
 
             // ---- gather: st <- f * (L T_{k-1})[own rows] - st ---------------------------------
+            // Software pipeline over the (statically unrolled) groups of this wave: the operator
+            // entries of group j+1 are requested -- always QMAX quads, unconditionally, so that
+            // the compiler can count the outstanding loads -- before group j is gathered.
+            Ops ops[2];
+            int glen[2], gq[2];
+            auto request = [&](int slot, int g) {
+                const bool ok = g < e.ngroups && !(abl & 2);
+                const int2 gi = ok ? e.ginfo[g] : make_int2(0, 0);
+                glen[slot] = gi.y;
+                gq[slot] = gi.x;
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) {
+                    ops[slot].c[q] = e.colq[(size_t)(gi.x + q) * 64 + lane];
+                    ops[slot].v[q] = e.valq[(size_t)(gi.x + q) * 64 + lane];
+                }
+            };
+            request(0, wave);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int g = j * nwaves + wave;            // wave-uniform
+                if (j + 1 < NJ) request((j + 1) & 1, (j + 1) * nwaves + wave);
+                if (!ADJ && do_out && (j % QS) == 0 && (j / QS) < NQ)       // one linear piece every QS groups
+                    copy_out_piece(j / QS, out_slab, grp, iso_sign, src);
+                const Ops& o = ops[j & 1];
+                const int len = glen[j & 1];
                 float acc[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p] = 0.f;
-                int len = 0;
-                const uint16_t* cp = e.col;
-                const float* vp = e.val;
-                if (g < e.ngroups && !(abl & 2)) {
-                    const int off = e.goff[g];
-                    len = e.goff[g + 1] - off;
-                    cp += (size_t)off * 64 + lane;
-                    vp += (size_t)off * 64 + lane;
-                }
-                // group lengths are even; request all entries (up to RMAX) first
-                unsigned c[RMAX];
-                float v[RMAX];
-                if (len >= 8) {
+                // gather from LDS in batches of four entries (group lengths are even)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { c[u] = cp[u * 64]; v[u] = vp[u * 64]; }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; u += 2)
-                        if (u < len) { c[u] = cp[u * 64]; v[u] = vp[u * 64]; c[u + 1] = cp[(u + 1) * 64]; v[u + 1] = vp[(u + 1) * 64]; }
-                }
-#pragma unroll
-                for (int u = 8; u < RMAX; u += 2)
-                    if (u < len) { c[u] = cp[u * 64]; v[u] = vp[u * 64]; c[u + 1] = cp[(u + 1) * 64]; v[u + 1] = vp[(u + 1) * 64]; }
-                if (!ADJ && do_out && (j % QS) == 0 && (j / QS) < NQ)       // one linear piece every QS groups
-                    copy_out_piece(j / QS, out_slab, grp, iso_sign, src);
-                // gather from LDS in batches of four entries
-#pragma unroll
-                for (int b = 0; b < RMAX; b += 4) {
-                    if (b + 4 <= len) {
+                for (int q = 0; q < QMAX; ++q) {
+                    if (4 * q + 4 <= len) {
                         Ent<P> t[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, c[b + i]);
+                        for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, slot_of(o.c[q], i));
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int p = 0; p < P; ++p) acc[p] = fmaf(v[b + i], t[i].x[p], acc[p]);
-                    } else if (b + 2 <= len) {
+                            for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(o.v[q], i), t[i].x[p], acc[p]);
+                    } else if (4 * q + 2 <= len) {
                         Ent<P> t[2];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) t[i] = lds_get<P>(T, c[b + i]);
+                        for (int i = 0; i < 2; ++i) t[i] = lds_get<P>(T, slot_of(o.c[q], i));
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int p = 0; p < P; ++p) acc[p] = fmaf(v[b + i], t[i].x[p], acc[p]);
+                            for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(o.v[q], i), t[i].x[p], acc[p]);
                     }
                 }
-                for (int s = RMAX; s < len; s += 2) {       // rows longer than RMAX (rare)
-                    const unsigned c0 = cp[s * 64], c1 = cp[(s + 1) * 64];
-                    const float v0 = vp[s * 64], v1 = vp[(s + 1) * 64];
-                    const Ent<P> t0 = lds_get<P>(T, c0), t1 = lds_get<P>(T, c1);
+                for (int q = QMAX; 4 * q < len; ++q) {      // rows longer than 4*QMAX entries (rare)
+                    const uint2 c = e.colq[(size_t)(gq[j & 1] + q) * 64 + lane];
+                    const float4 v = e.valq[(size_t)(gq[j & 1] + q) * 64 + lane];
+                    const int n = (4 * q + 4 <= len) ? 4 : 2;
+                    for (int i = 0; i < n; ++i) {
+                        const Ent<P> t = lds_get<P>(T, slot_of(c, i));
 #pragma unroll
-                    for (int p = 0; p < P; ++p) acc[p] = fmaf(v1, t1.x[p], fmaf(v0, t0.x[p], acc[p]));
+                        for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(v, i), t.x[p], acc[p]);
+                    }
                 }
 #pragma unroll
                 for (int p = 0; p < P; ++p) st[j].x[p] = fmaf(f, acc[p], -st[j].x[p]);

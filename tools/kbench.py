@@ -31,6 +31,7 @@ def main():
                                                      'contract_bwd_w', 'contract_bwd_x', 'brelu_pool_bwd'])
     ap.add_argument('--ablate', type=int, nargs='+', default=[0])
     ap.add_argument('--json', default=None)
+    ap.add_argument('--planes', type=int, default=2, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
     args = ap.parse_args()
 
     import torch
@@ -38,8 +39,10 @@ def main():
     from gcn_fmri_decoding_amd import _lib, ops
     dev = torch.device('cuda:0')
     Ls, perm = bench.load_graph(10000, 1, 0, 1, None)
-    g = ops.Graph(Ls[0], dev)
     lib = _lib.lib()
+    lib.chebgcn_tune(1, args.planes)
+    g = ops.Graph(Ls[0], dev)
+    print('planes per workgroup:', g.query(6), flush=True)
     M, Mp = g.M, g.Mp
     results = []
 
