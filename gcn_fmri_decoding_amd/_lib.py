@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libchebgcn.so')
+LIB_PATH = os.environ.get('CHEBGCN_LIB') or os.path.join(_HERE, 'libchebgcn.so')   # override: kernel experiments only
 
 BIAS_NONE, BIAS_FILTER, BIAS_VERTEX = 0, 1, 2
 POOL_MAX, POOL_AVG = 0, 1

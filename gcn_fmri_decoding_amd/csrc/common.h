@@ -16,6 +16,7 @@ namespace chebgcn {
 
 inline int plane_stride(int M) { return (M + 31) & ~31; }
 constexpr int kQuadPad = 4;
+constexpr int kQuadMin = 3;      // quads stored (zero-padded) for every group, = QMAX of recurrence.hip
 
 // Length-sorted sliced ELL image of one sparse operator (device memory), laid out for the
 // on-chip recurrence kernel (recurrence.hip).
@@ -23,7 +24,8 @@ constexpr int kQuadPad = 4;
 //    LDS image of the ACTIVE vertices fits with 16 B per vertex, else 2 (8 B per vertex).
 //    A vertex is active when its row or its column of the operator is non-empty; with P = 4
 //    only active vertices get an LDS slot (isolated ones obey T_k = -T_{k-2} and are patched
-//    in by the streaming code), with P = 2 every vertex has slot = vertex id.
+//    in by the streaming code), with P = 2 every vertex has one.  Slots are numbered
+//    component-major (vertices 4q first, then 4q+1, ...; see build_ell).
 //  * Ranked rows (all rows for P = 2, active rows for P = 4) are sorted by descending length;
 //    rank r lives in group r/64, lane r%64.  Group g owns quads [ginfo[g].x, +ceil(len/4)); a
 //    quad holds 4 consecutive entries of each of the 64 rows: colq[quad*64 + lane] = 4 packed

@@ -64,16 +64,20 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     if (planes == 0) return CHEBGCN_OK;
 
     auto rlen = [&](int r) { return rowptr[r + 1] - rowptr[r]; };
-    // LDS slots: P = 4 keeps only the active vertices (compacted, in vertex order); P = 2 keeps
-    // all of them with slot = vertex id
+    // LDS slots: P = 4 keeps only the active vertices, P = 2 all of them.  Slots are handed out
+    // component-major -- all vertices 4q, then all 4q+1, ... -- because the linear phases of the
+    // kernel give lane l the four vertices 4(q0+l)..+3: for a fixed component the lanes of a wave
+    // then touch consecutive slots (no bank conflicts), where slot = vertex id would be 4-way
+    // (8-byte entries) or 8-way (16-byte entries) conflicted.
     std::vector<uint16_t> nodeslot((size_t)Mp + 4, 0xFFFF);
     std::vector<int32_t> order;
     int nslot = 0;
-    for (int v = 0; v < M; ++v)
-        if (planes == 2 || active[v]) {
-            nodeslot[v] = (uint16_t)nslot++;
-            order.push_back(v);
-        }
+    for (int i = 0; i < 4; ++i)
+        for (int v = i; v < M; v += 4)
+            if (planes == 2 || active[v]) {
+                nodeslot[v] = (uint16_t)nslot++;
+                order.push_back(v);
+            }
     const int zero_slot = nslot;
     const int lds_entries = (nslot + 1 + 3) & ~3;
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rlen(a) > rlen(b); });
@@ -86,7 +90,7 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
         const int len = rlen(order[g * 64]);              // longest row of the group
         max_len = std::max(max_len, len);
         ginfo[g] = make_int2((int)nquads, (len + 1) & ~1);   // even: the kernel gathers in pairs
-        nquads += (len + 3) / 4;
+        nquads += std::max((len + 3) / 4, kQuadMin);      // the kernel gathers kQuadMin quads unconditionally
         nslots += (len + 1) & ~1;
     }
     const uint32_t zz = (uint32_t)zero_slot | ((uint32_t)zero_slot << 16);

@@ -52,8 +52,11 @@ static inline EllView view(const Ell& e) {
     return EllView{e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
 }
 
+#ifndef CG_X
+#define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
+#endif
 constexpr int QMAX = 3;      // quads (4 operator entries each) requested per group, always, one group ahead
-static_assert(QMAX <= kQuadPad, "the operator arrays are padded for the unconditional requests");
+static_assert(QMAX <= kQuadPad && QMAX == kQuadMin, "the operator arrays are padded for the unconditional requests");
 
 // operator entries of one 64-row group as requested from L2
 struct Ops {
@@ -134,6 +137,11 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
         const int q = tid + u * nthr;
         nsreg[u] = (q < Mq) ? reinterpret_cast<const uint2*>(e.nodeslot)[q] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     }
+    // {quad offset, even length} of this wave's groups: lane j holds group j*nwaves + wave.  The
+    // gather reads them with v_readlane -- a load inside the loop would have to be waited for
+    // with vmcnt(0), draining the operator requests that are in flight.
+    int2 gtab = make_int2(0, 0);
+    if (lane < NJ && lane * nwaves + wave < e.ngroups) gtab = e.ginfo[lane * nwaves + wave];
     if (tid < P) T[e.zero_slot * P + tid] = 0.f;      // never written again
     // One-off stagger of the workgroups of an XCD (blockIdx % 8 selects the XCD): started in
     // lock-step, all CUs would stream from L2, gather from LDS and write to HBM at the same
@@ -163,34 +171,62 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     auto copy_out_piece = [&](int u, float* out, int grp, float iso_sign, const float* xiso) {
         const int q = tid + u * nthr;
         if (q < Mq && !(abl & 1)) {
-            float4 o[P];
-            unsigned iso = 0;
             const uint2 nq = nsreg[u];
+            if constexpr (P == 4) {
+                // two plane pairs one after the other (8-byte LDS reads): half the live registers
+                unsigned sl[4];
+                bool none[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned sl = slot_of(nq, i);
-                if (sl != 0xFFFFu) {
-                    const Ent<P> t = lds_get<P>(T, sl);
-#pragma unroll
-                    for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
-                } else {
-                    if (4 * q + i < M) iso |= 1u << i;
-#pragma unroll
-                    for (int p = 0; p < P; ++p) set_comp(o[p], i, 0.f);
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned id = slot_of(nq, i);
+                    none[i] = id == 0xFFFFu;
+                    sl[i] = none[i] ? (unsigned)e.zero_slot : id;
                 }
-            }
-            if (P == 4 && iso != 0 && iso_sign != 0.f) {
+                // an isolated vertex (no slot) takes sign * x; the pad beyond M (no slot either) stays 0
+                bool patch = false;
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const float4 x = ldg4(xiso + (size_t)plane_of(grp, p) * Mp + 4 * q);
+                for (int i = 0; i < 4; ++i) patch |= none[i] && 4 * q + i < M;
+                patch = patch && iso_sign != 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (iso & (1u << i)) set_comp(o[p], i, iso_sign * comp(x, i));
+                for (int h = 0; h < 2; ++h) {
+                    float4 o[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        o[p] = zero4;
+                        if (patch) {
+                            const float4 x = ldg4(xiso + (size_t)plane_of(grp, 2 * h + p) * Mp + 4 * q);
+                            o[p] = make_float4(iso_sign * x.x, iso_sign * x.y, iso_sign * x.z, iso_sign * x.w);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float2 t = *reinterpret_cast<const float2*>(T + sl[i] * 4 + 2 * h);
+                        const bool pad = 4 * q + i >= M;
+                        set_comp(o[0], i, none[i] ? (pad ? 0.f : comp(o[0], i)) : t.x);
+                        set_comp(o[1], i, none[i] ? (pad ? 0.f : comp(o[1], i)) : t.y);
+                    }
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        if (grp * P + 2 * h + p < nplanes) stg4(out + (size_t)(grp * P + 2 * h + p) * Mp + 4 * q, o[p]);
                 }
-            }
+            } else {
+                float4 o[P];
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-                if (grp * P + p < nplanes) stg4(out + (size_t)(grp * P + p) * Mp + 4 * q, o[p]);
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned sl = slot_of(nq, i);
+                    if (sl != 0xFFFFu) {
+                        const Ent<P> t = lds_get<P>(T, sl);
+#pragma unroll
+                        for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < P; ++p) set_comp(o[p], i, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    if (grp * P + p < nplanes) stg4(out + (size_t)(grp * P + p) * Mp + 4 * q, o[p]);
+            }
         }
     };
 
@@ -215,6 +251,11 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                         lds_put<P>(T, sl, t);
                     }
                 }
+                if (!ADJ && copy_t0 && !(abl & 1)) {            // T_0 = x goes straight to slab 0
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        if (grp * P + p < nplanes) stg4(dst + (size_t)(grp * P + p) * Mp + 4 * q, pre[u][p]);
+                }
             }
         }
         __syncthreads();
@@ -229,7 +270,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             const float f = ADJ ? (step == K - 1 ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
             // forward: slab step-1 is written out while this step gathers; an isolated vertex has
             // T_k = 0 for odd k and (-1)^(k/2) x for even k
-            const bool do_out = !ADJ && (step > 1 || copy_t0);
+            const bool do_out = !ADJ && step > 1;
             float* out_slab = dst + (size_t)(step - 1) * slab;
             const int ko = step - 1;
             const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);
@@ -240,48 +281,41 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             // the compiler can count the outstanding loads -- before group j is gathered.
             Ops ops[2];
             int glen[2], gq[2];
-            auto request = [&](int slot, int g) {
-                const bool ok = g < e.ngroups && !(abl & 2);
-                const int2 gi = ok ? e.ginfo[g] : make_int2(0, 0);
+            auto request = [&](int slot, int j) {
+                // {quad offset, length} of group j*nwaves + wave, from lane j of the wave's table
+                int2 gi = make_int2(__builtin_amdgcn_readlane(gtab.x, j), __builtin_amdgcn_readlane(gtab.y, j));
+                if (abl & 2) gi = make_int2(0, 0);
                 glen[slot] = gi.y;
+                if (CG_X & 1) gi.x = 0;              // experiment: operator always from the same (L1-resident) quads
                 gq[slot] = gi.x;
+                if ((CG_X & 4) && j != 0) return;  // experiment: no operator loads after the first group
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
                     ops[slot].c[q] = e.colq[(size_t)(gi.x + q) * 64 + lane];
                     ops[slot].v[q] = e.valq[(size_t)(gi.x + q) * 64 + lane];
                 }
             };
-            request(0, wave);
+            request(0, 0);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (j + 1 < NJ) request((j + 1) & 1, (j + 1) * nwaves + wave);
+                if (j + 1 < NJ) request((j + 1) & 1, j + 1);
                 if (!ADJ && do_out && (j % QS) == 0 && (j / QS) < NQ)       // one linear piece every QS groups
                     copy_out_piece(j / QS, out_slab, grp, iso_sign, src);
-                const Ops& o = ops[j & 1];
+                const Ops& o = ops[(CG_X & 4) ? 0 : (j & 1)];
                 const int len = glen[j & 1];
                 float acc[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p] = 0.f;
-                // gather from LDS in batches of four entries (group lengths are even)
+                // every group stores QMAX quads (padding: value 0, zero slot): no length tests here
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
-                    if (4 * q + 4 <= len) {
-                        Ent<P> t[4];
+                    Ent<P> t[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, slot_of(o.c[q], i));
+                    for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, (CG_X & 2) ? lane + 64 * i : slot_of(o.c[q], i));
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(o.v[q], i), t[i].x[p], acc[p]);
-                    } else if (4 * q + 2 <= len) {
-                        Ent<P> t[2];
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) t[i] = lds_get<P>(T, slot_of(o.c[q], i));
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(o.v[q], i), t[i].x[p], acc[p]);
-                    }
+                        for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(o.v[q], i), t[i].x[p], acc[p]);
                 }
                 for (int q = QMAX; 4 * q < len; ++q) {      // rows longer than 4*QMAX entries (rare)
                     const uint2 c = e.colq[(size_t)(gq[j & 1] + q) * 64 + lane];
@@ -437,7 +471,7 @@ static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst,
 #define CG_TRY(NJ, NQ, NTHR) if (fits(NJ, NQ, NTHR)) return launch_onchip<P, NJ, NQ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
     CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
     if (P == 4) {
-        CG_TRY(8, 3, 512); CG_TRY(12, 4, 512); CG_TRY(16, 5, 512); CG_TRY(20, 6, 512);      // <= 10240 rows (LDS limit)
+        CG_TRY(8, 3, 512); CG_TRY(11, 4, 768); CG_TRY(14, 4, 768); CG_TRY(20, 6, 512);      // <= 10240 rows (LDS limit)
     } else {
         CG_TRY(8, 3, 512); CG_TRY(8, 3, 768); CG_TRY(11, 4, 768); CG_TRY(14, 4, 768);        // <= 10752
         CG_TRY(24, 7, 512); CG_TRY(32, 9, 512); CG_TRY(40, 11, 512);                         // <= 20480

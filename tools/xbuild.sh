@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds timing-experiment variants of the library (recurrence.hip compiled with -DCG_X=<bits>)
+# into build_x/libchebgcn_x<bits>.so; select one with CHEBGCN_LIB=... python tools/kbench.py.
+set -e
+cd "$(dirname "$0")/../gcn_fmri_decoding_amd/csrc"
+make -s
+mkdir -p ../../build_x
+for x in "$@"; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -DCG_X=$x -c recurrence.hip -o ../../build_x/recurrence_x$x.o
+  /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 graph.o ../../build_x/recurrence_x$x.o contract.o pointwise.o coarsen_host.o -o ../../build_x/libchebgcn_x$x.so
+done
