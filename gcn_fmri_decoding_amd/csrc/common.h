@@ -42,6 +42,7 @@ struct Ell {
     int zero_slot = 0;
     int64_t nslots = 0;           // sum of (even) group lengths
     int64_t nquads = 0;
+    int64_t cost_before = 0, cost_after = 0, cost_ideal = 0;   // bank-conflict statistics of build_ell (graph_query 9, 10)
     int2* ginfo = nullptr;        // [ngroups] {quad offset, even length}
     uint2* colq = nullptr;        // [(nquads + kQuadPad)*64]
     float4* valq = nullptr;       // [(nquads + kQuadPad)*64]
@@ -53,6 +54,29 @@ struct Ell {
     float* cval = nullptr;        // [nnz]
 };
 
+// what the on-chip kernels take by value
+struct EllView {
+    const int2* ginfo;
+    const uint2* colq;
+    const float4* valq;
+    const uint16_t* rowslot;
+    const uint16_t* nodeslot;
+    int ngroups, zero_slot;
+};
+
+static inline EllView view(const Ell& e) {
+    return EllView{e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
+}
+
+}  // namespace chebgcn
+
+struct chebgcn_graph;
+namespace chebgcn {
+// recurrence4.hip: four-plane kernel for graphs beyond 2048 ranked rows
+bool onchip4_fits(int lds_entries, int rows, int Mq);
+template <bool ADJ>
+int dispatch_onchip4(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K, int copy_t0,
+                     hipStream_t stream);
 }  // namespace chebgcn
 
 struct chebgcn_graph {

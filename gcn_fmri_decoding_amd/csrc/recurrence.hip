@@ -39,30 +39,11 @@ namespace chebgcn {
 int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
 extern int g_prefer_planes;
 
-struct EllView {
-    const int2* ginfo;
-    const uint2* colq;
-    const float4* valq;
-    const uint16_t* rowslot;
-    const uint16_t* nodeslot;
-    int ngroups, zero_slot;
-};
-
-static inline EllView view(const Ell& e) {
-    return EllView{e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
-}
-
 #ifndef CG_X
 #define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
 #endif
 constexpr int QMAX = 3;      // quads (4 operator entries each) requested per group, always, one group ahead
 static_assert(QMAX <= kQuadPad && QMAX == kQuadMin, "the operator arrays are padded for the unconditional requests");
-
-// operator entries of one 64-row group as requested from L2
-struct Ops {
-    uint2 c[QMAX];
-    float4 v[QMAX];
-};
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -74,6 +55,12 @@ __device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : i
 __device__ __forceinline__ void set_comp(float4& v, int i, float x) {
     if (i == 0) v.x = x; else if (i == 1) v.y = x; else if (i == 2) v.z = x; else v.w = x;
 }
+
+// Identity the optimiser cannot see through: keeps values DERIVED from the small per-thread
+// tables (unpacked slot ids, flags) from being hoisted out of the plane-group loop, where they
+// would occupy registers for the whole kernel and spill.
+__device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ uint2 opaque(uint2 x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); return x; }
 
 template <int P> struct Ent { float x[P]; };       // one LDS entry: P planes of one vertex
 
@@ -171,7 +158,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     auto copy_out_piece = [&](int u, float* out, int grp, float iso_sign, const float* xiso) {
         const int q = tid + u * nthr;
         if (q < Mq && !(abl & 1)) {
-            const uint2 nq = nsreg[u];
+            const uint2 nq = opaque(nsreg[u]);
             if constexpr (P == 4) {
                 // two plane pairs one after the other (8-byte LDS reads): half the live registers
                 unsigned sl[4];
@@ -240,7 +227,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
         for (int u = 0; u < NQ; ++u) {
             const int q = tid + u * nthr;
             if (q < Mq) {
-                const uint2 nq = nsreg[u];
+                const uint2 nq = opaque(nsreg[u]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const unsigned sl = slot_of(nq, i);
@@ -276,55 +263,60 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);
 
             // ---- gather: st <- f * (L T_{k-1})[own rows] - st ---------------------------------
-            // Software pipeline over the (statically unrolled) groups of this wave: the operator
-            // entries of group j+1 are requested -- always QMAX quads, unconditionally, so that
-            // the compiler can count the outstanding loads -- before group j is gathered.
-            Ops ops[2];
-            int glen[2], gq[2];
-            auto request = [&](int slot, int j) {
+            // Operator entries travel through a ring of RING quads (4 entries of each of the 64
+            // rows): every group stores QMAX zero-padded quads, quad n = QMAX*j + q lives in ring
+            // slot n % RING and is requested RING quads (two groups) before it is gathered -- one
+            // group of lead does not cover the L2 latency.  Requests are unconditional, so the
+            // compiler can count the loads in flight (s_waitcnt vmcnt(N), N > 0).
+            constexpr int RING = 2 * QMAX;
+            uint2 rc[RING];
+            float4 rv[RING];
+            auto group_info = [&](int j, int& qoff, int& len) {
                 // {quad offset, length} of group j*nwaves + wave, from lane j of the wave's table
-                int2 gi = make_int2(__builtin_amdgcn_readlane(gtab.x, j), __builtin_amdgcn_readlane(gtab.y, j));
-                if (abl & 2) gi = make_int2(0, 0);
-                glen[slot] = gi.y;
-                if (CG_X & 1) gi.x = 0;              // experiment: operator always from the same (L1-resident) quads
-                gq[slot] = gi.x;
-                if ((CG_X & 4) && j != 0) return;  // experiment: no operator loads after the first group
-#pragma unroll
-                for (int q = 0; q < QMAX; ++q) {
-                    ops[slot].c[q] = e.colq[(size_t)(gi.x + q) * 64 + lane];
-                    ops[slot].v[q] = e.valq[(size_t)(gi.x + q) * 64 + lane];
-                }
+                qoff = __builtin_amdgcn_readlane(gtab.x, j);
+                len = __builtin_amdgcn_readlane(gtab.y, j);
+                if (abl & 2) { qoff = 0; len = 0; }
+                if (CG_X & 1) qoff = 0;              // experiment: operator always from the same (L1-resident) quads
             };
-            request(0, 0);
+            auto request = [&](int j, int q) {       // quad q of group j -> its ring slot
+                int qoff, len;
+                group_info(j, qoff, len);
+                rc[(QMAX * j + q) % RING] = e.colq[(size_t)(qoff + q) * 64 + lane];
+                rv[(QMAX * j + q) % RING] = e.valq[(size_t)(qoff + q) * 64 + lane];
+            };
+            auto quad = [&](const uint2 c, const float4 v, float (&acc)[P]) {
+                Ent<P> t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, (CG_X & 2) ? lane + 64 * i : slot_of(c, i));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(v, i), t[i].x[p], acc[p]);
+            };
+#pragma unroll
+            for (int n = 0; n < RING; ++n)
+                if (n / QMAX < NJ) request(n / QMAX, n % QMAX);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (j + 1 < NJ) request((j + 1) & 1, j + 1);
                 if (!ADJ && do_out && (j % QS) == 0 && (j / QS) < NQ)       // one linear piece every QS groups
                     copy_out_piece(j / QS, out_slab, grp, iso_sign, src);
-                const Ops& o = ops[(CG_X & 4) ? 0 : (j & 1)];
-                const int len = glen[j & 1];
+                int qoff, len;
+                group_info(j, qoff, len);
                 float acc[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p] = 0.f;
-                // every group stores QMAX quads (padding: value 0, zero slot): no length tests here
+                const bool gather = !(abl & 2);
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
-                    Ent<P> t[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, (CG_X & 2) ? lane + 64 * i : slot_of(o.c[q], i));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(o.v[q], i), t[i].x[p], acc[p]);
+                    // the first two quads always (zero-padded), the third for rows beyond 8 entries
+                    if (gather && (q < 2 || len > 8)) quad(rc[(QMAX * j + q) % RING], rv[(QMAX * j + q) % RING], acc);
+                    if (j + 2 < NJ) request(j + 2, q);           // refill the slot just consumed
                 }
-                for (int q = QMAX; 4 * q < len; ++q) {      // rows longer than 4*QMAX entries (rare)
-                    const uint2 c = e.colq[(size_t)(gq[j & 1] + q) * 64 + lane];
-                    const float4 v = e.valq[(size_t)(gq[j & 1] + q) * 64 + lane];
-                    const int n = (4 * q + 4 <= len) ? 4 : 2;
-                    for (int i = 0; i < n; ++i) {
-                        const Ent<P> t = lds_get<P>(T, slot_of(c, i));
-#pragma unroll
-                        for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(v, i), t.x[p], acc[p]);
+                if (gather && len > 4 * QMAX) {
+                    for (int q = QMAX; 4 * q < len; ++q) {       // rows longer than 4*QMAX entries (rare)
+                        const uint2 c = e.colq[(size_t)(qoff + q) * 64 + lane];
+                        const float4 v = e.valq[(size_t)(qoff + q) * 64 + lane];
+                        quad(c, v, acc);
                     }
                 }
 #pragma unroll
@@ -338,7 +330,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const unsigned r = (rowreg[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
                 if (r != 0xFFFFu) {
                     const Ent<P> old = lds_get<P>(T, r);
                     lds_put<P>(T, r, st[j]);
@@ -352,7 +344,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 for (int u = 0; u < NQ; ++u) {
                     const int q = tid + u * nthr;
                     if (q < Mq) {
-                        const uint2 nq = nsreg[u];
+                        const uint2 nq = opaque(nsreg[u]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const unsigned sl = slot_of(nq, i);
@@ -383,7 +375,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 if (q < Mq && !(abl & 1)) {
                     float4 o[P];
                     unsigned iso = 0;
-                    const uint2 nq = nsreg[u];
+                    const uint2 nq = opaque(nsreg[u]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const unsigned sl = slot_of(nq, i);
@@ -470,8 +462,9 @@ static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst,
     auto fits = [&](int nj, int nq, int nthr) { return nj * nthr >= rows && nq * nthr >= Mq; };
 #define CG_TRY(NJ, NQ, NTHR) if (fits(NJ, NQ, NTHR)) return launch_onchip<P, NJ, NQ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
     CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
-    if (P == 4) {
-        CG_TRY(8, 3, 512); CG_TRY(11, 4, 768); CG_TRY(14, 4, 768); CG_TRY(20, 6, 512);      // <= 10240 rows (LDS limit)
+    if constexpr (P == 4) {
+        // beyond 2048 rows: the dedicated kernel of recurrence4.hip
+        return dispatch_onchip4<ADJ>(g, src, dst, nplanes, K, copy_t0, stream);
     } else {
         CG_TRY(8, 3, 512); CG_TRY(8, 3, 768); CG_TRY(11, 4, 768); CG_TRY(14, 4, 768);        // <= 10752
         CG_TRY(24, 7, 512); CG_TRY(32, 9, 512); CG_TRY(40, 11, 512);                         // <= 20480

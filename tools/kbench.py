@@ -42,7 +42,8 @@ def main():
     lib = _lib.lib()
     lib.chebgcn_tune(1, args.planes)
     g = ops.Graph(Ls[0], dev)
-    print('planes per workgroup:', g.query(6), flush=True)
+    print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
+          g.query(11), flush=True)
     M, Mp = g.M, g.Mp
     results = []
 
