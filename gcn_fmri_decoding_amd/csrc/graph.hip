@@ -40,6 +40,7 @@ static void free_ell(Ell& e) {
 
 constexpr int kLdsBytes = 160 * 1024;     // LDS per workgroup on gfx950
 int g_prefer_planes = 2;                  // chebgcn_tune(1, planes); see graph_create
+int g_slot_order = -1;                    // chebgcn_tune(2, x): experiments, -1 = automatic
 
 // Planes per workgroup for an image of n vertices (+1 zero slot, rounded to 4 entries):
 // 4 if 16 B per vertex fit the LDS, else 2 if 8 B fit, else 0 (no on-chip path).
@@ -72,8 +73,13 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     std::vector<uint16_t> nodeslot((size_t)Mp + 4, 0xFFFF);
     std::vector<int32_t> order;
     int nslot = 0;
-    for (int i = 0; i < 4; ++i)
-        for (int v = i; v < M; v += 4)
+    int nactive = 0;
+    for (int v = 0; v < M; ++v) nactive += active[v] != 0;
+    // ... except for the four-plane kernel of recurrence4.hip (more than 2048 rows), whose linear
+    // phases give every lane ONE vertex: there slots follow the vertex order.
+    const bool vertex_major = g_slot_order >= 0 ? g_slot_order == 1 : planes == 4 && ((nactive + 63) / 64) * 64 > 2048;
+    for (int i = 0; i < (vertex_major ? 1 : 4); ++i)
+        for (int v = i; v < M; v += (vertex_major ? 1 : 4))
             if (planes == 2 || active[v]) {
                 nodeslot[v] = (uint16_t)nslot++;
                 order.push_back(v);

@@ -38,6 +38,7 @@ namespace chebgcn {
 
 int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
 extern int g_prefer_planes;
+extern int g_slot_order;
 
 #ifndef CG_X
 #define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
@@ -62,6 +63,15 @@ __device__ __forceinline__ void set_comp(float4& v, int i, float x) {
 __device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ uint2 opaque(uint2 x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); return x; }
 
+// LDS entries a workgroup shape can hold: one per ranked row (+ zero slot, rounded), capped by
+// the 160 KB of a CU.  For P = 4 the image holds only active vertices, all of them ranked.
+__host__ __device__ constexpr int lds_capacity(int nj, int nthr, int planes) {
+    return (nj * nthr + 4) * planes * 4 <= 160 * 1024 ? nj * nthr + 4 : 160 * 1024 / (planes * 4);
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int P> struct Ent { float x[P]; };       // one LDS entry: P planes of one vertex
 
 template <int P>
@@ -77,6 +87,33 @@ __device__ __forceinline__ Ent<P> lds_get(const float* T, unsigned slot) {
     return r;
 }
 template <int P>
+__device__ __forceinline__ Ent<P> lds_at(const float* T, unsigned byteoff) {
+    Ent<P> r;
+    const char* p = reinterpret_cast<const char*>(T) + byteoff;
+    if constexpr (P == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        r.x[0] = t.x; r.x[1] = t.y; r.x[2] = t.z; r.x[3] = t.w;
+    } else {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        r.x[0] = t.x; r.x[1] = t.y;
+    }
+    return r;
+}
+// byte offset of the LDS entry named by the low (H = 0) / high (H = 1) 16 bits of w: one VALU op
+template <int P, int H>
+__device__ __forceinline__ unsigned entry_ofs(unsigned w) {
+    unsigned r;
+    if constexpr (P == 4 && H == 0)
+        asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(w));
+    else if constexpr (P == 4)
+        asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(w));
+    else if constexpr (H == 0)
+        asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(w));
+    else
+        asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(w));
+    return r;
+}
+template <int P>
 __device__ __forceinline__ void lds_put(float* T, unsigned slot, const Ent<P>& v) {
     if constexpr (P == 4) *reinterpret_cast<float4*>(T + slot * 4) = make_float4(v.x[0], v.x[1], v.x[2], v.x[3]);
     else *reinterpret_cast<float2*>(T + slot * 2) = make_float2(v.x[0], v.x[1]);
@@ -88,7 +125,8 @@ template <int P, int NJ, int NQ, int NTHR, bool ADJ>
 __global__ void __launch_bounds__(NTHR)
 cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst,
                    int M, int Mp, int nplanes, int K, size_t slab, int flags) {
-    extern __shared__ __attribute__((aligned(16))) float T[];    // [lds_entries][P], slot-indexed
+    // static image: its address folds into the LDS instructions (no base add per access)
+    __shared__ __attribute__((aligned(16))) float T[lds_capacity(NJ, NTHR, P) * P];    // [entries][P], slot-indexed
     constexpr int QS = NJ / NQ > 0 ? NJ / NQ : 1;   // a linear piece every QS groups
     constexpr int nthr = NTHR;
     constexpr int nwaves = NTHR >> 6;
@@ -129,6 +167,8 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     // with vmcnt(0), draining the operator requests that are in flight.
     int2 gtab = make_int2(0, 0);
     if (lane < NJ && lane * nwaves + wave < e.ngroups) gtab = e.ginfo[lane * nwaves + wave];
+    const __amdgpu_buffer_rsrc_t colq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colq, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valq, 0, 0x7FFFFFFF, 0x00020000);
     if (tid < P) T[e.zero_slot * P + tid] = 0.f;      // never written again
     // One-off stagger of the workgroups of an XCD (blockIdx % 8 selects the XCD): started in
     // lock-step, all CUs would stream from L2, gather from LDS and write to HBM at the same
@@ -281,13 +321,20 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             auto request = [&](int j, int q) {       // quad q of group j -> its ring slot
                 int qoff, len;
                 group_info(j, qoff, len);
-                rc[(QMAX * j + q) % RING] = e.colq[(size_t)(qoff + q) * 64 + lane];
-                rv[(QMAX * j + q) % RING] = e.valq[(size_t)(qoff + q) * 64 + lane];
+                if ((CG_X & 4) && j > 1) return;               // experiment: no operator loads after the prologue
+                if (q >= 2 && len <= 8) return;                // the third quad only where a row needs it
+                // buffer loads: descriptor + uniform offset in SGPRs, lane offset in one VGPR -- no
+                // 64-bit address arithmetic on the vector ALU
+                const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(colq_rsrc, lane * 8, (qoff + q) * 512, 0);
+                const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(valq_rsrc, lane * 16, (qoff + q) * 1024, 0);
+                rc[(QMAX * j + q) % RING] = make_uint2(c.x, c.y);
+                rv[(QMAX * j + q) % RING] = make_float4(v.x, v.y, v.z, v.w);
             };
             auto quad = [&](const uint2 c, const float4 v, float (&acc)[P]) {
                 Ent<P> t[4];
+                unsigned at[4] = {entry_ofs<P, 0>(c.x), entry_ofs<P, 1>(c.x), entry_ofs<P, 0>(c.y), entry_ofs<P, 1>(c.y)};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, (CG_X & 2) ? lane + 64 * i : slot_of(c, i));
+                for (int i = 0; i < 4; ++i) t[i] = lds_at<P>(T, (CG_X & 2) ? (lane + 64 * i) * 4 * P : at[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -432,10 +479,9 @@ cheb_step_global_kernel(const int32_t* __restrict__ rowptr, const int32_t* __res
 template <int P, int NJ, int NQ, int NTHR, bool ADJ>
 static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst,
                          int nplanes, int K, int copy_t0, hipStream_t stream) {
-    const size_t lds = (size_t)ell.lds_entries * P * sizeof(float);
+    const size_t lds = (size_t)lds_capacity(NJ, NTHR, P) * P * sizeof(float);
     static_assert(NQ <= NJ, "a linear piece is issued per group at most");
     auto kern = cheb_onchip_kernel<P, NJ, NQ, NTHR, ADJ>;
-    CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : per_cu;
     if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
@@ -444,7 +490,7 @@ static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* sr
     int grid = g->num_cus * per_cu;
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, stream, view(ell), src, dst, g->M, g->Mp,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), 0, stream, view(ell), src, dst, g->M, g->Mp,
                        nplanes, K, slab, copy_t0 | (g_ablate << 8));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
@@ -459,7 +505,9 @@ static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst,
     const Ell& ell = ADJ ? g->adj : g->fwd;
     const int rows = ell.ngroups * 64;
     const int Mq = g->Mp / 4;
-    auto fits = [&](int nj, int nq, int nthr) { return nj * nthr >= rows && nq * nthr >= Mq; };
+    auto fits = [&](int nj, int nq, int nthr) {
+        return nj * nthr >= rows && nq * nthr >= Mq && ell.lds_entries <= lds_capacity(nj, nthr, P);
+    };
 #define CG_TRY(NJ, NQ, NTHR) if (fits(NJ, NQ, NTHR)) return launch_onchip<P, NJ, NQ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
     CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
     if constexpr (P == 4) {
@@ -490,6 +538,7 @@ using namespace chebgcn;
 extern "C" int chebgcn_tune(int key, int value) {
     if (key == 0) { g_ablate = value; return 0; }
     if (key == 1 && (value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards
+    if (key == 2) { g_slot_order = value; return 0; }
     return -1;
 }
 

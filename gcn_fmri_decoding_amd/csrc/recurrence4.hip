@@ -46,6 +46,12 @@ __device__ __forceinline__ float4 ldg4(const float* ubase, unsigned byteoff) {
 __device__ __forceinline__ void stg4(float* ubase, unsigned byteoff, float4 v) {
     *reinterpret_cast<float4*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
 }
+__device__ __forceinline__ float ldg1(const float* ubase, unsigned byteoff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + byteoff);
+}
+__device__ __forceinline__ void stg1(float* ubase, unsigned byteoff, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
+}
 __device__ __forceinline__ unsigned slot_of(uint2 c, int i) {
     const unsigned w = (i & 2) ? c.y : c.x;
     return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
@@ -63,22 +69,26 @@ __device__ __forceinline__ float4 fma4(float s, float4 t, float4 a) {
     return make_float4(fmaf(s, t.x, a.x), fmaf(s, t.y, a.y), fmaf(s, t.z, a.z), fmaf(s, t.w, a.w));
 }
 
-// ENT = LDS entries (16 B each), NJ = row slices per thread, NQ = linear 4-vertex pieces per
-// thread and plane, NTHR = workgroup size.
-template <int ENT, int NJ, int NQ, int NTHR, bool ADJ>
+// ENT = LDS entries (16 B each), NJ = row slices per thread, NV = vertices per thread in the
+// linear (streaming) phases, NTHR = workgroup size.
+//
+// Streaming phases: lane l of the workgroup owns the vertices v = tid + u*NTHR (u < NV).  A wave
+// therefore touches 64 consecutive vertices of a plane with one 4-byte access per lane (256 B,
+// two full cache lines) and -- slots being numbered in vertex order -- 64 consecutive LDS
+// entries with one conflict-free 16-byte access per lane.  No transposes, no per-component
+// branches: a vertex without a slot is handled by predicating its lane.
+template <int ENT, int NJ, int NV, int NTHR, bool ADJ>
 __global__ void __launch_bounds__(NTHR)
 cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, int M, int Mp, int nplanes,
              int K, size_t slab, int flags) {
     __shared__ float4 T[ENT];                        // slot-indexed: the four planes of one vertex
     constexpr int nwaves = NTHR >> 6;
-    constexpr int QS = NJ / NQ;                      // a linear piece is copied out every QS groups
-    static_assert(QS >= 1 && NJ <= 64, "shape");
+    static_assert(NJ <= 64 && NV <= 2 * NJ, "shape");
     const int copy_t0 = flags & 1;
     const int abl = flags >> 8;                      // tools/kbench.py: 1 no stores, 2 no gather, 16 no loads
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Mq = Mp >> 2;
     const int ngrp = (nplanes + 3) >> 2;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto lds = [&](unsigned byteoff) -> float4 {
@@ -99,12 +109,20 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
         }
         rowreg[j2] = r;
     }
-    uint2 nsreg[NQ];                                 // LDS slots of the 4 vertices of linear piece u
+    constexpr int NV2 = (NV + 1) / 2;
+    unsigned vsreg[NV2];                             // LDS slot of the own vertex u (two per register), 0xFFFF = none
 #pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        const int q = tid + u * NTHR;
-        nsreg[u] = (q < Mq) ? reinterpret_cast<const uint2*>(e.nodeslot)[q] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (int u2 = 0; u2 < NV2; ++u2) {
+        unsigned r = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int v = tid + (2 * u2 + h) * NTHR;
+            const unsigned id = (2 * u2 + h < NV && v < Mp) ? e.nodeslot[v] : 0xFFFFu;
+            r |= id << (16 * h);
+        }
+        vsreg[u2] = r;
     }
+    auto vslot = [&](int u) -> unsigned { return (opaque(vsreg[u >> 1]) >> (16 * (u & 1))) & 0xFFFFu; };
     int2 gtab = make_int2(0, 0);                     // lane j: {quad offset, length} of group j*nwaves + wave
     if (lane < NJ && lane * nwaves + wave < e.ngroups) gtab = e.ginfo[lane * nwaves + wave];
     if (tid == 0) T[e.zero_slot] = zero4;            // never written again
@@ -125,104 +143,58 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             pv[p] = i < nplanes;
             pl[p] = (size_t)(pv[p] ? i : nplanes - 1) * Mp;
         }
-        float4 pre[NQ][4];                           // linear staging: input planes, G_j of the adjoint
-        auto fetch = [&](const float* base) {
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) {
-                const int q = tid + u * NTHR;
-                const unsigned qb = opaque((unsigned)q * 16u);     // not hoisted, not folded into a 64-bit base
-#pragma unroll
-                for (int p = 0; p < 4; ++p) pre[u][p] = zero4;
-                if (q < Mq && !(abl & 16)) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) pre[u][p] = ldg4(base + pl[p], qb);
-                }
-            }
-        };
-        // LDS image -> the four planes of slab `out` (forward), two plane pairs one after the other
-        // (8-byte LDS reads: half the live registers).  Isolated vertices have no slot: in an odd
-        // slab they are 0 like the zero slot; their values in the even slabs were stored when the
-        // input was staged, so there (`keep`) a piece that contains one stores its other
-        // components one by one.
+        // LDS image -> the four planes of slab `out` (forward).  A vertex without a slot reads
+        // the zero slot; isolated vertices were stored into the even slabs when the input was
+        // staged, so there (`keep`) their lanes do not store.
         auto copy_out = [&](int u, float* out, bool keep) {
-            const int q = tid + u * NTHR;
-            const unsigned qb = opaque((unsigned)q * 16u);     // not hoisted, not folded into a 64-bit base
-            if (q < Mq && !(abl & 1)) {
-                const uint2 nq = opaque(nsreg[u]);
-                unsigned at[4];
-                bool iso[4];
-                bool any_iso = false;
+            const int v = tid + u * NTHR;
+            const unsigned vb = opaque((unsigned)v * 4u);
+            if (v < Mp && !(abl & 1)) {
+                const unsigned id = vslot(u);
+                const bool none = id == 0xFFFFu;
+                const float4 t = T[none ? (unsigned)e.zero_slot : id];
+                if (!(keep && none && v < M)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned id = slot_of(nq, i);
-                    const bool none = id == 0xFFFFu;
-                    iso[i] = none && 4 * q + i < M;
-                    any_iso |= iso[i];
-                    at[i] = (none ? (unsigned)e.zero_slot : id) * 16u;
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float4 o[2];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(T) + at[i] + 8 * h);
-                        set_comp(o[0], i, t.x);
-                        set_comp(o[1], i, t.y);
-                    }
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        if (!pv[2 * h + p]) continue;
-                        float* plane = out + pl[2 * h + p];
-                        if (keep && any_iso) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                if (!iso[i]) *reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + qb + 4 * i) = comp(o[p], i);
-                        } else {
-                            stg4(plane, qb, o[p]);
-                        }
-                    }
+                    for (int p = 0; p < 4; ++p)
+                        if (pv[p]) stg1(out + pl[p], vb, comp(t, p));
                 }
             }
         };
 
         // ---- input planes -> LDS image (forward: and straight to slab 0) --------------------
-        fetch(src + in_base);
+        constexpr int NVH = (NV + 1) / 2;            // two batches: half the staging registers
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) {
-            const int q = tid + u * NTHR;
-                const unsigned qb = opaque((unsigned)q * 16u);     // not hoisted, not folded into a 64-bit base
-            if (q < Mq) {
-                const uint2 nq = opaque(nsreg[u]);
+        for (int u0 = 0; u0 < NV; u0 += NVH) {
+            float4 x[NVH];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned id = slot_of(nq, i);
-                    if (id != 0xFFFFu)
-                        T[id] = make_float4(comp(pre[u][0], i), comp(pre[u][1], i), comp(pre[u][2], i), comp(pre[u][3], i));
-                }
-                if (!ADJ && !(abl & 1)) {
-                    if (copy_t0) {
+            for (int uu = 0; uu < NVH; ++uu) {
+                const int v = tid + (u0 + uu) * NTHR;
+                const unsigned vb = opaque((unsigned)v * 4u);
+                x[uu] = zero4;
+                if (u0 + uu < NV && v < Mp && !(abl & 16))
+                    x[uu] = make_float4(ldg1(src + in_base + pl[0], vb), ldg1(src + in_base + pl[1], vb),
+                                        ldg1(src + in_base + pl[2], vb), ldg1(src + in_base + pl[3], vb));
+            }
 #pragma unroll
-                        for (int p = 0; p < 4; ++p)
-                            if (pv[p]) stg4(dst + pl[p], qb, pre[u][p]);
-                    }
-                    // an isolated vertex has T_k = (-1)^(k/2) x in the even slabs: stored here, once
-                    bool iso[4];
-                    bool any_iso = false;
+            for (int uu = 0; uu < NVH; ++uu) {
+                const int v = tid + (u0 + uu) * NTHR;
+                const unsigned vb = opaque((unsigned)v * 4u);
+                if (u0 + uu < NV && v < Mp) {
+                    const unsigned id = vslot(u0 + uu);
+                    if (id != 0xFFFFu) T[id] = x[uu];
+                    if (!ADJ && !(abl & 1)) {
+                        if (copy_t0) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        iso[i] = slot_of(nq, i) == 0xFFFFu && 4 * q + i < M;
-                        any_iso |= iso[i];
-                    }
-                    if (any_iso) {
-                        float sgn = -1.f;
-                        for (int k = 2; k < K; k += 2, sgn = -sgn) {
+                            for (int p = 0; p < 4; ++p)
+                                if (pv[p]) stg1(dst + pl[p], vb, comp(x[uu], p));
+                        }
+                        // an isolated vertex has T_k = (-1)^(k/2) x in the even slabs: stored here, once
+                        if (id == 0xFFFFu && v < M) {
+                            float sgn = -1.f;
+                            for (int k = 2; k < K; k += 2, sgn = -sgn) {
 #pragma unroll
-                            for (int p = 0; p < 4; ++p) {
-                                if (!pv[p]) continue;
-                                char* plane = reinterpret_cast<char*>(dst + (size_t)k * slab + pl[p]) + qb;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (iso[i]) *reinterpret_cast<float*>(plane + 4 * i) = sgn * comp(pre[u][p], i);
+                                for (int p = 0; p < 4; ++p)
+                                    if (pv[p]) stg1(dst + (size_t)k * slab + pl[p], vb, sgn * comp(x[uu], p));
                             }
                         }
                     }
@@ -260,6 +232,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             auto request = [&](int j, int q) {                   // quad q of group j -> its ring slot
                 int qoff, len;
                 group_info(j, qoff, len);
+                if ((CG_X & 4) && j > 1) return;               // experiment: no operator loads after the prologue
                 rc[(QMAX * j + q) % RING] = e.colq[(size_t)(qoff + q) * 64 + lane];
                 rv[(QMAX * j + q) % RING] = e.valq[(size_t)(qoff + q) * 64 + lane];
             };
@@ -277,7 +250,13 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 if (n / QMAX < NJ) request(n / QMAX, n % QMAX);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (do_out && (j % QS) == 0 && (j / QS) < NQ) copy_out(j / QS, out_slab, keep);
+                if (do_out) {
+                    // the vertices u in [j*NV/NJ, (j+1)*NV/NJ) go out with this group: small store
+                    // packets spread over the whole gather
+                    const int ua = j * NV / NJ, ub = (j + 1) * NV / NJ;
+                    if (ua < ub) copy_out(ua, out_slab, keep);
+                    if (ua + 1 < ub) copy_out(ua + 1, out_slab, keep);
+                }
                 int qoff, len;
                 group_info(j, qoff, len);
                 float4 acc = zero4;
@@ -298,7 +277,19 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
                                     fmaf(f, acc.w, -st[j].w));
             }
-            if (ADJ) fetch(src + (size_t)(K - 1 - step) * slab);      // G_j, added after the rotate
+            float4 gj[ADJ ? NV : 1];                 // G_j of the adjoint, added after the rotate
+            if (ADJ) {
+                const float* gs = src + (size_t)(K - 1 - step) * slab;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int v = tid + u * NTHR;
+                    const unsigned vb = opaque((unsigned)v * 4u);
+                    gj[u] = zero4;
+                    if (v < Mp && !(abl & 16))
+                        gj[u] = make_float4(ldg1(gs + pl[0], vb), ldg1(gs + pl[1], vb), ldg1(gs + pl[2], vb),
+                                            ldg1(gs + pl[3], vb));
+                }
+            }
             __syncthreads();                         // every gather (and copy-out read) of this step is done
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows ------------------------
 #pragma unroll
@@ -314,22 +305,15 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             if (ADJ) {
                 // ---- c_j += G_j, linear ---------------------------------------------------------
 #pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const int q = tid + u * NTHR;
-                    if (q < Mq) {
-                        const uint2 nq = opaque(nsreg[u]);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const unsigned id = slot_of(nq, i);
-                            if (id != 0xFFFFu) {
-                                float4 t = T[id];
-                                t.x += comp(pre[u][0], i);
-                                t.y += comp(pre[u][1], i);
-                                t.z += comp(pre[u][2], i);
-                                t.w += comp(pre[u][3], i);
-                                T[id] = t;
-                            }
-                        }
+                for (int u = 0; u < NV; ++u) {
+                    const unsigned id = vslot(u);
+                    if (id != 0xFFFFu) {
+                        float4 t = T[id];
+                        t.x += gj[u].x;
+                        t.y += gj[u].y;
+                        t.z += gj[u].z;
+                        t.w += gj[u].w;
+                        T[id] = t;
                     }
                 }
                 __syncthreads();
@@ -340,45 +324,30 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
         if (!ADJ) {
             const int ko = K - 1;
 #pragma unroll
-            for (int u = 0; u < NQ; ++u) copy_out(u, dst + (size_t)ko * slab, (ko & 1) == 0);
+            for (int u = 0; u < NV; ++u) copy_out(u, dst + (size_t)ko * slab, (ko & 1) == 0);
         } else {
             // dx; an isolated vertex has dx = G_0 - G_2 + G_4 - ...
 #pragma unroll
-            for (int u = 0; u < NQ; ++u) {
-                const int q = tid + u * NTHR;
-                const unsigned qb = opaque((unsigned)q * 16u);     // not hoisted, not folded into a 64-bit base
-                if (q < Mq && !(abl & 1)) {
-                    const uint2 nq = opaque(nsreg[u]);
-                    float4 t[4];
-                    bool iso[4];
-                    bool patch = false;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const unsigned id = slot_of(nq, i);
-                        const bool none = id == 0xFFFFu;
-                        iso[i] = none && 4 * q + i < M;
-                        patch |= iso[i];
-                        t[i] = T[none ? (unsigned)e.zero_slot : id];
-                    }
-                    float4 o[4];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        o[p] = make_float4(comp(t[0], p), comp(t[1], p), comp(t[2], p), comp(t[3], p));
-                    if (patch) {
+            for (int u = 0; u < NV; ++u) {
+                const int v = tid + u * NTHR;
+                const unsigned vb = opaque((unsigned)v * 4u);
+                if (v < Mp && !(abl & 1)) {
+                    const unsigned id = vslot(u);
+                    const bool none = id == 0xFFFFu;
+                    float4 t = T[none ? (unsigned)e.zero_slot : id];
+                    if (none && v < M) {
                         float sgn = 1.f;
                         for (int m = 0; m < K; m += 2, sgn = -sgn) {
-#pragma unroll
-                            for (int p = 0; p < 4; ++p) {
-                                const float4 x = ldg4(src + (size_t)m * slab + pl[p], qb);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (iso[i]) set_comp(o[p], i, comp(o[p], i) + sgn * comp(x, i));
-                            }
+                            const float* gs = src + (size_t)m * slab;
+                            t.x += sgn * ldg1(gs + pl[0], vb);
+                            t.y += sgn * ldg1(gs + pl[1], vb);
+                            t.z += sgn * ldg1(gs + pl[2], vb);
+                            t.w += sgn * ldg1(gs + pl[3], vb);
                         }
                     }
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
-                        if (pv[p]) stg4(dst + pl[p], qb, o[p]);
+                        if (pv[p]) stg1(dst + pl[p], vb, comp(t, p));
                 }
             }
         }
@@ -386,7 +355,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     }
 }
 
-template <int ENT, int NJ, int NQ, int NTHR, bool ADJ>
+template <int ENT, int NJ, int NV, int NTHR, bool ADJ>
 int launch4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
             hipStream_t stream) {
     const int per_cu = (160 * 1024) / (ENT * 16);
@@ -394,7 +363,7 @@ int launch4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst
     int grid = g->num_cus * (per_cu < 1 ? 1 : per_cu);
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
-    hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, NTHR, ADJ>), dim3(grid), dim3(NTHR), 0, stream, view(ell), src, dst,
+    hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NV, NTHR, ADJ>), dim3(grid), dim3(NTHR), 0, stream, view(ell), src, dst,
                        g->M, g->Mp, nplanes, K, slab, copy_t0 | (g_ablate << 8));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
@@ -403,8 +372,8 @@ int launch4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst
 // shape 0 = none, 1 = 5120 entries, 512 threads x 10 rows, 2 = 10240 entries, 768 threads x 14 rows
 int shape4(int lds_entries, int rows, int Mq) {
     if (rows <= 2048) return 0;                      // small graphs: the generic kernel of recurrence.hip
-    if (lds_entries <= 5120 && rows <= 10 * 512 && Mq <= 3 * 512) return 1;
-    if (lds_entries <= 10240 && rows <= 14 * 768 && Mq <= 4 * 768) return 2;
+    if (lds_entries <= 5120 && rows <= 10 * 512 && Mq * 4 <= 12 * 512) return 1;
+    if (lds_entries <= 10240 && rows <= 14 * 768 && Mq * 4 <= 14 * 768) return 2;
     return 0;
 }
 
@@ -417,8 +386,8 @@ int dispatch_onchip4(const chebgcn_graph* g, const float* src, float* dst, int n
                      hipStream_t stream) {
     const Ell& ell = ADJ ? g->adj : g->fwd;
     switch (shape4(ell.lds_entries, ell.ngroups * 64, g->Mp / 4)) {
-        case 1: return launch4<5120, 10, 3, 512, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
-        case 2: return launch4<10240, 14, 4, 768, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 1: return launch4<5120, 10, 12, 512, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 2: return launch4<10240, 14, 14, 768, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
         default: break;
     }
     return fail(CHEBGCN_EUNSUPPORTED, "recurrence: no four-plane kernel shape for %d rows", ell.ngroups * 64);

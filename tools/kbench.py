@@ -32,6 +32,7 @@ def main():
     ap.add_argument('--ablate', type=int, nargs='+', default=[0])
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=2, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
+    ap.add_argument('--slot-order', type=int, default=-1, help='chebgcn_tune(2, x): 0 component-major, 1 vertex-major slots')
     args = ap.parse_args()
 
     import torch
@@ -41,6 +42,7 @@ def main():
     Ls, perm = bench.load_graph(10000, 1, 0, 1, None)
     lib = _lib.lib()
     lib.chebgcn_tune(1, args.planes)
+    lib.chebgcn_tune(2, args.slot_order)
     g = ops.Graph(Ls[0], dev)
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
           g.query(11), flush=True)
