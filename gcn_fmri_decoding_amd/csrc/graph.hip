@@ -42,10 +42,10 @@ constexpr int kLdsBytes = 160 * 1024;     // LDS per workgroup on gfx950
 int g_prefer_planes = 2;                  // chebgcn_tune(1, planes); see graph_create
 int g_slot_order = -1;                    // chebgcn_tune(2, x): experiments, -1 = automatic
 
-// Planes per workgroup for an image of n vertices (+1 zero slot, rounded to 4 entries):
+// Planes per workgroup for an image of n vertices (+ zero and trash slot, rounded to 4 entries):
 // 4 if 16 B per vertex fit the LDS, else 2 if 8 B fit, else 0 (no on-chip path).
 static int planes_for(int n) {
-    const size_t entries = ((size_t)n + 1 + 3) & ~(size_t)3;
+    const size_t entries = ((size_t)n + 2 + 3) & ~(size_t)3;
     if (n >= 65535) return 0;
     if (entries * 16 <= (size_t)kLdsBytes) return 4;
     if (entries * 8 <= (size_t)kLdsBytes) return 2;
@@ -85,8 +85,36 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
                 order.push_back(v);
             }
     const int zero_slot = nslot;
-    const int lds_entries = (nslot + 1 + 3) & ~3;
+    const int lds_entries = (nslot + 2 + 3) & ~3;          // + zero slot + trash slot (zero_slot + 1)
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return rlen(a) > rlen(b); });
+    // Rows of equal length may take any lane.  The rotate phase of the kernels reads and writes
+    // the OWN row's entry of every lane with one LDS instruction; giving lane l a row whose slot
+    // is congruent to l modulo the number of entry-sized bank groups makes those accesses
+    // conflict-free (every lane set of MI355X_MICROARCH.md "LDS" then covers each bank once).
+    {
+        const int nb = planes == 4 ? 16 : 32;
+        std::vector<int32_t> placed;
+        placed.reserve(order.size());
+        size_t a = 0;
+        while (a < order.size()) {
+            size_t b = a;
+            while (b < order.size() && rlen(order[b]) == rlen(order[a])) ++b;       // one length class
+            std::vector<std::vector<int32_t>> bucket(nb);
+            for (size_t i = b; i-- > a;) bucket[nodeslot[order[i]] % nb].push_back(order[i]);   // pop_back = ascending
+            for (size_t i = a; i < b; ++i) {
+                int want = (int)(placed.size() % 64) % nb;
+                if (bucket[want].empty()) {                      // residue used up: take from the fullest
+                    want = 0;
+                    for (int k = 1; k < nb; ++k)
+                        if (bucket[k].size() > bucket[want].size()) want = k;
+                }
+                placed.push_back(bucket[want].back());
+                bucket[want].pop_back();
+            }
+            a = b;
+        }
+        order.swap(placed);
+    }
     const int nranked = (int)order.size();
     const int ngroups = (nranked + 63) / 64;
     std::vector<int2> ginfo(ngroups);
@@ -257,7 +285,7 @@ extern "C" int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr, c
         // M ~ 10k (fewer waves, register spills), so they are opt-in: chebgcn_tune(1, 4)
         planes = planes_for(M) >= 2 ? 2 : 0;
         if (g_prefer_planes == 4 && planes_for(nactive) == 4) {
-            const int rows = ((nactive + 63) / 64) * 64, entries = (nactive + 1 + 3) & ~3;
+            const int rows = ((nactive + 63) / 64) * 64, entries = (nactive + 2 + 3) & ~3;
             if (rows <= 2048 || onchip4_fits(entries, rows, g->Mp / 4)) planes = 4;
         }
     }

@@ -170,6 +170,11 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     const __amdgpu_buffer_rsrc_t colq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colq, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valq, 0, 0x7FFFFFFF, 0x00020000);
     if (tid < P) T[e.zero_slot * P + tid] = 0.f;      // never written again
+    // Vertices / ranks without an LDS slot (id 0xFFFF) read the zero slot and write a trash slot:
+    // straight-line code whose LDS accesses can all be in flight together, instead of a branch
+    // and a round trip per access.
+    auto rd_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot : id; };
+    auto wr_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot + 1u : id; };
     // One-off stagger of the workgroups of an XCD (blockIdx % 8 selects the XCD): started in
     // lock-step, all CUs would stream from L2, gather from LDS and write to HBM at the same
     // times; spread over roughly one step they overlap each other's phases instead.
@@ -239,16 +244,10 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             } else {
                 float4 o[P];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned sl = slot_of(nq, i);
-                    if (sl != 0xFFFFu) {
-                        const Ent<P> t = lds_get<P>(T, sl);
+                for (int i = 0; i < 4; ++i) {                    // no branches: a vertex without a slot reads 0
+                    const Ent<P> t = lds_get<P>(T, rd_slot(slot_of(nq, i)));
 #pragma unroll
-                        for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
-                    } else {
-#pragma unroll
-                        for (int p = 0; p < P; ++p) set_comp(o[p], i, 0.f);
-                    }
+                    for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
                 }
 #pragma unroll
                 for (int p = 0; p < P; ++p)
@@ -270,13 +269,10 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 const uint2 nq = opaque(nsreg[u]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const unsigned sl = slot_of(nq, i);
-                    if (sl != 0xFFFFu) {
-                        Ent<P> t;
+                    Ent<P> t;
 #pragma unroll
-                        for (int p = 0; p < P; ++p) t.x[p] = comp(pre[u][p], i);
-                        lds_put<P>(T, sl, t);
-                    }
+                    for (int p = 0; p < P; ++p) t.x[p] = comp(pre[u][p], i);
+                    lds_put<P>(T, wr_slot(slot_of(nq, i)), t);
                 }
                 if (!ADJ && copy_t0 && !(abl & 1)) {            // T_0 = x goes straight to slab 0
 #pragma unroll
@@ -373,18 +369,23 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 // request G_j now; it is added after the rotate (two barriers later)
                 fetch(src + (size_t)(K - 1 - step) * slab, grp);
             }
-            __syncthreads();                  // every gather (and copy-out read) of this step is done
+            if (!(CG_X & 32)) __syncthreads();                  // every gather (and copy-out read) of this step is done
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
+            if (!(CG_X & 16)) {
+                Ent<P> prev[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
-                if (r != 0xFFFFu) {
-                    const Ent<P> old = lds_get<P>(T, r);
-                    lds_put<P>(T, r, st[j]);
-                    st[j] = old;
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                    prev[j] = lds_get<P>(T, rd_slot(r));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                    lds_put<P>(T, wr_slot(r), st[j]);
+                    st[j] = prev[j];
                 }
             }
-            __syncthreads();
+            if (!(CG_X & 32)) __syncthreads();
             if (ADJ) {
                 // ---- c_j += G_j, linear --------------------------------------------------------
 #pragma unroll
@@ -392,15 +393,14 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                     const int q = tid + u * nthr;
                     if (q < Mq) {
                         const uint2 nq = opaque(nsreg[u]);
+                        Ent<P> t[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, rd_slot(slot_of(nq, i)));
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const unsigned sl = slot_of(nq, i);
-                            if (sl != 0xFFFFu) {
-                                Ent<P> t = lds_get<P>(T, sl);
 #pragma unroll
-                                for (int p = 0; p < P; ++p) t.x[p] += comp(pre[u][p], i);
-                                lds_put<P>(T, sl, t);
-                            }
+                            for (int p = 0; p < P; ++p) t[i].x[p] += comp(pre[u][p], i);
+                            lds_put<P>(T, wr_slot(slot_of(nq, i)), t[i]);
                         }
                     }
                 }
@@ -426,15 +426,10 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const unsigned sl = slot_of(nq, i);
-                        if (sl != 0xFFFFu) {
-                            const Ent<P> t = lds_get<P>(T, sl);
+                        const Ent<P> t = lds_get<P>(T, rd_slot(sl));
+                        if (sl == 0xFFFFu && 4 * q + i < M) iso |= 1u << i;
 #pragma unroll
-                            for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
-                        } else {
-                            if (4 * q + i < M) iso |= 1u << i;
-#pragma unroll
-                            for (int p = 0; p < P; ++p) set_comp(o[p], i, 0.f);
-                        }
+                        for (int p = 0; p < P; ++p) set_comp(o[p], i, t.x[p]);
                     }
                     if (P == 4 && iso != 0) {
                         float sgn = 1.f;

@@ -126,6 +126,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     int2 gtab = make_int2(0, 0);                     // lane j: {quad offset, length} of group j*nwaves + wave
     if (lane < NJ && lane * nwaves + wave < e.ngroups) gtab = e.ginfo[lane * nwaves + wave];
     if (tid == 0) T[e.zero_slot] = zero4;            // never written again
+    // no slot (id 0xFFFF): read the zero slot, write the trash slot -- straight-line LDS code
+    auto rd_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot : id; };
+    auto wr_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot + 1u : id; };
     if (!(abl & 32)) {                               // spread the workgroups of an XCD over one step
         const int reps = 2 * ((blockIdx.x >> 3) & 31);
         for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
@@ -181,7 +184,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 const unsigned vb = opaque((unsigned)v * 4u);
                 if (u0 + uu < NV && v < Mp) {
                     const unsigned id = vslot(u0 + uu);
-                    if (id != 0xFFFFu) T[id] = x[uu];
+                    T[wr_slot(id)] = x[uu];
                     if (!ADJ && !(abl & 1)) {
                         if (copy_t0) {
 #pragma unroll
@@ -292,13 +295,18 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             }
             __syncthreads();                         // every gather (and copy-out read) of this step is done
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows ------------------------
+            {
+                float4 prev[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
-                if (r != 0xFFFFu) {
-                    const float4 old = T[r];
-                    T[r] = st[j];
-                    st[j] = old;
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                    prev[j] = T[rd_slot(r)];
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                    T[wr_slot(r)] = st[j];
+                    st[j] = prev[j];
                 }
             }
             __syncthreads();
@@ -307,14 +315,12 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
 #pragma unroll
                 for (int u = 0; u < NV; ++u) {
                     const unsigned id = vslot(u);
-                    if (id != 0xFFFFu) {
-                        float4 t = T[id];
-                        t.x += gj[u].x;
-                        t.y += gj[u].y;
-                        t.z += gj[u].z;
-                        t.w += gj[u].w;
-                        T[id] = t;
-                    }
+                    float4 t = T[rd_slot(id)];
+                    t.x += gj[u].x;
+                    t.y += gj[u].y;
+                    t.z += gj[u].z;
+                    t.w += gj[u].w;
+                    T[wr_slot(id)] = t;
                 }
                 __syncthreads();
             }
