@@ -13,7 +13,7 @@
 //     a byte offset with one SDWA shift), all streaming addresses are uniform base + 32-bit
 //     lane offset.
 // Reference semantics: lib_new/models_gcn.py:587-617 (chebyshev5), forward; the adjoint is the
-// Clenshaw form of its gradient (oracle/layers_ref.py chebyshev5_bwd).
+// Clenshaw form of its gradient (see recurrence.hip).
 #include "common.h"
 
 namespace chebgcn {
