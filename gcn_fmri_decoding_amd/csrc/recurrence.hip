@@ -39,6 +39,7 @@ namespace chebgcn {
 int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
 extern int g_prefer_planes;
 extern int g_slot_order;
+int g_wide = 0;            // chebgcn_tune(3, 1): prefer the 1024-thread shape (experiment)
 
 #ifndef CG_X
 #define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
@@ -509,7 +510,9 @@ static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst,
         // beyond 2048 rows: the dedicated kernel of recurrence4.hip
         return dispatch_onchip4<ADJ>(g, src, dst, nplanes, K, copy_t0, stream);
     } else {
-        CG_TRY(8, 3, 512); CG_TRY(8, 3, 768); CG_TRY(11, 4, 768); CG_TRY(14, 4, 768);        // <= 10752
+        CG_TRY(8, 3, 512); CG_TRY(8, 3, 768); CG_TRY(11, 4, 768);
+        if (g_wide) { CG_TRY(11, 3, 1024); }                                                  // experiment: 16 waves
+        CG_TRY(14, 4, 768);                                                                   // <= 10752
         CG_TRY(24, 7, 512); CG_TRY(32, 9, 512); CG_TRY(40, 11, 512);                         // <= 20480
     }
 #undef CG_TRY
@@ -534,6 +537,7 @@ extern "C" int chebgcn_tune(int key, int value) {
     if (key == 0) { g_ablate = value; return 0; }
     if (key == 1 && (value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards
     if (key == 2) { g_slot_order = value; return 0; }
+    if (key == 3) { g_wide = value; return 0; }
     return -1;
 }
 

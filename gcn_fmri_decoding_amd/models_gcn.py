@@ -606,8 +606,11 @@ class cgcnn(base_model):
                 next_stack = torch.empty((self.K[i + 1], B, self.F[i], self.graphs[i + 1].Mp), dtype=torch.float32,
                                          device=x.device)
                 out = next_stack[0]
+            # training: the layer's gradients go straight into the flat (zeroed) gradient buffer
+            direct = self.training_mode and W.grad is not None and b.grad is not None and torch.is_grad_enabled()
             x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
-                              BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out)
+                              BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out,
+                              dW=W.grad if direct else None, dbias=b.grad if direct else None)
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
         return self._head(ops.FeatureMean.apply(x, M_last), dropout)

@@ -220,6 +220,11 @@ def _workspace(nbytes, device):
     return ws
 
 
+def _check_grad_buffer(buf, shape, what):
+    if tuple(buf.shape) != tuple(shape) or not buf.is_contiguous() or buf.dtype != torch.float32 or not buf.is_cuda:
+        raise ValueError('%s buffer must be a contiguous float32 device tensor of shape %s' % (what, tuple(shape)))
+
+
 class ChebConv(torch.autograd.Function):
     """y = pool(act(sum_k T_k(L~) x W_k + bias)) on plane storage tensors.
 
@@ -271,12 +276,14 @@ class ChebConv(torch.autograd.Function):
         ctx.save_for_backward(stack, Wc, out, argmax)
         ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.lib()
         stack, Wc, out, argmax = ctx.saved_tensors
+        dW_buf, dbias_buf = ctx.grad_bufs
         B, M, Fin, K, Fout, pool, pool_kind, relu, bias_kind = ctx.cfg
         g = ctx.graph
         gout = gout.contiguous()
@@ -284,7 +291,11 @@ class ChebConv(torch.autograd.Function):
         dy = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev)
         dbias = None
         if bias_kind != BIAS_NONE and ctx.needs_input_grad[2]:
-            dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
+            if dbias_buf is not None:
+                _check_grad_buffer(dbias_buf, ctx.bias_shape, 'dbias')
+                dbias = dbias_buf                 # zeroed by the owner; the kernel accumulates
+            else:
+                dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
         Mo = M // pool
         _lib.check(_launch('brelu_pool_bwd', 4.0 * B * Fout * (2 * Mo + M), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
             _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bias_kind if dbias is not None else BIAS_NONE, B, M, Fout,
@@ -293,7 +304,11 @@ class ChebConv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             nbytes = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
             ws = _workspace(nbytes, dev)
-            dW = torch.empty((Fin * K, Fout), dtype=torch.float32, device=dev)
+            if dW_buf is not None:
+                _check_grad_buffer(dW_buf, (Fin * K, Fout), 'dW')
+                dW = dW_buf                       # written, not accumulated: one use per step
+            else:
+                dW = torch.empty((Fin * K, Fout), dtype=torch.float32, device=dev)
             _lib.check(_launch('contract_bwd_w', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
                                lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
                                                                   K, Fout, _stream())), 'contract_bwd_w')
@@ -306,19 +321,27 @@ class ChebConv(torch.autograd.Function):
             dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
             _lib.check(_launch('recurrence_bwd', 4.0 * B * M * Fin * (K + 1), 0.0, lambda: lib.chebgcn_recurrence_bwd(
                 g.handle, _p(gstack), _p(dx), B, Fin, K, _stream())), 'recurrence_bwd')
-        return dx, dW, dbias, None, None, None, None, None, None, None
+        # gradients written into the caller's buffers are not handed to autograd a second time
+        return (dx, None if dW_buf is not None else dW, None if dbias_buf is not None else dbias,
+                None, None, None, None, None, None, None)
 
 
 class Buffers:
-    """Preallocated stack / output buffers for ``cheb_conv`` (plain object, not a tensor)."""
-    __slots__ = ('stack', 'out')
+    """Preallocated buffers for ``cheb_conv`` (plain object, not a tensor).  ``stack`` / ``out``:
+    see ChebConv.  ``dW`` / ``dbias``: gradient buffers the backward pass ACCUMULATES into in place
+    of returning the gradients to autograd -- the model hands over views of its flat, zeroed
+    gradient buffer and saves an add (and a zero fill) per variable and step."""
+    __slots__ = ('stack', 'out', 'dW', 'dbias')
 
-    def __init__(self, stack=None, out=None):
-        self.stack, self.out = stack, out
+    def __init__(self, stack=None, out=None, dW=None, dbias=None):
+        self.stack, self.out, self.dW, self.dbias = stack, out, dW, dbias
 
 
-def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None):
-    bufs = Buffers(stack, out) if (stack is not None or out is not None) else None
+def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
+              dW=None, dbias=None):
+    bufs = None
+    if stack is not None or out is not None or dW is not None or dbias is not None:
+        bufs = Buffers(stack, out, dW, dbias)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 

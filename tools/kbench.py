@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=2, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
     ap.add_argument('--slot-order', type=int, default=-1, help='chebgcn_tune(2, x): 0 component-major, 1 vertex-major slots')
+    ap.add_argument('--wide', type=int, default=0, help='chebgcn_tune(3, x): 1 = 1024-thread recurrence shape')
     args = ap.parse_args()
 
     import torch
@@ -43,6 +44,7 @@ def main():
     lib = _lib.lib()
     lib.chebgcn_tune(1, args.planes)
     lib.chebgcn_tune(2, args.slot_order)
+    lib.chebgcn_tune(3, args.wide)
     g = ops.Graph(Ls[0], dev)
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
           g.query(11), flush=True)
