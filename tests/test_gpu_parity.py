@@ -440,6 +440,60 @@ def test_four_plane_kernel_matches_two_plane(ops, dev, lvl, B, Fin, K):
     close(stack_to_ref(s4, M), ref, what='4-plane stack')
 
 
+@pytest.mark.parametrize('nodes,B,Fin,K', [(10000, 3, 3, 5), (4000, 2, 5, 4), (10000, 1, 2, 25)])
+def test_four_plane_large_graph_kernel(ops, dev, nodes, B, Fin, K):
+    """recurrence4.hip (more than 2048 ranked rows): 16-byte LDS entries for the active vertices
+    only, isolated ("fake") vertices stored at staging; B*Fin is not a multiple of 4, x and G are
+    non-zero at the fake vertices.  Checked against the two-plane kernel, the adjoint identity
+    and the oracle on two planes."""
+    from gcn_fmri_decoding_amd import _lib, graph
+    Ls, perm, _ = graph.synthetic_graph(nodes, k=8, levels=1)
+    L = Ls[0]
+    M = L.shape[0]
+    g2 = ops.Graph(L, dev)
+    assert g2.query(6) == 2
+    _lib.lib().chebgcn_tune(1, 4)
+    try:
+        g4 = ops.Graph(L, dev)
+    finally:
+        _lib.lib().chebgcn_tune(1, 2)
+    assert g4.query(6) == 4 and 2048 < g4.query(7) < M        # some vertices are isolated
+    torch.manual_seed(nodes + K)
+    x = torch.randn(B, Fin, g2.Mp, device=dev)
+    G = torch.randn(K, B, Fin, g2.Mp, device=dev)
+    x[:, :, M:] = 0
+    G[:, :, :, M:] = 0
+    s2, d2 = _run_fwd_bwd(ops, g2, x, G, K)
+    s4, d4 = _run_fwd_bwd(ops, g4, x, G, K)
+    close(s4[:, :, :, :M].cpu().numpy(), s2[:, :, :, :M].cpu().numpy(), what='4-plane vs 2-plane stack')
+    close(d4[:, :, :M].cpu().numpy(), d2[:, :, :M].cpu().numpy(), what='4-plane vs 2-plane dx')
+    lhs = (s4[:, :, :, :M].double() * G[:, :, :, :M].double()).sum().item()
+    rhs = (x[:, :, :M].double() * d4[:, :, :M].double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+    Lr = R.rescaled_laplacian(L, np.float32)
+    xp = x[B - 1, Fin - 2:Fin, :M].cpu().numpy().T.copy()                 # the last (partial) plane group
+    ref = GR.chebyshev(Lr, xp, K)
+    got = s4[:, B - 1, Fin - 2:Fin, :M].permute(0, 2, 1).cpu().numpy()
+    close(got, ref, what='4-plane stack vs oracle')
+    # in-place T_0 (x is slab 0 of the stack)
+    s4b = torch.full((K, B, Fin, g4.Mp), float('nan'), device=dev)
+    s4b[0] = x
+    _lib.check(_lib.lib().chebgcn_recurrence_fwd(g4.handle, ops._p(s4b[0]), ops._p(s4b), B, Fin, K, ops._stream()), 'fwd')
+    assert torch.equal(s4b[:, :, :, :M], s4[:, :, :, :M])
+
+
+def test_operator_layout_statistics(ops, dev):
+    """graph_query 9..11: modelled LDS cycles of one gather pass in the caller's entry order, after
+    the bank-aware placement of build_ell, and without any conflict."""
+    from gcn_fmri_decoding_amd import graph
+    Ls, _, _ = graph.synthetic_graph(4000, k=8, levels=1)
+    g = ops.Graph(Ls[0], dev)
+    before, after, ideal = g.query(9), g.query(10), g.query(11)
+    assert ideal > 0 and ideal <= after <= before
+    assert after < 0.75 * before                      # the placement removes a good part of the conflicts
+    assert g.query(8) <= 160 * 1024 and g.query(5) >= 8
+
+
 def test_out_of_lds_fallback(ops, dev):
     """A graph too large for the LDS image (M > 20480) takes the kernel-per-step path."""
     rs = np.random.RandomState(5)
