@@ -44,6 +44,9 @@ int g_wide = 0;            // chebgcn_tune(3, 1): prefer the 1024-thread shape (
 #ifndef CG_X
 #define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
 #endif
+#ifndef CG_ABL
+#define CG_ABL 0             // 1: honour the ablation bits of chebgcn_tune(0, bits) (tools/xbuild.sh); 0 in production
+#endif
 constexpr int QMAX = 3;      // quads (4 operator entries each) requested per group, always, one group ahead
 static_assert(QMAX <= kQuadPad && QMAX == kQuadMin, "the operator arrays are padded for the unconditional requests");
 
@@ -69,6 +72,15 @@ __device__ __forceinline__ uint2 opaque(uint2 x) { asm volatile("" : "+v"(x.x), 
 __host__ __device__ constexpr int lds_capacity(int nj, int nthr, int planes) {
     return (nj * nthr + 4) * planes * 4 <= 160 * 1024 ? nj * nthr + 4 : 160 * 1024 / (planes * 4);
 }
+
+// In-kernel phase stamps (CG_X & 64, tools/xbuild.sh): lane 0 of every wave of workgroup
+// g_dbg_block records the cycle counter at phase boundaries of its SECOND plane group.
+__device__ long long g_dbg[16 * 64];
+#define CG_STAMP(id)                                                                          \
+    do {                                                                                      \
+        if ((CG_X & 64) && (id) < 64 && lane == 0 && blockIdx.x == 37 && grp == blockIdx.x + (int)gridDim.x) \
+            g_dbg[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();                \
+    } while (0)
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -134,7 +146,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     const int copy_t0 = flags & 1;
     // ablation bits for tools/kbench.py (always 0 in production):
     // 1 = no global stores, 2 = no gather, 16 = no global loads, 32 = no start stagger
-    const int abl = flags >> 8;
+    const int abl = CG_ABL ? flags >> 8 : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -260,9 +272,12 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     int grp = blockIdx.x;
     const size_t in_base = ADJ ? (size_t)(K - 1) * slab : 0;
     __syncthreads();
+    // The input of a plane group is requested while the previous group finishes (its last rotate
+    // and copy-out), so the HBM latency and the burst of one workgroup's 2*P*Mp bytes are hidden.
+    if (grp < ngrp) fetch(src + in_base, grp);
     for (; grp < ngrp; grp += gridDim.x) {
         // ---- input planes -> LDS image ----------------------------------------------------------
-        fetch(src + in_base, grp);
+        CG_STAMP(0);
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int q = tid + u * nthr;
@@ -282,7 +297,9 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 }
             }
         }
+        CG_STAMP(1);
         __syncthreads();
+        CG_STAMP(2);
 
         Ent<P> st[NJ];                        // T_{k-2} of the own rows, replaced by T_k in place
 #pragma unroll
@@ -290,7 +307,70 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
             for (int p = 0; p < P; ++p) st[j].x[p] = 0.f;
 
+        // Closes step `sdone`: once every wave has finished its gather, LDS <- T_k and the
+        // registers <- T_{k-1} of the own rows (adjoint: then c_j += G_j).  Runs at the top of the
+        // next step and, for the last step, after the loop.
+        // Requests the next group's input (the else branch ends the live range of the old staging registers)
+        auto fetch_next = [&]() {
+            if (grp + (int)gridDim.x < ngrp) fetch(src + in_base, grp + gridDim.x);
+            else {
+#pragma unroll
+                for (int u = 0; u < NQ; ++u)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) pre[u][p] = zero4;
+            }
+        };
+        auto finish_step = [&](int sdone, bool last) {
+            if (ADJ && (CG_X & 2048)) fetch(src + (size_t)(K - 1 - sdone) * slab, grp);   // experiment: before the barrier
+            CG_STAMP(4 * sdone + 0);
+            if (!(CG_X & 32)) __syncthreads();                  // every gather (and copy-out read) of this step is done
+            CG_STAMP(4 * sdone + 1);
+            // forward: only now, behind the barrier -- HBM loads queued while other waves still
+            // gather would hold up their operator loads (the vector memory pipeline returns in order)
+            if (!ADJ && last) fetch_next();
+            // adjoint: G_j of the finished step, added after the rotate
+            if (ADJ && !(CG_X & 2048)) fetch(src + (size_t)(K - 1 - sdone) * slab, grp);
+            // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
+            if (!(CG_X & 16)) {
+                Ent<P> prev[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                    prev[j] = lds_get<P>(T, rd_slot(r));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                    lds_put<P>(T, wr_slot(r), st[j]);
+                    st[j] = prev[j];
+                }
+            }
+            CG_STAMP(4 * sdone + 2);
+            if (!(CG_X & 32)) __syncthreads();
+            CG_STAMP(4 * sdone + 3);
+            if (ADJ) {
+                // ---- c_j += G_j, linear --------------------------------------------------------
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const int q = tid + u * nthr;
+                    if (q < Mq) {
+                        const uint2 nq = opaque(nsreg[u]);
+                        Ent<P> t[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, rd_slot(slot_of(nq, i)));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int p = 0; p < P; ++p) t[i].x[p] += comp(pre[u][p], i);
+                            lds_put<P>(T, wr_slot(slot_of(nq, i)), t[i]);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+                };
         for (int step = 1; step < K; ++step) {
+            if (step > 1) finish_step(step - 1, false);
             const float f = ADJ ? (step == K - 1 ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
             // forward: slab step-1 is written out while this step gathers; an isolated vertex has
             // T_k = 0 for odd k and (-1)^(k/2) x for even k
@@ -331,7 +411,9 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 Ent<P> t[4];
                 unsigned at[4] = {entry_ofs<P, 0>(c.x), entry_ofs<P, 1>(c.x), entry_ofs<P, 0>(c.y), entry_ofs<P, 1>(c.y)};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = lds_at<P>(T, (CG_X & 2) ? (lane + 64 * i) * 4 * P : at[i]);
+                for (int i = 0; i < 4; ++i)
+                    t[i] = lds_at<P>(T, (CG_X & 512) ? (at[i] & 4u) + (lane + 64 * i) * 4 * P       // conflict-free, still data-dependent
+                                        : (CG_X & 2) ? (lane + 64 * i) * 4 * P : at[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -344,6 +426,15 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             for (int j = 0; j < NJ; ++j) {
                 if (!ADJ && do_out && (j % QS) == 0 && (j / QS) < NQ)       // one linear piece every QS groups
                     copy_out_piece(j / QS, out_slab, grp, iso_sign, src);
+                // waves that are ahead yield to the ones behind, so that the waves of a SIMD reach
+                // the barrier together instead of the oldest finishing early (fewer waves = less overlap)
+                if (!(CG_X & 1024) && NJ >= 4 && (j == 0 || (4 * j) / NJ != (4 * (j - 1)) / NJ)) {
+                    const int pr = 3 - (4 * j) / NJ;
+                    if (pr == 3) __builtin_amdgcn_s_setprio(3);
+                    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
                 int qoff, len;
                 group_info(j, qoff, len);
                 float acc[P];
@@ -366,48 +457,9 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
                 for (int p = 0; p < P; ++p) st[j].x[p] = fmaf(f, acc[p], -st[j].x[p]);
             }
-            if (ADJ) {
-                // request G_j now; it is added after the rotate (two barriers later)
-                fetch(src + (size_t)(K - 1 - step) * slab, grp);
-            }
-            if (!(CG_X & 32)) __syncthreads();                  // every gather (and copy-out read) of this step is done
-            // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
-            if (!(CG_X & 16)) {
-                Ent<P> prev[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
-                    prev[j] = lds_get<P>(T, rd_slot(r));
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
-                    lds_put<P>(T, wr_slot(r), st[j]);
-                    st[j] = prev[j];
-                }
-            }
-            if (!(CG_X & 32)) __syncthreads();
-            if (ADJ) {
-                // ---- c_j += G_j, linear --------------------------------------------------------
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const int q = tid + u * nthr;
-                    if (q < Mq) {
-                        const uint2 nq = opaque(nsreg[u]);
-                        Ent<P> t[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) t[i] = lds_get<P>(T, rd_slot(slot_of(nq, i)));
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                            for (int p = 0; p < P; ++p) t[i].x[p] += comp(pre[u][p], i);
-                            lds_put<P>(T, wr_slot(slot_of(nq, i)), t[i]);
-                        }
-                    }
-                }
-                __syncthreads();
-            }
         }
+        finish_step(K - 1, true);
+        if (ADJ) fetch_next();
 
         // ---- stream the last image out ---------------------------------------------------------
         if (!ADJ) {
@@ -450,7 +502,9 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 }
             }
         }
+        CG_STAMP(40);
         __syncthreads();                      // LDS reads done before the image is overwritten
+        CG_STAMP(41);
     }
 }
 
@@ -533,6 +587,10 @@ static int step_global(const chebgcn_graph* g, const Ell& ell, const float* src,
 using namespace chebgcn;
 
 // Undeclared tuning hook for tools/kbench.py (not part of the ABI in include/chebgcn.h).
+extern "C" int chebgcn_debug_stamps(long long* out) {       // CG_X & 64 builds only (tools/kbench.py --stamps)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(chebgcn::g_dbg), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : -1;
+}
+
 extern "C" int chebgcn_tune(int key, int value) {
     if (key == 0) { g_ablate = value; return 0; }
     if (key == 1 && (value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards

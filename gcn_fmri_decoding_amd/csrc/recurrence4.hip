@@ -19,14 +19,24 @@
 namespace chebgcn {
 
 extern int g_ablate;
+__device__ long long g_dbg4[16 * 64];            // phase stamps of CG_X & 64 builds (tools/kbench.py --stamps)
 
 namespace {
 
 #ifndef CG_X
 #define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
 #endif
+#ifndef CG_ABL
+#define CG_ABL 0
+#endif
 
 constexpr int QMAX = kQuadMin;   // quads stored for every group and requested one group ahead
+
+#define CG_STAMP(id)                                                                          \
+    do {                                                                                      \
+        if ((CG_X & 64) && (id) < 64 && lane == 0 && blockIdx.x == 37 && grp == (int)(blockIdx.x + gridDim.x)) \
+            g_dbg4[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();                \
+    } while (0)
 
 // byte offset of the 16-byte LDS entry named by the low / high 16 bits of w: one VALU op
 __device__ __forceinline__ unsigned ofs_lo(unsigned w) {
@@ -85,7 +95,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     constexpr int nwaves = NTHR >> 6;
     static_assert(NJ <= 64 && NV <= 2 * NJ, "shape");
     const int copy_t0 = flags & 1;
-    const int abl = flags >> 8;                      // tools/kbench.py: 1 no stores, 2 no gather, 16 no loads
+    const int abl = CG_ABL ? flags >> 8 : 0;         // tools/kbench.py (xbuild only): 1 no stores, 2 no gather, 16 no loads
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,6 +175,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
         };
 
         // ---- input planes -> LDS image (forward: and straight to slab 0) --------------------
+        CG_STAMP(0);
         constexpr int NVH = (NV + 1) / 2;            // two batches: half the staging registers
 #pragma unroll
         for (int u0 = 0; u0 < NV; u0 += NVH) {
@@ -204,7 +215,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 }
             }
         }
+        CG_STAMP(1);
         __syncthreads();
+        CG_STAMP(2);
 
         float4 st[NJ];                               // T_{k-2} of the own rows, replaced by T_k in place
 #pragma unroll
@@ -293,7 +306,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                                             ldg1(gs + pl[3], vb));
                 }
             }
+            CG_STAMP(4 * step + 0);
             __syncthreads();                         // every gather (and copy-out read) of this step is done
+            CG_STAMP(4 * step + 1);
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows ------------------------
             {
                 float4 prev[NJ];
@@ -309,7 +324,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                     st[j] = prev[j];
                 }
             }
+            CG_STAMP(4 * step + 2);
             __syncthreads();
+            CG_STAMP(4 * step + 3);
             if (ADJ) {
                 // ---- c_j += G_j, linear ---------------------------------------------------------
 #pragma unroll
@@ -357,7 +374,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 }
             }
         }
+        CG_STAMP(40);
         __syncthreads();                             // LDS reads done before the image is overwritten
+        CG_STAMP(41);
     }
 }
 
@@ -403,3 +422,7 @@ template int dispatch_onchip4<false>(const chebgcn_graph*, const float*, float*,
 template int dispatch_onchip4<true>(const chebgcn_graph*, const float*, float*, int, int, int, hipStream_t);
 
 }  // namespace chebgcn
+
+extern "C" int chebgcn_debug_stamps4(long long* out) {      // CG_X & 64 builds only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(chebgcn::g_dbg4), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : -1;
+}

@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=2, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
     ap.add_argument('--slot-order', type=int, default=-1, help='chebgcn_tune(2, x): 0 component-major, 1 vertex-major slots')
+    ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
     ap.add_argument('--wide', type=int, default=0, help='chebgcn_tune(3, x): 1 = 1024-thread recurrence shape')
     args = ap.parse_args()
 
@@ -108,6 +109,18 @@ def main():
                      'min_ms': best, 'GBps': nbytes / med / 1e6, 'frac_hbm': nbytes / med / 1e6 / 8000.0,
                      'TFLOPs': flops / med / 1e9}
                 results.append(r)
+                if args.stamps and name.startswith('recurrence'):
+                    import ctypes
+                    buf = (ctypes.c_longlong * (16 * 64))()
+                    assert (lib.chebgcn_debug_stamps4 if g.query(6) == 4 else lib.chebgcn_debug_stamps)(buf) == 0
+                    t = np.array(buf, dtype=np.int64).reshape(16, 64)
+                    t0 = t[:, 0][t[:, 0] > 0].min()
+                    print('   stamps (cycle counter ticks since the first wave entered the group), one row per wave:')
+                    ids = [i for i in range(64) if (t[:, i] > 0).any()]
+                    print('   id   ' + ' '.join('%7d' % i for i in ids))
+                    for w in range(16):
+                        if t[w, 0] > 0:
+                            print('   w%-3d ' % w + ' '.join('%7d' % (t[w, i] - t0) for i in ids))
                 print('%-16s B=%-4d abl=%-2d  %8.3f ms (min %7.3f)  %7.0f GB/s  %5.1f%% of 8 TB/s  %6.1f TFLOP/s'
                       % (name, B, abl, med, best, r['GBps'], 100 * r['frac_hbm'], r['TFLOPs']), flush=True)
     if args.json:
