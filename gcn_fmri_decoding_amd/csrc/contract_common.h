@@ -1,0 +1,105 @@
+// Shared by the contraction kernels (contract.hip: f32 MFMA, contract_bf16.hip: bf16 MFMA).
+#pragma once
+#include "common.h"
+
+namespace chebgcn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// streaming (non-temporal) 16-byte load: the stack / gradient planes are read once
+__device__ __forceinline__ float4 ld_stream(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// row of accumulator register j for a lane in half h (32x32 C/D layout, every input dtype)
+__device__ __forceinline__ int acc_row(int j, int h) { return (j & 3) + 8 * (j >> 2) + 4 * h; }
+
+struct FwdArgs {
+    const float* stack; const float* W; const float* bias; float* out; uint8_t* argmax;
+    int B, M, Mp, Fin, K, Fout, FinK;
+    int pool, pool_kind, relu, bias_kind;
+    int Mo, Mpo;
+    size_t slab;                 // B*Fin*Mp
+};
+
+// Epilogue of one filter row for the four vertices n0..n0+3 held by lane c of a half-wave:
+// bias (models_gcn.py:619-629), ReLU, graph pooling over p consecutive vertices (:631-648),
+// store; `argmax` receives the arg-max byte (max pooling) or the ReLU mask (average pooling).
+__device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo, float (&v)[4], int n0, bool valid,
+                                                 int c) {
+    const bool fo_ok = fo < a.Fout;
+    const int p = a.pool;
+    const int lanes_per_win = p > 4 ? (p >> 2) : 1;     // lanes sharing one pooling window
+    if (a.bias_kind == CHEBGCN_BIAS_FILTER) {
+        const float bb = fo_ok ? a.bias[fo] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bb;
+    } else if (a.bias_kind == CHEBGCN_BIAS_VERTEX) {
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fo_ok && valid) bb = *reinterpret_cast<const float4*>(a.bias + (size_t)fo * a.Mp + n0);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    float* orow = a.out + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo;
+    uint8_t* arow = a.argmax ? a.argmax + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo : nullptr;
+    if (p == 1) {
+        if (fo_ok && valid) *reinterpret_cast<float4*>(orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (a.pool_kind == CHEBGCN_POOL_MAX) {
+        if (p == 2) {
+            const int no = n0 >> 1;
+            if (fo_ok && no < a.Mpo) {
+                const bool s0 = v[1] > v[0], s1 = v[3] > v[2];
+                *reinterpret_cast<float2*>(orow + no) = make_float2(s0 ? v[1] : v[0], s1 ? v[3] : v[2]);
+                if (arow) *reinterpret_cast<uchar2*>(arow + no) = make_uchar2(s0 ? 1 : 0, s1 ? 1 : 0);
+            }
+        } else {
+            float m = v[0];
+            int idx = 0;
+#pragma unroll
+            for (int r = 1; r < 4; ++r)
+                if (v[r] > m) { m = v[r]; idx = r; }
+            idx += 4 * (c & (lanes_per_win - 1));
+            for (int d = 1; d < lanes_per_win; d <<= 1) {
+                const float om = __shfl_xor(m, d);
+                const int oi = __shfl_xor(idx, d);
+                if (om > m || (om == m && oi < idx)) { m = om; idx = oi; }
+            }
+            const int no = n0 / p;
+            if (fo_ok && (c & (lanes_per_win - 1)) == 0 && no < a.Mpo) {
+                orow[no] = m;
+                if (arow) arow[no] = (uint8_t)idx;
+            }
+        }
+    } else {
+        // average pooling; the argmax buffer receives the ReLU mask of the window
+        // (bit i set <=> element i of the window is > 0), which is all the
+        // gradient needs (pool <= 8)
+        const int mask = (v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0);
+        if (p == 2) {
+            const int no = n0 >> 1;
+            if (fo_ok && no < a.Mpo) {
+                *reinterpret_cast<float2*>(orow + no) = make_float2(0.5f * (v[0] + v[1]), 0.5f * (v[2] + v[3]));
+                if (arow) *reinterpret_cast<uchar2*>(arow + no) = make_uchar2(mask & 3, mask >> 2);
+            }
+        } else {
+            float s = (v[0] + v[1]) + (v[2] + v[3]);
+            int mk = mask << (4 * (c & (lanes_per_win - 1) & 1));
+            for (int d = 1; d < lanes_per_win; d <<= 1) {
+                s += __shfl_xor(s, d);
+                mk |= __shfl_xor(mk, d);
+            }
+            const int no = n0 / p;
+            if (fo_ok && (c & (lanes_per_win - 1)) == 0 && no < a.Mpo) {
+                orow[no] = s / (float)p;
+                if (arow) arow[no] = (uint8_t)mk;
+            }
+        }
+    }
+}
+
+}  // namespace chebgcn

@@ -474,6 +474,10 @@ class cgcnn(base_model):
         self.regularization, self.dropout = regularization, dropout
         self.batch_size, self.eval_frequency = batch_size, eval_frequency
         self.dir_name = dir_name
+        # arithmetic of the forward contraction: 'f32' (exact, default), 'bf16' or 'bf16x3' (bf16
+        # matrix cores for wide layers, ops.contract_fwd_into); not a reference keyword -- set it
+        # on the instance
+        self.contraction = 'f32'
         self.filter = getattr(self, filter)
         self.brelu = getattr(self, brelu)
         self.pool = getattr(self, pool)
@@ -519,7 +523,7 @@ class cgcnn(base_model):
         W = self._weight_variable([int(Fin) * K, int(Fout)], regularization=True)
         if x.is_meta:
             return torch.empty((N, M, int(Fout)), device='meta')
-        y = ops.cheb_conv(ops.plane_storage(x), W, None, self._graph_of(L), K)
+        y = ops.cheb_conv(ops.plane_storage(x), W, None, self._graph_of(L), K, precision=self.contraction)
         return ops.plane_view(y, M)
 
     def _brelu(self, x, per_vertex):
@@ -610,7 +614,8 @@ class cgcnn(base_model):
             direct = self.training_mode and W.grad is not None and b.grad is not None and torch.is_grad_enabled()
             x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
                               BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out,
-                              dW=W.grad if direct else None, dbias=b.grad if direct else None)
+                              dW=W.grad if direct else None, dbias=b.grad if direct else None,
+                              precision=self.contraction)
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
         return self._head(ops.FeatureMean.apply(x, M_last), dropout)

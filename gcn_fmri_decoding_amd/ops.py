@@ -225,6 +225,34 @@ def _check_grad_buffer(buf, shape, what):
         raise ValueError('%s buffer must be a contiguous float32 device tensor of shape %s' % (what, tuple(shape)))
 
 
+PRECISIONS = {'f32': 0, 'bf16': 1, 'bf16x3': 3}     # contraction arithmetic -> passes of chebgcn_contract_fwd_bf16
+
+
+def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision='f32'):
+    """Launches the forward contraction (models_gcn.py:611-648) into ``out``.
+
+    precision 'f32' = chebgcn_contract_fwd (exact fp32 MFMA); 'bf16' / 'bf16x3' =
+    chebgcn_contract_fwd_bf16 with 1 / 3 passes (wide layers, BASELINE config 5)."""
+    lib = _lib.lib()
+    if precision not in PRECISIONS:
+        raise ValueError('precision must be one of %s' % sorted(PRECISIONS))
+    Mo = M // pool
+    nbytes, flops = 4.0 * B * (M * Fin * K + Mo * Fout), 2.0 * B * M * Fin * K * Fout
+    if precision == 'f32':
+        _lib.check(_launch('contract_fwd', nbytes, flops,
+                           lambda: lib.chebgcn_contract_fwd(_p(stack), _p(W), _p(bias), bias_kind, _p(out), _p(argmax), B, M,
+                                                            Fin, K, Fout, pool, pool_kind, int(relu), _stream())),
+                   'contract_fwd')
+        return
+    nws = lib.chebgcn_contract_fwd_bf16_workspace(Fin, K, Fout)
+    ws = torch.empty(nws, dtype=torch.uint8, device=stack.device)
+    _lib.check(_launch('contract_fwd_' + precision, nbytes, flops,
+                       lambda: lib.chebgcn_contract_fwd_bf16(_p(stack), _p(W), _p(bias), bias_kind, _p(out), _p(argmax), B, M,
+                                                             Fin, K, Fout, pool, pool_kind, int(relu), PRECISIONS[precision],
+                                                             _p(ws), nws, _stream())),
+               'contract_fwd_bf16')
+
+
 class ChebConv(torch.autograd.Function):
     """y = pool(act(sum_k T_k(L~) x W_k + bias)) on plane storage tensors.
 
@@ -269,10 +297,8 @@ class ChebConv(torch.autograd.Function):
         b = bias.detach() if bias is not None else None
         if b is not None and not b.is_contiguous():
             b = b.contiguous()
-        _lib.check(_launch('contract_fwd', 4.0 * B * (M * Fin * K + Mo * Fout), 2.0 * B * M * Fin * K * Fout,
-                           lambda: lib.chebgcn_contract_fwd(_p(stack), _p(Wc), _p(b), bias_kind, _p(out), _p(argmax), B, M,
-                                                            Fin, K, Fout, pool, pool_kind, int(relu), _stream())),
-                   'contract_fwd')
+        precision = getattr(bufs, 'precision', 'f32') if bufs is not None else 'f32'
+        contract_fwd_into(stack, Wc, b, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision)
         ctx.save_for_backward(stack, Wc, out, argmax)
         ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
@@ -331,17 +357,19 @@ class Buffers:
     see ChebConv.  ``dW`` / ``dbias``: gradient buffers the backward pass ACCUMULATES into in place
     of returning the gradients to autograd -- the model hands over views of its flat, zeroed
     gradient buffer and saves an add (and a zero fill) per variable and step."""
-    __slots__ = ('stack', 'out', 'dW', 'dbias')
+    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision')
 
-    def __init__(self, stack=None, out=None, dW=None, dbias=None):
-        self.stack, self.out, self.dW, self.dbias = stack, out, dW, dbias
+    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32'):
+        self.stack, self.out, self.dW, self.dbias, self.precision = stack, out, dW, dbias, precision
 
 
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
-              dW=None, dbias=None):
+              dW=None, dbias=None, precision='f32'):
+    """``precision``: arithmetic of the forward contraction ('f32', 'bf16', 'bf16x3'); the
+    recurrence and every gradient stay fp32."""
     bufs = None
-    if stack is not None or out is not None or dW is not None or dbias is not None:
-        bufs = Buffers(stack, out, dW, dbias)
+    if stack is not None or out is not None or dW is not None or dbias is not None or precision != 'f32':
+        bufs = Buffers(stack, out, dW, dbias, precision)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 

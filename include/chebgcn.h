@@ -97,6 +97,19 @@ int chebgcn_contract_fwd(const float* stack, const float* W, const float* bias, 
                          float* out, uint8_t* argmax, int B, int M, int Fin, int K, int Fout,
                          int pool, int pool_kind, int relu, chebgcn_stream stream);
 
+/* ---- the same contraction on the bf16 matrix cores (wide layers: block_dura = 60, Fout = 256,
+ * where the fp32-input MFMA is compute bound).  Same operands, epilogue and results layout as
+ * chebgcn_contract_fwd; fp32 in HBM, converted in registers, fp32 accumulate.
+ * passes = 1: operands rounded to bf16;  passes = 3: operands split into two bf16 each and
+ * hi*hi + hi*lo + lo*hi accumulated (fp32-grade results, three times the matrix work).
+ * workspace: device scratch of at least chebgcn_contract_fwd_bf16_workspace(Fin, K, Fout) bytes
+ * (the packed bf16 image of W, rebuilt on every call). */
+size_t chebgcn_contract_fwd_bf16_workspace(int Fin, int K, int Fout);
+int chebgcn_contract_fwd_bf16(const float* stack, const float* W, const float* bias, int bias_kind,
+                              float* out, uint8_t* argmax, int B, int M, int Fin, int K, int Fout,
+                              int pool, int pool_kind, int relu, int passes, void* workspace,
+                              size_t workspace_bytes, chebgcn_stream stream);
+
 /* ---- bias + ReLU + pooling on their own (b1relu / b2relu / mpool1 / apool1 called
  * separately, models_gcn.py:619-648); same conventions as the epilogue of contract_fwd.
  * x: [B][F][Mp(M)] -> out: [B][F][Mp(M/pool)]. */

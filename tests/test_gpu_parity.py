@@ -241,6 +241,83 @@ def test_layer_gradients_vs_oracle(ops, dev, lvl, B, Fin, Fout, K, p, pool_kind,
 
 
 # ---------------------------------------------------------------------------------------
+# bf16 matrix-core contraction (BASELINE config 5).  Tolerances (relative to max|ref|): one pass
+# rounds both operands to bf16 (2^-9 each) -> 1e-2; three passes keep hi*hi + hi*lo + lo*hi of
+# the two-bf16 split of each operand (dropped lo*lo and the rounding of lo: ~2^-16 per product)
+# -> 5e-5, i.e. fp32-grade.
+# ---------------------------------------------------------------------------------------
+BF16_REL = {'bf16': 1e-2, 'bf16x3': 5e-5}
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('lvl,B,Fin,Fout,K,p,pool_kind,bias', [
+    (0, 2, 12, 256, 5, 1, 0, 2), (0, 2, 3, 40, 3, 2, 0, 1), (1, 2, 4, 33, 2, 4, 0, 2), (0, 1, 7, 300, 5, 1, 0, 0),
+    (0, 2, 6, 70, 4, 2, 1, 2), (0, 3, 3, 5, 3, 8, 0, 2), (0, 1, 16, 64, 1, 1, 0, 1)])
+def test_bf16_contraction_vs_oracle(ops, dev, precision, lvl, B, Fin, Fout, K, p, pool_kind, bias):
+    L = levels()[lvl]
+    M = L.shape[0]
+    g = ops.Graph(L, dev)
+    rs = np.random.RandomState(5 * lvl + Fout)
+    x = rs.randn(B, M, Fin).astype(np.float32)
+    W = (rs.randn(Fin * K, Fout) * 0.3).astype(np.float32)
+    if bias == 1:
+        b = (rs.randn(1, 1, Fout) * 0.5).astype(np.float32)
+    elif bias == 2:
+        b = (rs.randn(1, M, Fout) * 0.5).astype(np.float32)
+    else:
+        b = np.zeros((1, 1, Fout), np.float32)
+    relu = bias != 0
+    y = R.chebyshev5_fwd(x, L, W, K)
+    a = R.brelu_fwd(y, b) if relu else y + b
+    # pooling picks may flip under rounding; values still agree to the bound
+    o = R.mpool1_fwd(a, p)[0] if pool_kind == 0 else R.apool1_fwd(a, p)
+    xs = to_storage(ops, x, dev)
+    Wd = torch.as_tensor(W).to(dev)
+    if bias == 1:
+        bd, kind = torch.as_tensor(b.reshape(-1)).to(dev), ops.BIAS_FILTER
+    elif bias == 2:
+        bd = torch.zeros((Fout, g.Mp), device=dev)
+        bd[:, :M] = torch.as_tensor(b[0].T.copy()).to(dev)
+        kind = ops.BIAS_VERTEX
+    else:
+        bd, kind = None, ops.BIAS_NONE
+    out = ops.cheb_conv(xs, Wd, bd, g, K, pool=p, pool_kind=pool_kind, relu=relu, bias_kind=kind, precision=precision)
+    # scale of the pre-activation sums: the rounding error does not shrink with the ReLU / bias
+    scale = np.abs(y).max()
+    err = np.abs(from_storage(out, M // p).astype(np.float64) - o).max() / scale
+    assert err <= BF16_REL[precision], '%s: rel err %.3e' % (precision, err)
+    if precision == 'bf16':
+        assert err > 1e-6, 'bf16 path suspiciously exact: is it running the fp32 kernel?'
+    # gradients of a mixed-precision layer are the fp32 ones (recurrence and all backward kernels stay fp32)
+    xs2 = to_storage(ops, x, dev).requires_grad_(True)
+    Wd2 = Wd.clone().requires_grad_(True)
+    out2 = ops.cheb_conv(xs2, Wd2, bd, g, K, pool=p, pool_kind=pool_kind, relu=relu, bias_kind=kind, precision=precision)
+    gout = torch.zeros_like(out2)
+    gout[:, :, :M // p] = 1.0
+    out2.backward(gout)
+    assert torch.isfinite(xs2.grad[:, :, :M]).all() and torch.isfinite(Wd2.grad).all()
+
+
+def test_bf16_contraction_config5_shape(ops, dev):
+    """BASELINE config 5 (block_dura 60 -> Fin = 60, Fout = 256, K = 5) on the benchmark graph,
+    two windows: bf16 / bf16x3 against the exact fp32 MFMA kernel on the same stack."""
+    import bench
+    Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
+    g = ops.Graph(Ls[0], dev)
+    B, Fin, Fout, K, M = 2, 60, 256, 5, g.M
+    torch.manual_seed(3)
+    x = torch.randn(B, Fin, g.Mp, device=dev)
+    W = torch.randn(Fin * K, Fout, device=dev) * 0.1
+    bias = torch.randn(Fout, g.Mp, device=dev) * 0.5
+    ref = ops.cheb_conv(x, W, bias, g, K, relu=True, bias_kind=ops.BIAS_VERTEX)[:, :, :M].double()
+    pre = ops.cheb_conv(x, W, None, g, K)[:, :, :M].double()
+    for precision, rel in BF16_REL.items():
+        got = ops.cheb_conv(x, W, bias, g, K, relu=True, bias_kind=ops.BIAS_VERTEX, precision=precision)[:, :, :M].double()
+        err = float((got - ref).abs().max() / pre.abs().max())
+        assert err <= rel, '%s: rel err %.3e' % (precision, err)
+
+
+# ---------------------------------------------------------------------------------------
 # staging, head, optimizer
 # ---------------------------------------------------------------------------------------
 

@@ -79,6 +79,7 @@ def main():
         dbias = torch.empty(Fout, Mp, device=dev)
         dW = torch.empty(Fin * K, Fout, device=dev)
         ws = torch.empty(lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout), dtype=torch.uint8, device=dev)
+        ws16 = torch.empty(lib.chebgcn_contract_fwd_bf16_workspace(Fin, K, Fout), dtype=torch.uint8, device=dev)
         st = ops._stream()
         P = ops._p
         calls = {
@@ -89,6 +90,12 @@ def main():
             'contract_fwd': (lambda: lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), 2, P(out), None, B, M, Fin, K, Fout,
                                                               1, 0, 1, st),
                              4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_fwd_bf16': (lambda: lib.chebgcn_contract_fwd_bf16(P(stack), P(W), P(bias), 2, P(out), None, B, M, Fin, K,
+                                                                        Fout, 1, 0, 1, 1, P(ws16), ws16.numel(), st),
+                                  4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_fwd_bf16x3': (lambda: lib.chebgcn_contract_fwd_bf16(P(stack), P(W), P(bias), 2, P(out), None, B, M, Fin,
+                                                                          K, Fout, 1, 0, 1, 3, P(ws16), ws16.numel(), st),
+                                    4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
             'contract_bwd_w': (lambda: lib.chebgcn_contract_bwd_w(P(stack), P(dy), P(dW), P(ws), ws.numel(), B, M, Fin, K,
                                                                   Fout, st),
                                4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
