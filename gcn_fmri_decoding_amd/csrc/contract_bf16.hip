@@ -48,65 +48,110 @@ pack_w_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ Wp, int Fin
     }
 }
 
-// k-steps the operands are requested ahead.  The reduction is padded to a multiple of DEPTH
-// k-steps (zero weights against the last plane again: an L1/L2 hit), so that the register
-// slot of a k-step is static and every iteration issues the same number of loads -- the
-// compiler then waits with exact counts (s_waitcnt vmcnt(N)) instead of draining the queue.
-constexpr int BF16_DEPTH = 5;
+// Operand pipeline.  Both operands of a k-step travel by LDS-DMA (global_load_lds, 16 B per lane,
+// no register round trip) into a ring of stages in LDS:
+//   stage = [16 rows][128 vertices] fp32 of the stack (8 KB) + PARTS x [256 filters][16] bf16 of W (8 KB each).
+// The four waves split every stage between them (2 + 2*PARTS wave instructions each), so what is
+// in flight per CU is DEPTH *distinct* stages -- with register prefetch the four waves of a
+// workgroup would all request the same rows and only one wave's worth of bytes would be in the
+// air.  Every vector-memory operation of the main loop is such a DMA issued DEPTH steps ahead:
+// the queue returns in order, so a short L2 load between them would wait for the HBM ones.
+// Hand-placed waits: the wave's own DMAs of the step about to be consumed are DEPTH*NDMA
+// operations old (s_waitcnt vmcnt(DEPTH*NDMA)), a barrier WITHOUT a fence (the fence would
+// drain the queue) publishes them, and the operands are read with ds_read_b128 in one asm
+// block (compiler-visible LDS reads would be ordered behind every DMA in flight).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int PASSES>
+struct Bf16Cfg {
+    static constexpr int PARTS = PASSES == 3 ? 2 : 1;
+    static constexpr int STAGE = 8192 + PARTS * 8192;             // bytes
+    static constexpr int NSTAGE = PASSES == 3 ? 6 : 9;            // 144 KB either way
+    static constexpr int DEPTH = NSTAGE - 2;
+    static constexpr int NDMA = 2 + 2 * PARTS;                    // wave instructions per wave and stage
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int PASSES>
 __global__ void __launch_bounds__(256)
-contract_fwd_bf16_kernel(FwdArgs a, const bf16x8* __restrict__ Wp, int nks, int FoutP, int ntm, int nitems) {
-    constexpr int DEPTH = BF16_DEPTH;
-    extern __shared__ size_t rowoff[];                  // [nks*16] plane offset of reduction row r
+contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int FoutP, int ntm, int nitems) {
+    using C = Bf16Cfg<PASSES>;
+    extern __shared__ __attribute__((aligned(16))) char ring[];         // [NSTAGE][STAGE]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, g = lane >> 5;
-    for (int r = threadIdx.x; r < nks * 16; r += 256) {
-        // rows beyond Fin*K re-read the last plane (finite data) against zero weights
-        const int rr = r < a.FinK ? r : a.FinK - 1;
-        const int fin = rr / a.K, k = rr - fin * a.K;
-        rowoff[r] = (size_t)k * a.slab + (size_t)fin * a.Mp;
-    }
-    __syncthreads();
-    const size_t lo_part = (size_t)nks * FoutP * 2;     // in bf16x8 units
+    const size_t lo_part = (size_t)nks * FoutP * 16;                     // bf16 elements between the hi and lo image
 
-    // work item = (filter group of 256, window, 128 vertices); a workgroup walks its items with
-    // the operand pipeline running across item boundaries
-    struct Item { int fo0, b, n0; bool valid; const float* base; };
-    auto item_of = [&](int it) {
-        Item r;
-        const int mt = it % ntm, rest = it / ntm;
-        r.b = rest % a.B;
-        r.fo0 = ((rest / a.B) * 4 + wave) * 64;
-        r.n0 = mt * 128 + 4 * c;
-        r.valid = r.n0 < a.Mp;
-        r.base = a.stack + (size_t)r.b * a.Fin * a.Mp + (r.valid ? r.n0 : 0);     // always a readable address
-        return r;
+    // work item = (filter group of 256, window, 128 vertices), walked with the pipeline running
+    auto item_mt = [&](int it) { return it % ntm; };
+    auto item_b = [&](int it) { return (it / ntm) % a.B; };
+    auto item_z = [&](int it) { return it / ntm / a.B; };
+
+    // ---- producer state: the step DEPTH ahead of the consumer -----------------------------------
+    // Kept incremental -- with one wave per SIMD every instruction of the loop is on the critical
+    // path: the item is decomposed once per item, the plane of reduction row r = 16*ks + row
+    // (row = 4*wave + 2q + (lane >> 5) for DMA instruction q) advances by 16 rows per step.
+    int p_it = blockIdx.x, p_ks = 0;
+    const int s16f = 16 / a.K, s16k = 16 % a.K;
+    int pf[2], pk[2];
+    const float* p_base;                                           // window + vertex part of the source address
+    const __bf16* p_w;                                             // this lane's 16 bytes of the packed W, k-step 0
+    auto producer_item = [&]() {
+        int m = item_mt(p_it) * 128 + 4 * c;
+        if (m >= a.Mp) m = 0;                                      // beyond the plane: any readable address, never stored
+        p_base = a.stack + (size_t)item_b(p_it) * a.Fin * a.Mp + m;
+        p_w = Wp + (size_t)item_z(p_it) * 256 * 16 + (size_t)wave * 1024 + lane * 8;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = 4 * wave + 2 * q + g;
+            pf[q] = row / a.K;
+            pk[q] = row - pf[q] * a.K;
+        }
     };
-
-    float4 x[DEPTH][8];
-    bf16x8 ah[DEPTH][2], al[DEPTH][2];
-    auto request = [&](const float* base, int fo0, int ks, int slot) {
+    producer_item();
+    const size_t w_step = (size_t)FoutP * 16;                      // bf16 elements per k-step of the packed W
+    auto produce = [&](int slot) {
+        const unsigned stage = (unsigned)(size_t)ring + slot * C::STAGE;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[slot][i] = *reinterpret_cast<const float4*>(base + rowoff[ks * 16 + 8 * g + i]);   // shared by the four waves: keep it cacheable
-        const int fo = fo0 < a.Fout ? fo0 : 0;          // idle waves (Fout < 256) read tile 0 and store nothing
+        for (int q = 0; q < 2; ++q) {
+            // rows beyond Fin*K re-read the last plane (finite data) against zero weights
+            const bool live = pf[q] < a.Fin;
+            const int fin = live ? pf[q] : a.Fin - 1, k = live ? pk[q] : a.K - 1;
+            const float* src = p_base + (size_t)k * a.slab + (size_t)fin * a.Mp;
+            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                                      stage + (4 * wave + 2 * q) * 512), 16, 0, 0);
+            pk[q] += s16k;
+            pf[q] += s16f;
+            if (pk[q] >= a.K) { pk[q] -= a.K; ++pf[q]; }
+        }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const size_t at = ((size_t)ks * FoutP + fo + 32 * t + c) * 2 + g;
-            ah[slot][t] = Wp[at];
-            if (PASSES == 3) al[slot][t] = Wp[lo_part + at];
+        for (int part = 0; part < C::PARTS; ++part)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                __builtin_amdgcn_global_load_lds(p_w + part * lo_part + q * 512,
+                                                 reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                                     stage + 8192 + part * 8192 + wave * 2048 + q * 1024),
+                                                 16, 0, 0);
+        p_w += w_step;
+        if (++p_ks == nks) {
+            p_ks = 0;
+            if (p_it + (int)gridDim.x < nitems) p_it += gridDim.x;   // after the last item: harmless re-reads
+            producer_item();
         }
     };
 
-    int it = blockIdx.x;
-    if (it >= nitems) return;
-    Item cur = item_of(it);
-#pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) request(cur.base, cur.fo0, d, d);            // nks >= DEPTH by construction
-    for (; it < nitems; it += gridDim.x) {
-        const int itn = it + (int)gridDim.x < nitems ? it + (int)gridDim.x : it;   // last item: harmless re-reads
-        const Item nxt = item_of(itn);
+    if ((int)blockIdx.x >= nitems) return;
+    int pslot = 0;
+#pragma unroll 1
+    for (int d = 0; d < C::DEPTH; ++d) { produce(pslot); pslot = pslot + 1 == C::NSTAGE ? 0 : pslot + 1; }
+    int cslot = 0;
+
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int fo0 = (item_z(it) * 4 + wave) * 64;
+        const int b = item_b(it);
+        const int n0 = item_mt(it) * 128 + 4 * c;
+        const bool valid = n0 < a.Mp;
         f32x16 acc[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -115,54 +160,93 @@ contract_fwd_bf16_kernel(FwdArgs a, const bf16x8* __restrict__ Wp, int nks, int 
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[t][r][j] = 0.f;
 
-        for (int ks0 = 0; ks0 < nks; ks0 += DEPTH) {
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            produce(pslot);
+            pslot = pslot + 1 == C::NSTAGE ? 0 : pslot + 1;
+            wait_vmcnt<C::DEPTH * C::NDMA>();                  // this wave's part of stage `cslot` has landed
+            __builtin_amdgcn_s_barrier();                      // ... and everybody else's
+            const unsigned xb = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + g * 4096 + c * 16;
+            const unsigned ab = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + 8192 + (64 * wave + c) * 32 + 16 * g;
+            f32x4 x[8];
+            i32x4 ar[2 * C::PARTS];
+            if (PASSES == 3) {
+                asm volatile(
+                    "ds_read_b128 %0, %12\n ds_read_b128 %1, %12 offset:512\n ds_read_b128 %2, %12 offset:1024\n"
+                    "ds_read_b128 %3, %12 offset:1536\n ds_read_b128 %4, %12 offset:2048\n ds_read_b128 %5, %12 offset:2560\n"
+                    "ds_read_b128 %6, %12 offset:3072\n ds_read_b128 %7, %12 offset:3584\n"
+                    "ds_read_b128 %8, %13\n ds_read_b128 %9, %13 offset:1024\n"
+                    "ds_read_b128 %10, %13 offset:8192\n ds_read_b128 %11, %13 offset:9216\n s_waitcnt lgkmcnt(0)"
+                    : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
+                      "=&v"(ar[0]), "=&v"(ar[1]), "=&v"(ar[2 % (2 * C::PARTS)]), "=&v"(ar[3 % (2 * C::PARTS)])
+                    : "v"(xb), "v"(ab)
+                    : "memory");
+            } else {
+                asm volatile(
+                    "ds_read_b128 %0, %10\n ds_read_b128 %1, %10 offset:512\n ds_read_b128 %2, %10 offset:1024\n"
+                    "ds_read_b128 %3, %10 offset:1536\n ds_read_b128 %4, %10 offset:2048\n ds_read_b128 %5, %10 offset:2560\n"
+                    "ds_read_b128 %6, %10 offset:3072\n ds_read_b128 %7, %10 offset:3584\n"
+                    "ds_read_b128 %8, %11\n ds_read_b128 %9, %11 offset:1024\n s_waitcnt lgkmcnt(0)"
+                    : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
+                      "=&v"(ar[0]), "=&v"(ar[1])
+                    : "v"(xb), "v"(ab)
+                    : "memory");
+            }
+            cslot = cslot + 1 == C::NSTAGE ? 0 : cslot + 1;
+            bf16x8 ah[2], al[2];
 #pragma unroll
-            for (int u = 0; u < DEPTH; ++u) {
-                const int ahead = ks0 + u + DEPTH - 1;
-                // straight-line (selects, no branch): every iteration issues the same loads
-                const bool wrap = ahead >= nks;
-                request(wrap ? nxt.base : cur.base, wrap ? nxt.fo0 : cur.fo0, wrap ? ahead - nks : ahead, (u + DEPTH - 1) % DEPTH);
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = __builtin_bit_cast(bf16x8, ar[t]);
+                if (PASSES == 3) al[t] = __builtin_bit_cast(bf16x8, ar[(2 + t) % (2 * C::PARTS)]);
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    bf16x8 bh, bl;
+            for (int r = 0; r < 4; ++r) {
+                bf16x8 bh, bl;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float4 xv = x[u][i];
-                        const float v = r == 0 ? xv.x : r == 1 ? xv.y : r == 2 ? xv.z : xv.w;
-                        bh[i] = (__bf16)v;
-                        if (PASSES == 3) bl[i] = (__bf16)(v - (float)bh[i]);
+                for (int i = 0; i < 8; ++i) {
+                    const float v = x[i][r];
+                    bh[i] = (__bf16)v;
+                    if (PASSES == 3) bl[i] = (__bf16)(v - (float)bh[i]);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (PASSES == 3) {
+                        acc[t][r] = mfma_bf16(al[t], bh, acc[t][r]);        // small terms first
+                        acc[t][r] = mfma_bf16(ah[t], bl, acc[t][r]);
                     }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        if (PASSES == 3) {
-                            acc[t][r] = mfma_bf16(al[u][t], bh, acc[t][r]);        // small terms first
-                            acc[t][r] = mfma_bf16(ah[u][t], bl, acc[t][r]);
-                        }
-                        acc[t][r] = mfma_bf16(ah[u][t], bh, acc[t][r]);
-                    }
+                    acc[t][r] = mfma_bf16(ah[t], bh, acc[t][r]);
                 }
             }
         }
 
-        if (cur.fo0 < a.Fout) {
+        if (fo0 < a.Fout) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
+                // the 16 per-vertex bias rows of the tile are requested together (one round trip)
+                float4 bb[16];
+                const bool vb = a.bias_kind == CHEBGCN_BIAS_VERTEX;
+                if (vb) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int fo = fo0 + 32 * t + acc_row(j, g);
+                        const int foc = fo < a.Fout ? fo : a.Fout - 1;
+                        bb[j] = *reinterpret_cast<const float4*>(a.bias + (size_t)foc * a.Mp + (valid ? n0 : 0));
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    const int fo = cur.fo0 + 32 * t + acc_row(j, g);
+                    const int fo = fo0 + 32 * t + acc_row(j, g);
                     float v[4] = {acc[t][0][j], acc[t][1][j], acc[t][2][j], acc[t][3][j]};
-                    fwd_epilogue_row(a, cur.b, fo, v, cur.n0, cur.valid, c);
+                    fwd_epilogue_row(a, b, fo, v, n0, valid, c, vb, vb ? bb[j] : make_float4(0.f, 0.f, 0.f, 0.f));
                 }
+            }
         }
-        cur = nxt;
     }
+    wait_vmcnt<0>();                                           // the run-ahead DMAs of the last item
 }
 
-// k-steps of 16 reduction rows, padded to a multiple of the prefetch depth
-static int bf16_ksteps(int FinK) {
-    const int nks = (FinK + 15) / 16;
-    return (nks + BF16_DEPTH - 1) / BF16_DEPTH * BF16_DEPTH;
-}
+// k-steps of 16 reduction rows
+static int bf16_ksteps(int FinK) { return (FinK + 15) / 16; }
 
 static bool check_pool_bf16(int pool, int M) {
     return pool >= 1 && pool <= 128 && (pool & (pool - 1)) == 0 && M % pool == 0;
@@ -212,14 +296,17 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const dim3 grid(nitems < cus ? nitems : cus);       // one workgroup per CU (128 accumulator registers per lane)
-    const size_t lds = (size_t)nks * 16 * sizeof(size_t);
-    CG_REQUIRE(lds <= 64 * 1024, "contract_fwd_bf16: Fin*K = %d too large", a.FinK);
-    if (passes == 3)
-        hipLaunchKernelGGL(contract_fwd_bf16_kernel<3>, grid, dim3(256), lds, stream, a, (const bf16x8*)workspace, nks, FoutP,
-                           ntm, nitems);
-    else
-        hipLaunchKernelGGL(contract_fwd_bf16_kernel<1>, grid, dim3(256), lds, stream, a, (const bf16x8*)workspace, nks, FoutP,
-                           ntm, nitems);
+    if (passes == 3) {
+        auto kern = contract_fwd_bf16_kernel<3>;
+        constexpr int lds = Bf16Cfg<3>::NSTAGE * Bf16Cfg<3>::STAGE;
+        CG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, (const __bf16*)workspace, nks, FoutP, ntm, nitems);
+    } else {
+        auto kern = contract_fwd_bf16_kernel<1>;
+        constexpr int lds = Bf16Cfg<1>::NSTAGE * Bf16Cfg<1>::STAGE;
+        CG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, (const __bf16*)workspace, nks, FoutP, ntm, nitems);
+    }
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

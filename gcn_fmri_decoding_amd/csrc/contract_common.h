@@ -27,8 +27,10 @@ struct FwdArgs {
 // Epilogue of one filter row for the four vertices n0..n0+3 held by lane c of a half-wave:
 // bias (models_gcn.py:619-629), ReLU, graph pooling over p consecutive vertices (:631-648),
 // store; `argmax` receives the arg-max byte (max pooling) or the ReLU mask (average pooling).
+// `bbv`: the per-vertex bias of this row when the caller fetched it ahead (have_bb), so that the
+// rows of a tile do not pay one memory round trip each.
 __device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo, float (&v)[4], int n0, bool valid,
-                                                 int c) {
+                                                 int c, bool have_bb = false, float4 bbv = make_float4(0.f, 0.f, 0.f, 0.f)) {
     const bool fo_ok = fo < a.Fout;
     const int p = a.pool;
     const int lanes_per_win = p > 4 ? (p >> 2) : 1;     // lanes sharing one pooling window
@@ -37,8 +39,11 @@ __device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bb;
     } else if (a.bias_kind == CHEBGCN_BIAS_VERTEX) {
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fo_ok && valid) bb = *reinterpret_cast<const float4*>(a.bias + (size_t)fo * a.Mp + n0);
+        float4 bb = bbv;
+        if (!have_bb) {
+            bb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fo_ok && valid) bb = *reinterpret_cast<const float4*>(a.bias + (size_t)fo * a.Mp + n0);
+        }
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
     }
     if (a.relu) {
