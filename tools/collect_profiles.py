@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Copies what tools/refresh_profiles.sh left under gpurun_out/refresh into profiles/ (tracked),
+named per round, and derives profiles/traffic.json (HBM bytes per launch and kernel, read by bench.py).
+
+    python tools/collect_profiles.py [round-tag, default r01]
+"""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'gpurun_out', 'refresh')
+DST = os.path.join(ROOT, 'profiles')
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+
+for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats.csv', '%s_bench_kernel_stats.csv'),
+                 ('kbench.txt', '%s_kbench.txt'), ('kbench.json', '%s_kbench.json'),
+                 ('kbench_config4.txt', '%s_kbench_config4_K25_F64.txt'), ('kbench_config5.txt', '%s_kbench_config5_bf16.txt'),
+                 ('traffic_raw.json', '%s_traffic_raw.json')]:
+    p = os.path.join(SRC, src)
+    if os.path.exists(p):
+        if src.endswith('.txt') or src == 'bench_line.json':
+            lines = [l for l in open(p) if 'amdgpu.ids' not in l and l.strip() not in ('1', '6 6 6')]
+            open(os.path.join(DST, dst % tag), 'w').writelines(lines)
+        else:
+            shutil.copy(p, os.path.join(DST, dst % tag))
+
+raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
+names = {'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd',
+         'contract_fwd_kernel<1>': 'contract_fwd', 'contract_bwd_w_kernel<5>': 'contract_bwd_w',
+         'contract_bwd_x_kernel<true>': 'contract_bwd_x', 'brelu_pool_bwd_kernel<2>': 'brelu_pool_bwd'}
+out = {'_note': 'HBM bytes per launch at the bench shape (B=64, Fin=Fout=32, K=5, M=10466), rocprofv3 --pmc FETCH_SIZE and '
+                'WRITE_SIZE in separate passes with --kernel-trace only (tools/pmc_traffic.sh); bytes = (2*FETCH_SIZE + '
+                'WRITE_SIZE) KiB -- FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; '
+                'raw counters in %s_traffic_raw.json' % tag}
+for k, v in raw.items():
+    for pat, name in names.items():
+        if pat in k:
+            out[name] = (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0
+json.dump(out, open(os.path.join(DST, 'traffic.json'), 'w'), indent=1)
+print(json.dumps(out, indent=1))
