@@ -192,7 +192,10 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     // lock-step, all CUs would stream from L2, gather from LDS and write to HBM at the same
     // times; spread over roughly one step they overlap each other's phases instead.
     if (!(abl & 32)) {
-        const int reps = 2 * ((blockIdx.x >> 3) & 31);
+        // ... scaled down when a workgroup has only a few groups to work through (measured: no
+        // stagger is best at 4 groups per workgroup, the full one at 16)
+        const int gpw = (ngrp + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int reps = ((blockIdx.x >> 3) & 31) * (gpw < 16 ? gpw : 16) / 8 * (gpw > 4);
         for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
     }
 

@@ -1,2 +1,2 @@
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
-python tools/kbench.py --B 64 256 --kernels contract_fwd --iters 20 2>&1 | grep contract
+python tools/kbench.py --B 64 128 256 --kernels recurrence_fwd recurrence_bwd --iters 20 2>&1 | grep recurrence
+python bench.py --cpu-windows 0 | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(l['value'], l['ms_per_step'], {k:round(v['avg_ms'],4) for k,v in l['kernels'].items()})"
