@@ -31,8 +31,8 @@ constexpr int kQuadMin = 3;      // quads stored (zero-padded) for every group, 
 //    quad holds 4 consecutive entries of each of the 64 rows: colq[quad*64 + lane] = 4 packed
 //    16-bit LDS slot ids, valq[quad*64 + lane] = 4 values; ginfo[g].y = the group's length
 //    rounded up to even.  Padding entries have val = 0 and point at zero_slot, an LDS entry
-//    that always holds 0.  kQuadPad spare quads follow the last group so that the kernel may
-//    always request a fixed number of quads per group.
+//    that always holds 0.  Every group stores an even number of quads (>= kQuadMin); kQuadPad
+//    spare quads follow the last group so that a kernel may request a fixed number per group.
 struct Ell {
     int planes = 2;
     int ngroups = 0;
@@ -45,6 +45,7 @@ struct Ell {
     int64_t cost_before = 0, cost_after = 0, cost_ideal = 0;   // bank-conflict statistics of build_ell (graph_query 9, 10)
     int2* ginfo = nullptr;        // [ngroups] {quad offset, even length}
     uint2* colq = nullptr;        // [(nquads + kQuadPad)*64]
+    uint4* colo = nullptr;        // [(nquads + kQuadPad)/2*64]  the same ids, quads 2o and 2o+1 in one record
     float4* valq = nullptr;       // [(nquads + kQuadPad)*64]
     uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> LDS slot of that row, 0xFFFF for padding ranks
     uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> LDS slot, 0xFFFF = none (isolated / pad)
@@ -58,6 +59,7 @@ struct Ell {
 struct EllView {
     const int2* ginfo;
     const uint2* colq;
+    const uint4* colo;
     const float4* valq;
     const uint16_t* rowslot;
     const uint16_t* nodeslot;
@@ -65,7 +67,7 @@ struct EllView {
 };
 
 static inline EllView view(const Ell& e) {
-    return EllView{e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
+    return EllView{e.ginfo, e.colq, e.colo, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
 }
 
 }  // namespace chebgcn

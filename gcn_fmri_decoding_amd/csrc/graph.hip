@@ -33,7 +33,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 static void free_ell(Ell& e) {
-    void* ptrs[] = {e.ginfo, e.colq, e.valq, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
+    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
     for (void* p : ptrs) (void)hipFree(p);
     e = Ell();
 }
@@ -124,7 +124,9 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
         const int len = rlen(order[g * 64]);              // longest row of the group
         max_len = std::max(max_len, len);
         ginfo[g] = make_int2((int)nquads, (len + 1) & ~1);   // even: the kernel gathers in pairs
-        nquads += std::max((len + 3) / 4, kQuadMin);      // the kernel gathers kQuadMin quads unconditionally
+        // at least kQuadMin quads (recurrence4.hip requests that many unconditionally), an even
+        // number of them: two quads share one 16-byte record of slot ids (colo below)
+        nquads += (std::max((len + 3) / 4, kQuadMin) + 1) & ~1;
         nslots += (len + 1) & ~1;
     }
     const uint32_t zz = (uint32_t)zero_slot | ((uint32_t)zero_slot << 16);
@@ -220,6 +222,15 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     out->nslots = nslots;
     out->nquads = nquads;
     if ((rc = upload(&out->ginfo, ginfo))) return rc;
+    // the slot ids once more, eight per lane and record: one 16-byte load serves two quads (the
+    // vector-memory path costs per wave instruction, not per byte)
+    std::vector<uint4> colo(colq.size() / 2);
+    for (size_t o = 0; o < colo.size() / 64; ++o)
+        for (int lane = 0; lane < 64; ++lane) {
+            const uint2 a = colq[(2 * o) * 64 + lane], b = colq[(2 * o + 1) * 64 + lane];
+            colo[o * 64 + lane] = make_uint4(a.x, a.y, b.x, b.y);
+        }
+    if ((rc = upload(&out->colo, colo))) return rc;
     if ((rc = upload(&out->colq, colq))) return rc;
     if ((rc = upload(&out->valq, valq))) return rc;
     if ((rc = upload(&out->rowslot, rowslot))) return rc;

@@ -82,7 +82,7 @@ __device__ long long g_dbg[16 * 64];
             g_dbg[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();                \
     } while (0)
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int P> struct Ent { float x[P]; };       // one LDS entry: P planes of one vertex
@@ -180,7 +180,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     // with vmcnt(0), draining the operator requests that are in flight.
     int2 gtab = make_int2(0, 0);
     if (lane < NJ && lane * nwaves + wave < e.ngroups) gtab = e.ginfo[lane * nwaves + wave];
-    const __amdgpu_buffer_rsrc_t colq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colq, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t colo_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colo, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valq, 0, 0x7FFFFFFF, 0x00020000);
     if (tid < P) T[e.zero_slot * P + tid] = 0.f;      // never written again
     // Vertices / ranks without an LDS slot (id 0xFFFF) read the zero slot and write a trash slot:
@@ -389,7 +389,9 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             // group of lead does not cover the L2 latency.  Requests are unconditional, so the
             // compiler can count the loads in flight (s_waitcnt vmcnt(N), N > 0).
             constexpr int RING = 2 * QMAX;
-            uint2 rc[RING];
+            constexpr int QO = (QMAX + 1) / 2;       // id records (two quads each) per group in the ring
+            constexpr int ORING = 2 * QO;
+            uint4 ro[ORING];
             float4 rv[RING];
             auto group_info = [&](int j, int& qoff, int& len) {
                 // {quad offset, length} of group j*nwaves + wave, from lane j of the wave's table
@@ -398,17 +400,28 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 if (abl & 2) { qoff = 0; len = 0; }
                 if (CG_X & 1) qoff = 0;              // experiment: operator always from the same (L1-resident) quads
             };
-            auto request = [&](int j, int q) {       // quad q of group j -> its ring slot
+            // buffer loads: descriptor + uniform offset in SGPRs, lane offset in one VGPR -- no 64-bit
+            // address arithmetic on the vector ALU.  Ids come eight at a time (one record per two
+            // quads): the vector-memory path costs ~16 cycles per wave instruction whatever its width.
+            auto request_ids = [&](int j, int o) {   // id record o of group j -> its ring slot
                 int qoff, len;
                 group_info(j, qoff, len);
                 if ((CG_X & 4) && j > 1) return;               // experiment: no operator loads after the prologue
+                if (o >= 1 && len <= 8) return;                // the second record only where a row needs it
+                const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(colo_rsrc, lane * 16, ((qoff >> 1) + o) * 1024, 0);
+                ro[(QO * j + o) % ORING] = make_uint4(c.x, c.y, c.z, c.w);
+            };
+            auto request = [&](int j, int q) {       // values of quad q of group j -> their ring slot
+                int qoff, len;
+                group_info(j, qoff, len);
+                if ((CG_X & 4) && j > 1) return;
                 if (q >= 2 && len <= 8) return;                // the third quad only where a row needs it
-                // buffer loads: descriptor + uniform offset in SGPRs, lane offset in one VGPR -- no
-                // 64-bit address arithmetic on the vector ALU
-                const u32x2 c = __builtin_amdgcn_raw_buffer_load_b64(colq_rsrc, lane * 8, (qoff + q) * 512, 0);
                 const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(valq_rsrc, lane * 16, (qoff + q) * 1024, 0);
-                rc[(QMAX * j + q) % RING] = make_uint2(c.x, c.y);
                 rv[(QMAX * j + q) % RING] = make_float4(v.x, v.y, v.z, v.w);
+            };
+            auto ids_of = [&](int j, int q) {        // the four ids of quad q of group j
+                const uint4 o = ro[(QO * j + (q >> 1)) % ORING];
+                return (q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y);
             };
             auto quad = [&](const uint2 c, const float4 v, float (&acc)[P]) {
                 Ent<P> t[4];
@@ -423,8 +436,13 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                     for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(v, i), t[i].x[p], acc[p]);
             };
 #pragma unroll
-            for (int n = 0; n < RING; ++n)
-                if (n / QMAX < NJ) request(n / QMAX, n % QMAX);
+            for (int jj = 0; jj < 2; ++jj) {
+                if (jj >= NJ) break;
+#pragma unroll
+                for (int o = 0; o < QO; ++o) request_ids(jj, o);
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) request(jj, q);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (!ADJ && do_out && (j % QS) == 0 && (j / QS) < NQ)       // one linear piece every QS groups
@@ -447,14 +465,17 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
                     // the first two quads always (zero-padded), the third for rows beyond 8 entries
-                    if (gather && (q < 2 || len > 8)) quad(rc[(QMAX * j + q) % RING], rv[(QMAX * j + q) % RING], acc);
-                    if (j + 2 < NJ) request(j + 2, q);           // refill the slot just consumed
+                    if (gather && (q < 2 || len > 8)) quad(ids_of(j, q), rv[(QMAX * j + q) % RING], acc);
+                    if (j + 2 < NJ) {
+                        request(j + 2, q);                       // refill the slots just consumed
+                        if ((q & 1) || q == QMAX - 1) request_ids(j + 2, q >> 1);
+                    }
                 }
                 if (gather && len > 4 * QMAX) {
                     for (int q = QMAX; 4 * q < len; ++q) {       // rows longer than 4*QMAX entries (rare)
-                        const uint2 c = e.colq[(size_t)(qoff + q) * 64 + lane];
+                        const uint4 o = e.colo[(size_t)((qoff >> 1) + (q >> 1)) * 64 + lane];
                         const float4 v = e.valq[(size_t)(qoff + q) * 64 + lane];
-                        quad(c, v, acc);
+                        quad((q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y), v, acc);
                     }
                 }
 #pragma unroll
