@@ -39,6 +39,7 @@ namespace chebgcn {
 int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
 extern int g_prefer_planes;
 extern int g_slot_order;
+int g_stagger = 0;          // chebgcn_tune(4, x): 0 = automatic
 int g_wide = 0;            // chebgcn_tune(3, 1): prefer the 1024-thread shape (experiment)
 
 #ifndef CG_X
@@ -192,10 +193,12 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     // lock-step, all CUs would stream from L2, gather from LDS and write to HBM at the same
     // times; spread over roughly one step they overlap each other's phases instead.
     if (!(abl & 32)) {
-        // ... scaled down when a workgroup has only a few groups to work through (measured: no
-        // stagger is best at 4 groups per workgroup, the full one at 16)
+        // ... scaled with the number of groups a workgroup works through
         const int gpw = (ngrp + (int)gridDim.x - 1) / (int)gridDim.x;
-        const int reps = ((blockIdx.x >> 3) & 31) * (gpw < 16 ? gpw : 16) / 8 * (gpw > 4);
+        const int sx = (flags >> 20) & 0xFF;             // chebgcn_tune(4, x): stagger in 1/8 units of 640 cycles per rank (experiment)
+        // measured best: 640 cycles per rank at 4 groups per workgroup, twice that from 16 groups on
+        const int m8 = gpw <= 4 ? 8 : gpw >= 16 ? 16 : 8 + (8 * (gpw - 4)) / 12;
+        const int reps = ((blockIdx.x >> 3) & 31) * (sx ? sx - 1 : m8) / 8;
         for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
     }
 
@@ -565,7 +568,7 @@ static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* sr
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), 0, stream, view(ell), src, dst, g->M, g->Mp,
-                       nplanes, K, slab, copy_t0 | (g_ablate << 8));
+                       nplanes, K, slab, copy_t0 | ((g_ablate & 0xFFF) << 8) | (g_stagger << 20));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
@@ -620,6 +623,7 @@ extern "C" int chebgcn_tune(int key, int value) {
     if (key == 1 && (value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards
     if (key == 2) { g_slot_order = value; return 0; }
     if (key == 3) { g_wide = value; return 0; }
+    if (key == 4) { g_stagger = value & 0xFF; return 0; }
     return -1;
 }
 

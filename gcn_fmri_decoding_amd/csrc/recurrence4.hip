@@ -140,10 +140,10 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     auto rd_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot : id; };
     auto wr_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot + 1u : id; };
     if (!(abl & 32)) {                               // spread the workgroups of an XCD over one step
-        // ... scaled down when a workgroup has only a few groups to work through (measured: no
-        // stagger is best at 4 groups per workgroup, the full one at 16)
+        // ... scaled with the number of groups a workgroup works through
         const int gpw = (ngrp + (int)gridDim.x - 1) / (int)gridDim.x;
-        const int reps = ((blockIdx.x >> 3) & 31) * (gpw < 16 ? gpw : 16) / 8 * (gpw > 4);
+        const int m8 = gpw <= 4 ? 8 : gpw >= 16 ? 16 : 8 + (8 * (gpw - 4)) / 12;
+        const int reps = ((blockIdx.x >> 3) & 31) * m8 / 8;
         for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
     }
     const size_t in_base = ADJ ? (size_t)(K - 1) * slab : 0;

@@ -49,6 +49,11 @@ def test_argument_validation_without_gpu():
     assert lib.chebgcn_recurrence_fwd(None, None, None, 1, 1, 1, None) == -1
     assert lib.chebgcn_contract_fwd(None, None, None, 0, None, None, 1, 1, 1, 1, 1, 1, 0, 0, None) == -1
     assert lib.chebgcn_contract_bwd_w_workspace(0, 1, 1, 1, 1) == 0
+    # bf16 contraction: workspace arithmetic and argument checks need no device
+    assert lib.chebgcn_contract_fwd_bf16_workspace(0, 5, 256) == 0
+    assert lib.chebgcn_contract_fwd_bf16_workspace(60, 5, 256) == 2 * 19 * 256 * 16 * 2      # hi + lo, 19 k-steps
+    assert lib.chebgcn_contract_fwd_bf16(None, None, None, 0, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 1, None, 0, None) == -1
+    assert b'contract_fwd_bf16' in lib.chebgcn_last_error()
     with pytest.raises(_lib.ChebgcnError):
         _lib.check(-1, 'x')
 

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--planes', type=int, default=2, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
     ap.add_argument('--slot-order', type=int, default=-1, help='chebgcn_tune(2, x): 0 component-major, 1 vertex-major slots')
     ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
+    ap.add_argument('--stagger', type=int, default=0, help='chebgcn_tune(4, x): start stagger override (x-1 eighths), 0 = automatic')
     ap.add_argument('--wide', type=int, default=0, help='chebgcn_tune(3, x): 1 = 1024-thread recurrence shape')
     args = ap.parse_args()
 
@@ -46,6 +47,7 @@ def main():
     lib.chebgcn_tune(1, args.planes)
     lib.chebgcn_tune(2, args.slot_order)
     lib.chebgcn_tune(3, args.wide)
+    lib.chebgcn_tune(4, args.stagger)
     g = ops.Graph(Ls[0], dev)
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
           g.query(11), flush=True)
