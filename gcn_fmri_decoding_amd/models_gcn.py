@@ -16,6 +16,7 @@ buffer (one fused TF-form Adam launch, one RCCL all-reduce per bucket).
 """
 import collections
 import contextlib
+import json
 import math
 import os
 import shutil
@@ -368,11 +369,15 @@ class base_model(object):
         self.global_step = int(sd['global_step'])
 
     def _save_best(self, accuracy, step, best, num_to_keep=3):
-        """Keep the ``num_to_keep`` best checkpoints by validation accuracy
-        (checkmat.BestCheckpointSaver as used at :127, :175)."""
+        """Keep the ``num_to_keep`` best checkpoints by validation accuracy, with the policy and
+        the on-disk index of checkmat.BestCheckpointSaver (checkmat.py:8-118, used at
+        models_gcn.py:127, 175): a JSON file ``best_checkpoints`` mapping ``best.ckpt-<step>`` to
+        its value; a new value replaces the worst kept one unless every kept value is >= it.  The
+        weights themselves are a torch file ``best.ckpt-<step>.pt`` (variable names and shapes as
+        in the reference), found by ``get_best_checkpoint``."""
         path = os.path.join(self._get_path('checkpoints'), 'model')
         os.makedirs(path, exist_ok=True)
-        if len(best) >= num_to_keep and accuracy <= min(a for a, _ in best):
+        if len(best) >= num_to_keep and all(a >= accuracy for a, _ in best):
             return
         fname = os.path.join(path, 'best.ckpt-%d.pt' % step)
         torch.save(self.state_dict(), fname)
@@ -383,8 +388,7 @@ class base_model(object):
                 os.remove(old)
         del best[num_to_keep:]
         with open(os.path.join(path, 'best_checkpoints'), 'w') as f:
-            import json
-            json.dump({os.path.basename(p): a for a, p in best}, f)
+            json.dump({os.path.basename(p)[:-3]: float(a) for a, p in best}, f, indent=3)
 
     def _restore_latest(self):
         path = os.path.join(self._get_path('checkpoints'), 'model')
@@ -630,6 +634,17 @@ class cgcnn(base_model):
         with self.variable_scope('logits'):
             x = self.fc(x, self.M[-1], relu=False)
         return x
+
+
+def get_best_checkpoint(best_checkpoint_dir, select_maximum_value=True):
+    """Path of the best checkpoint according to the ``best_checkpoints`` index
+    (checkmat.get_best_checkpoint, checkmat.py:121-138); the weights are in ``<path>.pt``."""
+    index = os.path.join(best_checkpoint_dir, 'best_checkpoints')
+    assert os.path.exists(index)
+    with open(index) as f:
+        best = json.load(f)
+    names = sorted(best, key=best.get, reverse=select_maximum_value)
+    return os.path.join(best_checkpoint_dir, names[0])
 
 
 class model_perf(object):

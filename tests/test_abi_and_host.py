@@ -113,3 +113,29 @@ def test_constructor_checks_like_reference():
         models_gcn.cgcnn('meta', L, [2], [2], [8], [3], verbose=False)
     net = models_gcn.cgcnn('meta', L, [2, 2], [2, 3], [2, 1], [3], verbose=False, batch_size=2)
     assert [l.shape[0] for l in net.L] == [16, 8]
+
+
+def test_best_checkpoint_policy_matches_checkmat(tmp_path):
+    """checkmat.BestCheckpointSaver (checkmat.py:8-118): keep the 3 best by value, JSON index
+    'best_checkpoints' keyed 'best.ckpt-<step>'; get_best_checkpoint (:121-138) returns the top one."""
+    import json
+    from gcn_fmri_decoding_amd import models_gcn as M
+
+    class Stub(M.base_model):
+        def __init__(self, root):
+            self.dir_name, self._root = 'run', str(root)
+
+        def _get_path(self, folder):
+            return os.path.join(self._root, folder, self.dir_name)
+
+        def state_dict(self):
+            return {'k': 1}
+
+    st, best = Stub(tmp_path), []
+    for step, acc in [(10, 0.3), (20, 0.5), (30, 0.4), (40, 0.35), (50, 0.6), (60, 0.1), (70, 0.5)]:
+        st._save_best(acc, step, best)
+    path = os.path.join(str(tmp_path), 'checkpoints', 'run', 'model')
+    index = json.load(open(os.path.join(path, 'best_checkpoints')))
+    assert index == {'best.ckpt-50': 0.6, 'best.ckpt-20': 0.5, 'best.ckpt-70': 0.5}
+    assert sorted(f for f in os.listdir(path) if f.endswith('.pt')) == ['best.ckpt-20.pt', 'best.ckpt-50.pt', 'best.ckpt-70.pt']
+    assert M.get_best_checkpoint(path) == os.path.join(path, 'best.ckpt-50')
