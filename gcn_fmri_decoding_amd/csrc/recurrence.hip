@@ -83,6 +83,14 @@ __device__ long long g_dbg[16 * 64];
             g_dbg[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();                \
     } while (0)
 
+// levels whose id records (2 per group) stay in LDS: big shapes only (one workgroup per CU anyway)
+__host__ __device__ constexpr int lds_id_levels(int nj, int nthr, int planes) {
+    if (nthr < 512) return 0;
+    const int spare = 160 * 1024 - lds_capacity(nj, nthr, planes) * planes * 4;
+    const int lv = spare / ((nthr >> 6) * 2 * 1024);
+    return lv > nj ? nj : lv < 0 ? 0 : lv;
+}
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -141,6 +149,10 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                    int M, int Mp, int nplanes, int K, size_t slab, int flags) {
     // static image: its address folds into the LDS instructions (no base add per access)
     __shared__ __attribute__((aligned(16))) float T[lds_capacity(NJ, NTHR, P) * P];    // [entries][P], slot-indexed
+    // What the image leaves free of the 160 KB holds the id records of the first JL levels of every
+    // wave (1 KB each): an LDS read instead of a vector-memory instruction per step and record.
+    constexpr int JL = lds_id_levels(NJ, NTHR, P);
+    __shared__ uint4 idrec[JL > 0 ? JL * (NTHR >> 6) * 2 * 64 : 1];
     constexpr int QS = NJ / NQ > 0 ? NJ / NQ : 1;   // a linear piece every QS groups
     constexpr int nthr = NTHR;
     constexpr int nwaves = NTHR >> 6;
@@ -184,6 +196,15 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     const __amdgpu_buffer_rsrc_t colo_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colo, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valq, 0, 0x7FFFFFFF, 0x00020000);
     if (tid < P) T[e.zero_slot * P + tid] = 0.f;      // never written again
+    if constexpr (JL > 0) {
+#pragma unroll
+        for (int j = 0; j < JL; ++j) {
+            const int qoff = __builtin_amdgcn_readlane(gtab.x, j);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+                idrec[((j * nwaves + wave) * 2 + o) * 64 + lane] = e.colo[(size_t)((qoff >> 1) + o) * 64 + lane];
+        }
+    }
     // Vertices / ranks without an LDS slot (id 0xFFFF) read the zero slot and write a trash slot:
     // straight-line code whose LDS accesses can all be in flight together, instead of a branch
     // and a round trip per access.
@@ -411,6 +432,10 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 group_info(j, qoff, len);
                 if ((CG_X & 4) && j > 1) return;               // experiment: no operator loads after the prologue
                 if (o >= 1 && len <= 8) return;                // the second record only where a row needs it
+                if (j < JL && o < 2 && !(CG_X & 32768)) {      // resident in LDS (j is a compile-time constant here)
+                    ro[(QO * j + o) % ORING] = idrec[((j * nwaves + wave) * 2 + o) * 64 + lane];
+                    return;
+                }
                 const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(colo_rsrc, lane * 16, ((qoff >> 1) + o) * 1024, 0);
                 ro[(QO * j + o) % ORING] = make_uint4(c.x, c.y, c.z, c.w);
             };
@@ -556,7 +581,8 @@ cheb_step_global_kernel(const int32_t* __restrict__ rowptr, const int32_t* __res
 template <int P, int NJ, int NQ, int NTHR, bool ADJ>
 static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst,
                          int nplanes, int K, int copy_t0, hipStream_t stream) {
-    const size_t lds = (size_t)lds_capacity(NJ, NTHR, P) * P * sizeof(float);
+    const size_t lds = (size_t)lds_capacity(NJ, NTHR, P) * P * sizeof(float) +
+                       (size_t)lds_id_levels(NJ, NTHR, P) * (NTHR >> 6) * 2 * 1024;
     static_assert(NQ <= NJ, "a linear piece is issued per group at most");
     auto kern = cheb_onchip_kernel<P, NJ, NQ, NTHR, ADJ>;
     int per_cu = (int)((160 * 1024) / lds);
