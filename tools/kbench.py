@@ -87,6 +87,9 @@ def main():
         calls = {
             'recurrence_fwd': (lambda: lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, st),
                                4.0 * M * Fin * K * B, 0.0),
+            # T_0 already in slab 0 of the stack (what the model does): no copy of the input
+            'recurrence_fwd_inplace': (lambda: lib.chebgcn_recurrence_fwd(g.handle, P(stack), P(stack), B, Fin, K, st),
+                                       4.0 * M * Fin * K * B, 0.0),
             'recurrence_bwd': (lambda: lib.chebgcn_recurrence_bwd(g.handle, P(gstack), P(dx), B, Fin, K, st),
                                4.0 * M * Fin * (K + 1) * B, 0.0),
             'contract_fwd': (lambda: lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), 2, P(out), None, B, M, Fin, K, Fout,
