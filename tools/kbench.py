@@ -27,7 +27,7 @@ def main():
     ap.add_argument('--fout', type=int, default=32)
     ap.add_argument('--K', type=int, default=5)
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_bwd', 'contract_fwd',
+    ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_fwd_inplace', 'recurrence_bwd', 'contract_fwd',
                                                      'contract_bwd_w', 'contract_bwd_x', 'brelu_pool_bwd'])
     ap.add_argument('--ablate', type=int, nargs='+', default=[0])
     ap.add_argument('--json', default=None)
