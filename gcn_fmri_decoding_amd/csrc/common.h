@@ -47,6 +47,7 @@ struct Ell {
     uint2* colq = nullptr;        // [(nquads + kQuadPad)*64]
     uint4* colo = nullptr;        // [(nquads + kQuadPad)/2*64]  the same ids, quads 2o and 2o+1 in one record
     float4* valq = nullptr;       // [(nquads + kQuadPad)*64]
+    float4* valp = nullptr;       // the same, with the two ids of a short third quad in .z / .w (graph.hip)
     uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> LDS slot of that row, 0xFFFF for padding ranks
     uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> LDS slot, 0xFFFF = none (isolated / pad)
     // plain CSR for the out-of-LDS fallback
@@ -61,13 +62,14 @@ struct EllView {
     const uint2* colq;
     const uint4* colo;
     const float4* valq;
+    const float4* valp;
     const uint16_t* rowslot;
     const uint16_t* nodeslot;
     int ngroups, zero_slot;
 };
 
 static inline EllView view(const Ell& e) {
-    return EllView{e.ginfo, e.colq, e.colo, e.valq, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
+    return EllView{e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
 }
 
 }  // namespace chebgcn

@@ -33,7 +33,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 static void free_ell(Ell& e) {
-    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
+    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
     for (void* p : ptrs) (void)hipFree(p);
     e = Ell();
 }
@@ -148,7 +148,9 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     int64_t cost_before = 0, cost_after = 0, cost_ideal = 0;
     for (int g = 0; g < ngroups; ++g) {
         const int L = ginfo[g].y;
-        const int npos = L <= 8 ? 8 : 4 * ((L + 3) / 4);   // positions the kernel visits (recurrence*.hip)
+        // positions the kernel visits (recurrence*.hip); a third quad of at most two entries is
+        // gathered as a pair (its ids travel in the value record, see valp below)
+        const int npos = L <= 8 ? 8 : L <= 10 ? 10 : 4 * ((L + 3) / 4);
         for (int set = 0; set < (planes == 4 ? 4 : 2); ++set) {
             std::vector<int> lanes;
             for (int lane = 0; lane < 64; ++lane)
@@ -233,6 +235,21 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     if ((rc = upload(&out->colo, colo))) return rc;
     if ((rc = upload(&out->colq, colq))) return rc;
     if ((rc = upload(&out->valq, valq))) return rc;
+    // values as the generic kernel reads them: where the third quad of a group holds at most two
+    // entries (length 9..10), its two ids ride in the unused half of the 16-byte value record, so
+    // that such a group needs no second id record (one vector-memory instruction less per step)
+    std::vector<float4> valp(valq);
+    for (int g = 0; g < ngroups; ++g) {
+        if (ginfo[g].y <= 8 || ginfo[g].y > 10) continue;
+        const size_t q2 = (size_t)ginfo[g].x + 2;
+        for (int lane = 0; lane < 64; ++lane) {
+            float4& v = valp[q2 * 64 + lane];
+            const uint32_t ids = colq[q2 * 64 + lane].x;
+            memcpy(&v.z, &ids, 4);
+            memcpy(&v.w, &zz, 4);
+        }
+    }
+    if ((rc = upload(&out->valp, valp))) return rc;
     if ((rc = upload(&out->rowslot, rowslot))) return rc;
     if ((rc = upload(&out->nodeslot, nodeslot))) return rc;
     return CHEBGCN_OK;

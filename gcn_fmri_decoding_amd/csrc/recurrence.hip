@@ -194,7 +194,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     int2 gtab = make_int2(0, 0);
     if (lane < NJ && lane * nwaves + wave < e.ngroups) gtab = e.ginfo[lane * nwaves + wave];
     const __amdgpu_buffer_rsrc_t colo_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colo, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valq, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valp, 0, 0x7FFFFFFF, 0x00020000);
     if (tid < P) T[e.zero_slot * P + tid] = 0.f;      // never written again
     if constexpr (JL > 0) {
 #pragma unroll
@@ -431,7 +431,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 int qoff, len;
                 group_info(j, qoff, len);
                 if ((CG_X & 4) && j > 1) return;               // experiment: no operator loads after the prologue
-                if (o >= 1 && len <= 8) return;                // the second record only where a row needs it
+                if (o >= 1 && len <= 10) return;               // the second record only beyond 10 entries (9..10: ids in the value record)
                 if (j < JL && o < 2 && !(CG_X & 32768)) {      // resident in LDS (j is a compile-time constant here)
                     ro[(QO * j + o) % ORING] = idrec[((j * nwaves + wave) * 2 + o) * 64 + lane];
                     return;
@@ -450,6 +450,13 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             auto ids_of = [&](int j, int q) {        // the four ids of quad q of group j
                 const uint4 o = ro[(QO * j + (q >> 1)) % ORING];
                 return (q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y);
+            };
+            auto pair = [&](const unsigned c, const float v0, const float v1, float (&acc)[P]) {
+                const Ent<P> t0 = lds_at<P>(T, entry_ofs<P, 0>(c)), t1 = lds_at<P>(T, entry_ofs<P, 1>(c));
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = fmaf(v0, t0.x[p], acc[p]);
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p] = fmaf(v1, t1.x[p], acc[p]);
             };
             auto quad = [&](const uint2 c, const float4 v, float (&acc)[P]) {
                 Ent<P> t[4];
@@ -493,7 +500,11 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
                     // the first two quads always (zero-padded), the third for rows beyond 8 entries
-                    if (gather && (q < 2 || len > 8)) quad(ids_of(j, q), rv[(QMAX * j + q) % RING], acc);
+                    if (gather && q == 2 && len > 8 && len <= 10) {
+                        // a third quad of two entries: their ids are the .z word of the value record
+                        const float4 v = rv[(QMAX * j + q) % RING];
+                        pair(__float_as_uint(v.z), v.x, v.y, acc);
+                    } else if (gather && (q < 2 || len > 10)) quad(ids_of(j, q), rv[(QMAX * j + q) % RING], acc);
                     if (j + 2 < NJ) {
                         request(j + 2, q);                       // refill the slots just consumed
                         if ((q & 1) || q == QMAX - 1) request_ids(j + 2, q >> 1);
