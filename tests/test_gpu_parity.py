@@ -559,6 +559,32 @@ def test_four_plane_large_graph_kernel(ops, dev, nodes, B, Fin, K):
     assert torch.equal(s4b[:, :, :, :M], s4[:, :, :, :M])
 
 
+@pytest.mark.parametrize('nodes', [1500, 2600, 6000, 13000])
+def test_recurrence_other_kernel_shapes(ops, dev, nodes):
+    """Graph sizes that select the other workgroup shapes of the on-chip kernel (256/512/768 threads,
+    8..24 rows per thread, with and without LDS-resident id records): forward against the oracle on
+    two planes, adjoint by the identity <T(x), G> = <x, T*(G)>."""
+    from gcn_fmri_decoding_amd import _lib, graph
+    Ls, perm, _ = graph.synthetic_graph(nodes, k=8, levels=1)
+    L = Ls[0]
+    M = L.shape[0]
+    g = ops.Graph(L, dev)
+    assert g.query(3) == 1 and g.query(6) == 2
+    B, Fin, K = 2, 3, 5
+    torch.manual_seed(nodes)
+    x = torch.randn(B, Fin, g.Mp, device=dev)
+    G = torch.randn(K, B, Fin, g.Mp, device=dev)
+    x[:, :, M:] = 0
+    G[:, :, :, M:] = 0
+    stack, dx = _run_fwd_bwd(ops, g, x, G, K)
+    Lr = R.rescaled_laplacian(L, np.float32)
+    ref = GR.chebyshev(Lr, x[0, :2, :M].cpu().numpy().T.copy(), K)
+    close(stack[:, 0, :2, :M].permute(0, 2, 1).cpu().numpy(), ref, what='stack vs oracle')
+    lhs = (stack[:, :, :, :M].double() * G[:, :, :, :M].double()).sum().item()
+    rhs = (x[:, :, :M].double() * dx[:, :, :M].double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+
+
 def test_operator_layout_statistics(ops, dev):
     """graph_query 9..11: modelled LDS cycles of one gather pass in the caller's entry order, after
     the bank-aware placement of build_ell, and without any conflict."""
