@@ -51,8 +51,17 @@ int g_wide = 0;            // chebgcn_tune(3, 1): prefer the 1024-thread shape (
 constexpr int QMAX = 3;      // quads (4 operator entries each) requested per group, always, one group ahead
 static_assert(QMAX <= kQuadPad && QMAX == kQuadMin, "the operator arrays are padded for the unconditional requests");
 
-__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// planes are read once and written once: streaming (non-temporal) accesses keep them from
+// pushing the operator, which every step re-reads, out of the XCD's L2
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stg4(float* p, float4 v) {
+    f32x4n t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(p));
+}
 __device__ __forceinline__ unsigned slot_of(uint2 c, int i) {        // i-th 16-bit id of a packed quad
     const unsigned w = (i & 2) ? c.y : c.x;
     return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
