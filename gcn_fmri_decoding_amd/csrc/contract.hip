@@ -265,7 +265,7 @@ contract_bwd_w_kernel(BwdWArgs a) {
                 if (m >= a.Mp) m = 0;                   // beyond the plane: any valid address, masked below
                 const float* src = (rwin[u] > 0 ? a.stack + (size_t)b * a.Fin * a.Mp : a.dy + (size_t)b * a.Fout * a.Mp)
                                    + roff[u] + m;
-                __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 2);   // aux 2 = nt: every chunk is read once
             }
         }
         __syncthreads();                                // DMA landed (the barrier's release waits vmcnt(0))
