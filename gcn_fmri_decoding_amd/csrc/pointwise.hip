@@ -25,9 +25,10 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
     if (live) {
         for (int b = 0; b < B; ++b) {
             const size_t oi = ((size_t)b * F + f) * Mpo + mo;
-            float g = dout[oi];
+            // read once: streaming loads leave the L2 to dy, which the next two kernels read
+            float g = __builtin_nontemporal_load(dout + oi);
             if (pool == 1) {
-                if (relu && !(out[oi] > 0.f)) g = 0.f;
+                if (relu && !(__builtin_nontemporal_load(out + oi) > 0.f)) g = 0.f;
             } else if (pool_kind == CHEBGCN_POOL_MAX) {
                 const bool sel = argmax[oi] == pos;
                 if (!sel || (relu && !(out[oi] > 0.f))) g = 0.f;
