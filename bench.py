@@ -85,6 +85,8 @@ def main():
     ap.add_argument('--block-dura', type=int, default=15)
     ap.add_argument('--cpu-windows', type=int, default=16, help='0 disables the CPU baseline leg')
     ap.add_argument('--no-timers', action='store_true')
+    ap.add_argument('--timer-every', type=int, default=4,
+                    help='per-kernel HIP-event timing on every n-th timed step (event markers cost ~5 %% of a step when on every step)')
     args = ap.parse_args()
 
     import torch
@@ -136,11 +138,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     if not args.no_timers:
-        ops.timers = ops.KernelTimers()
+        ops.timers = ops.KernelTimers(every=args.timer_every)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
+        if ops.timers is not None:
+            ops.timers.next_step()        # per-kernel HIP events on every timer_every-th step of the timed region
         _, loss = step(i)
     torch.cuda.synchronize()
     barrier()
@@ -150,6 +154,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern = ops.timers.summary() if ops.timers is not None else {}
+    sampled = ops.timers.sampled_steps if ops.timers is not None else 0
     ops.timers = None
     loss = float(loss)
 
@@ -181,7 +186,9 @@ def main():
             line['kernels'] = {k: {'avg_ms': v['avg_ms'], 'launches': v['launches'],
                                    'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
                                    'TFLOPs': v['flops'] / (v['total_ms'] * 1e-3) / 1e12,
-                                   'share_of_step': v['total_ms'] / (1e3 * dt)} for k, v in kern.items()}
+                                   'share_of_step': v['total_ms'] / max(sampled, 1) / (1e3 * dt / args.steps)}
+                               for k, v in kern.items()}
+            line['kernel_timing'] = 'HIP events around every launch of these kernels on %d of the %d timed steps' % (sampled, args.steps)
         if world == 1 and args.cpu_windows > 0:
             line['cpu_baseline'] = cpu_baseline(Ls[:1], cfg, args.cpu_windows)
         print(json.dumps(line))
