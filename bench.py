@@ -113,7 +113,9 @@ def main():
     Ls, perm = load_graph(args.nodes, 1, rank, world, barrier)
     cfg = dict(F=[32] * 6, K=[args.korder] * 6, p=[1] * 6, M=[512, 256, 22], channel=args.block_dura)
     torch.manual_seed(0)
-    net = models_gcn.cgcnn({'device': dev}, Ls[:1], cfg['F'], cfg['K'], cfg['p'], cfg['M'], filter='chebyshev5',
+    # one Laplacian per conv layer (no pooling: the same matrix object six times, one device graph);
+    # a shorter list makes the constructor print its consistency check, as the reference does
+    net = models_gcn.cgcnn({'device': dev}, [Ls[0]] * len(cfg['F']), cfg['F'], cfg['K'], cfg['p'], cfg['M'], filter='chebyshev5',
                            brelu='b2relu', pool='mpool1', initial='he', channel=cfg['channel'], regularization=5e-4,
                            dropout=0.5, batch_size=args.batch, learning_rate=0.001, decay_rate=0.9, momentum=0.9,
                            verbose=False)
