@@ -85,6 +85,7 @@ def main():
     ap.add_argument('--block-dura', type=int, default=15)
     ap.add_argument('--cpu-windows', type=int, default=16, help='0 disables the CPU baseline leg')
     ap.add_argument('--no-timers', action='store_true')
+    ap.add_argument('--overlap-bwd-w', type=int, default=0, help='experiment: contract_bwd_w on a second stream')
     ap.add_argument('--timer-every', type=int, default=4,
                     help='per-kernel HIP-event timing on every n-th timed step (event markers cost ~5 %% of a step when on every step)')
     args = ap.parse_args()
@@ -109,6 +110,7 @@ def main():
 
     from gcn_fmri_decoding_amd import models_gcn, ops
     from gcn_fmri_decoding_amd import dist as gdist
+    ops.overlap_bwd_w = bool(args.overlap_bwd_w)
 
     Ls, perm = load_graph(args.nodes, 1, rank, world, barrier)
     cfg = dict(F=[32] * 6, K=[args.korder] * 6, p=[1] * 6, M=[512, 256, 22], channel=args.block_dura)

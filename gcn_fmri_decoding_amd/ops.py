@@ -71,6 +71,15 @@ class KernelTimers:
 
 
 timers = None
+overlap_bwd_w = False        # experiment: contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = torch.device(dev).index
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
 
 
 def _launch(name, nbytes, flops, fn):
@@ -349,9 +358,20 @@ class ChebConv(torch.autograd.Function):
                 dW = dW_buf                       # written, not accumulated: one use per step
             else:
                 dW = torch.empty((Fin * K, Fout), dtype=torch.float32, device=dev)
-            _lib.check(_launch('contract_bwd_w', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
-                               lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
-                                                                  K, Fout, _stream())), 'contract_bwd_w')
+            side = _side_stream(dev) if (overlap_bwd_w and ctx.needs_input_grad[0]) else None
+            if side is not None:
+                # dW does not feed dx: it runs beside contract_bwd_x / recurrence_bwd on a second stream
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    _lib.check(_launch('contract_bwd_w', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
+                                       lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M,
+                                                                          Fin, K, Fout, _stream())), 'contract_bwd_w')
+            else:
+                _lib.check(_launch('contract_bwd_w', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
+                                   lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
+                                                                      K, Fout, _stream())), 'contract_bwd_w')
+        else:
+            side = None
         dx = None
         if ctx.needs_input_grad[0]:
             gstack = torch.empty((K, B, Fin, g.Mp), dtype=torch.float32, device=dev)
@@ -361,6 +381,10 @@ class ChebConv(torch.autograd.Function):
             dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
             _lib.check(_launch('recurrence_bwd', 4.0 * B * M * Fin * (K + 1), 0.0, lambda: lib.chebgcn_recurrence_bwd(
                 g.handle, _p(gstack), _p(dx), B, Fin, K, _stream())), 'recurrence_bwd')
+        if side is not None:
+            # joined before this layer's buffers (stack, dy, workspace) can be reused and before
+            # anything consumes dW
+            torch.cuda.current_stream(dev).wait_stream(side)
         # gradients written into the caller's buffers are not handed to autograd a second time
         return (dx, None if dW_buf is not None else dW, None if dbias_buf is not None else dbias,
                 None, None, None, None, None, None, None)
