@@ -438,6 +438,27 @@ def test_train_step_vs_oracle(ops, dev, name):
             close(net.get_var(k), params[k], rel=2e-5, what='step %d %s' % (step, k))
 
 
+def test_second_stream_for_bwd_w_is_bit_identical(ops, dev):
+    """ops.overlap_bwd_w: contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd.
+    Three training steps must leave bit-identical variables."""
+    z = load_golden('inference_pool_n212')
+    x = to_storage(ops, z['x'], dev)
+    labels = torch.as_tensor(np.arange(z['x'].shape[0]) % int(z['M'][-1])).to(dev)
+    results = []
+    for flag in (False, True):
+        ops.overlap_bwd_w = flag
+        try:
+            net, _, params = build_model(z, dev, regularization=5e-4, dropout=1)
+            for _ in range(3):
+                net.train_step(x, labels)
+            torch.cuda.synchronize()
+            results.append({k: net.get_var(k).copy() for k in params})
+        finally:
+            ops.overlap_bwd_w = False
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k]), k
+
+
 def net_grad_in_ref_shape(net, name):
     spec = next(s for s in net._spec_list if s.name == name)
     g = net._params[name].grad
