@@ -39,7 +39,7 @@ static void free_ell(Ell& e) {
 }
 
 constexpr int kLdsBytes = 160 * 1024;     // LDS per workgroup on gfx950
-int g_prefer_planes = 2;                  // chebgcn_tune(1, planes); see graph_create
+int g_prefer_planes = 0;                  // chebgcn_tune(1, planes): 0 = automatic, 2 or 4 forced; see graph_create
 int g_slot_order = -1;                    // chebgcn_tune(2, x): experiments, -1 = automatic
 
 // Planes per workgroup for an image of n vertices (+ zero and trash slot, rounded to 4 entries):
@@ -308,13 +308,15 @@ extern "C" int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr, c
     g->num_cus = prop.multiProcessorCount;
     int planes = 0;
     if ((size_t)kLdsBytes <= (size_t)prop.maxSharedMemoryPerMultiProcessor) {
-        // 2 planes per workgroup keep every vertex on chip; 4 planes (only the active vertices
-        // on chip) halve the operator stream per plane but measured slower on MI355X at
-        // M ~ 10k (fewer waves, register spills), so they are opt-in: chebgcn_tune(1, 4)
+        // 2 planes per workgroup keep every vertex on chip; 4 planes (only the active vertices on
+        // chip) halve the operator instructions per plane.  Measured on MI355X: up to 2048 rows
+        // (the sizes of real brain atlases, 246..1000 nodes) the generic kernel with 4 planes is
+        // 1.1-2x faster; beyond, the four-plane kernel of recurrence4.hip loses (registers), so
+        // there 4 planes are opt-in: chebgcn_tune(1, 4)
         planes = planes_for(M) >= 2 ? 2 : 0;
-        if (g_prefer_planes == 4 && planes_for(nactive) == 4) {
+        if (g_prefer_planes != 2 && planes_for(nactive) == 4) {
             const int rows = ((nactive + 63) / 64) * 64, entries = (nactive + 2 + 3) & ~3;
-            if (rows <= 2048 || onchip4_fits(entries, rows, g->Mp / 4)) planes = 4;
+            if (rows <= 2048 || (g_prefer_planes == 4 && onchip4_fits(entries, rows, g->Mp / 4))) planes = 4;
         }
     }
     g->lds_ok = planes != 0;

@@ -667,7 +667,7 @@ extern "C" int chebgcn_debug_stamps(long long* out) {       // CG_X & 64 builds 
 
 extern "C" int chebgcn_tune(int key, int value) {
     if (key == 0) { g_ablate = value; return 0; }
-    if (key == 1 && (value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards
+    if (key == 1 && (value == 0 || value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards; 0 = automatic
     if (key == 2) { g_slot_order = value; return 0; }
     if (key == 3) { g_wide = value; return 0; }
     if (key == 4) { g_stagger = value & 0xFF; return 0; }

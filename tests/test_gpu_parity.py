@@ -520,14 +520,16 @@ def test_four_plane_kernel_matches_two_plane(ops, dev, lvl, B, Fin, K):
     L = levels()[lvl]
     M = L.shape[0]
     torch.manual_seed(lvl)
-    g2 = ops.Graph(L, dev)
-    assert g2.query(6) == 2
-    _lib.lib().chebgcn_tune(1, 4)
+    _lib.lib().chebgcn_tune(1, 2)
     try:
+        g2 = ops.Graph(L, dev)
+        _lib.lib().chebgcn_tune(1, 4)
         g4 = ops.Graph(L, dev)
     finally:
-        _lib.lib().chebgcn_tune(1, 2)
+        _lib.lib().chebgcn_tune(1, 0)
+    assert g2.query(6) == 2
     assert g4.query(6) == 4 and g4.query(7) <= M
+    assert ops.Graph(L, dev).query(6) == 4               # the automatic choice for a small graph
     x = torch.randn(B, Fin, g2.Mp, device=dev)
     G = torch.randn(K, B, Fin, g2.Mp, device=dev)
     s2, d2 = _run_fwd_bwd(ops, g2, x, G, K)
@@ -554,7 +556,7 @@ def test_four_plane_large_graph_kernel(ops, dev, nodes, B, Fin, K):
     try:
         g4 = ops.Graph(L, dev)
     finally:
-        _lib.lib().chebgcn_tune(1, 2)
+        _lib.lib().chebgcn_tune(1, 0)
     assert g4.query(6) == 4 and 2048 < g4.query(7) < M        # some vertices are isolated
     torch.manual_seed(nodes + K)
     x = torch.randn(B, Fin, g2.Mp, device=dev)
@@ -590,7 +592,7 @@ def test_recurrence_other_kernel_shapes(ops, dev, nodes):
     L = Ls[0]
     M = L.shape[0]
     g = ops.Graph(L, dev)
-    assert g.query(3) == 1 and g.query(6) == 2
+    assert g.query(3) == 1 and g.query(6) == (4 if nodes <= 1500 else 2)      # automatic: 4 planes up to 2048 rows
     B, Fin, K = 2, 3, 5
     torch.manual_seed(nodes)
     x = torch.randn(B, Fin, g.Mp, device=dev)

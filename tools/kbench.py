@@ -31,7 +31,7 @@ def main():
                                                      'contract_bwd_w', 'contract_bwd_x', 'brelu_pool_bwd'])
     ap.add_argument('--ablate', type=int, nargs='+', default=[0])
     ap.add_argument('--json', default=None)
-    ap.add_argument('--planes', type=int, default=2, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
+    ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
     ap.add_argument('--slot-order', type=int, default=-1, help='chebgcn_tune(2, x): 0 component-major, 1 vertex-major slots')
     ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
     ap.add_argument('--stagger', type=int, default=0, help='chebgcn_tune(4, x): start stagger override (x-1 eighths), 0 = automatic')
