@@ -227,7 +227,8 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
         const int sx = (flags >> 20) & 0xFF;             // chebgcn_tune(4, x): stagger in 1/8 units of 640 cycles per rank (experiment)
         // measured best: 640 cycles per rank at 4 groups per workgroup, twice that from 16 groups on
         const int m8 = gpw <= 4 ? 8 : gpw >= 16 ? 16 : 8 + (8 * (gpw - 4)) / 12;
-        const int reps = ((blockIdx.x >> 3) & 31) * (sx ? sx - 1 : m8) / 8;
+        // small shapes (several workgroups per CU, about one group each) are not staggered: -10 % there
+        const int reps = ((blockIdx.x >> 3) & 31) * (sx ? sx - 1 : NTHR >= 512 ? m8 : 0) / 8;
         for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
     }
 
