@@ -6,16 +6,22 @@
 namespace chebgcn {
 
 // ---- d(pool o relu o bias): MaxPoolGrad + ReluGrad + bias reductions -------------------
-// thread = one pre-pool element (f, m); loops over the batch so that the per-vertex bias
-// gradient of b2relu (models_gcn.py:625-629) is a private register sum.
-template <int BIAS>
+// thread = one pre-pool element (f, m) and one of PARTS interleaved subsets of the batch; it loops
+// over its windows so that the per-vertex bias gradient of b2relu (models_gcn.py:625-629) is a
+// private register sum, and the PARTS partial sums of a vertex are added in LDS in a fixed order.
+// PARTS > 1 is for small graphs (the reference's atlases have 246..1000 nodes), where M*F threads
+// alone leave most of the chip idle.
+template <int BIAS, int PARTS>
 __global__ void __launch_bounds__(256)
 brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                       const uint8_t* __restrict__ argmax, float* __restrict__ dy,
                       float* __restrict__ dbias, int B, int M, int Mp, int F, int pool, int pool_kind,
                       int relu, int Mpo) {
+    constexpr int VB = 256 / PARTS;                  // vertices per block
     __shared__ float red[4];
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float psum[PARTS > 1 ? 256 : 1];
+    const int mloc = threadIdx.x % VB, part = threadIdx.x / VB;
+    const int m = blockIdx.x * VB + mloc;
     const int f = blockIdx.y;
     const bool live = m < M;
     const int mo = live ? m / pool : 0;
@@ -23,7 +29,7 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
     const float inv = 1.0f / (float)pool;
     float sum = 0.f;
     if (live) {
-        for (int b = 0; b < B; ++b) {
+        for (int b = part; b < B; b += PARTS) {
             const size_t oi = ((size_t)b * F + f) * Mpo + mo;
             // read once: streaming loads leave the L2 to dy, which the next two kernels read
             float g = __builtin_nontemporal_load(dout + oi);
@@ -41,7 +47,18 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
         }
     }
     if (BIAS == CHEBGCN_BIAS_VERTEX) {
-        if (live) dbias[(size_t)f * Mp + m] = sum;
+        if (PARTS > 1) {
+            psum[threadIdx.x] = sum;
+            __syncthreads();
+            if (part == 0 && live) {
+                float t = psum[mloc];
+#pragma unroll
+                for (int p = 1; p < PARTS; ++p) t += psum[p * VB + mloc];
+                dbias[(size_t)f * Mp + m] = t;
+            }
+        } else if (live) {
+            dbias[(size_t)f * Mp + m] = sum;
+        }
     } else if (BIAS == CHEBGCN_BIAS_FILTER) {
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
@@ -199,18 +216,23 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
     CG_REQUIRE(pool == 1 || argmax || (pool_kind == CHEBGCN_POOL_AVG && !relu), "brelu_pool_bwd: pooling needs argmax/mask");
     CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || dbias, "brelu_pool_bwd: dbias is NULL");
     const int Mp = plane_stride(M), Mpo = plane_stride(M / pool);
-    dim3 grid((M + 255) / 256, F);
-    if (bias_kind == CHEBGCN_BIAS_FILTER) {
-        CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));
-        hipLaunchKernelGGL(brelu_pool_bwd_kernel<CHEBGCN_BIAS_FILTER>, grid, dim3(256), 0, stream, dout, out, argmax, dy,
-                           dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo);
-    } else if (bias_kind == CHEBGCN_BIAS_VERTEX) {
-        hipLaunchKernelGGL(brelu_pool_bwd_kernel<CHEBGCN_BIAS_VERTEX>, grid, dim3(256), 0, stream, dout, out, argmax, dy,
-                           dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo);
-    } else {
-        hipLaunchKernelGGL(brelu_pool_bwd_kernel<CHEBGCN_BIAS_NONE>, grid, dim3(256), 0, stream, dout, out, argmax, dy,
-                           dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo);
-    }
+    // enough workgroups for the chip: small graphs split the batch over 4 or 8 thread groups
+    const int parts = ((M + 255) / 256) * F >= 1024 ? 1 : ((M + 63) / 64) * F >= 1024 ? 4 : 8;
+    if (bias_kind == CHEBGCN_BIAS_FILTER) CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));
+#define CG_BRELU(BK, PARTS)                                                                                       \
+    hipLaunchKernelGGL((brelu_pool_bwd_kernel<BK, PARTS>), dim3((M + 256 / PARTS - 1) / (256 / PARTS), F), dim3(256), \
+                       0, stream, dout, out, argmax, dy, dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo)
+#define CG_BRELU_P(BK)                                                        \
+    do {                                                                      \
+        if (parts == 1) CG_BRELU(BK, 1);                                      \
+        else if (parts == 4) CG_BRELU(BK, 4);                                 \
+        else CG_BRELU(BK, 8);                                                 \
+    } while (0)
+    if (bias_kind == CHEBGCN_BIAS_FILTER) CG_BRELU_P(CHEBGCN_BIAS_FILTER);
+    else if (bias_kind == CHEBGCN_BIAS_VERTEX) CG_BRELU_P(CHEBGCN_BIAS_VERTEX);
+    else CG_BRELU_P(CHEBGCN_BIAS_NONE);
+#undef CG_BRELU_P
+#undef CG_BRELU
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -440,8 +440,9 @@ def test_train_step_vs_oracle(ops, dev, name):
 
 def test_second_stream_for_bwd_w_is_bit_identical(ops, dev):
     """ops.overlap_bwd_w: contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd.
-    Three training steps must leave bit-identical variables."""
-    z = load_golden('inference_pool_n212')
+    Three training steps must leave bit-identical variables.  (b2relu model: the per-filter bias
+    gradient of b1relu is summed with atomics across workgroups, whose order is not fixed.)"""
+    z = load_golden('inference_flat_n212')
     x = to_storage(ops, z['x'], dev)
     labels = torch.as_tensor(np.arange(z['x'].shape[0]) % int(z['M'][-1])).to(dev)
     results = []
