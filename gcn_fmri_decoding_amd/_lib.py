@@ -64,6 +64,9 @@ def lib():
                 '`python -c "import __graft_entry__ as g; g.build()"` or '
                 '`make -C gcn_fmri_decoding_amd/csrc` (needs hipcc, --offload-arch=gfx950). '
                 'There is no CPU fallback.' % LIB_PATH)
+        # PyTorch first: libchebgcn.so needs libamdhip64, and the copy PyTorch bundles must be the one
+        # in the process -- loaded the other way round, two HIP runtimes coexist and ours sees no device
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)        # AttributeError if the symbol is missing
