@@ -46,15 +46,24 @@ def load_graph(n_nodes, levels, rank, world, barrier):
     return Ls, z['perm']
 
 
-def cpu_baseline(Ls, cfg, n_windows, seed=0):
-    """The oracle (NumPy/SciPy restatement of the reference's algorithm) timed on the host:
-    forward + loss + backward + Adam for ``n_windows`` windows of the same workload."""
+def cpu_baseline(Ls, cfg, n_windows, seed=0, repeats=5):
+    """CPU baselines on the GPU box's host, same workload, ``n_windows`` windows per step
+    (BASELINE.md section 2):
+
+    * B2 (the headline ``value``): oracle/torch_cpu_ref.py -- torch CPU, ``torch.sparse_csr``
+      SpMM + matmul + autograd + TF-form Adam on every host core torch uses; one warm-up step,
+      then the median of ``repeats`` steps;
+    * ``scipy``: oracle/layers_ref.py -- NumPy/SciPy with the hand-written backward (SciPy's
+      SpMM runs on one thread, BLAS on many), one warm-up and one timed step.
+    Reported baselines, not the optimisation target."""
+    import torch
     from oracle import layers_ref as R
+    from oracle import torch_cpu_ref as TR
     try:
         import threadpoolctl
-        threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+        blas_threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count() or 1
+        blas_threads = os.cpu_count() or 1
     net = R.Net(Ls, cfg['F'], cfg['K'], cfg['p'], cfg['M'], channel=cfg['channel'], brelu='b2relu', regularization=5e-4)
     rs = np.random.RandomState(seed)
     params = {}
@@ -63,15 +72,83 @@ def cpu_baseline(Ls, cfg, n_windows, seed=0):
                      else (rs.randn(*s) * np.sqrt(2.0 / s[0])).astype(np.float32))
     x = rs.randn(n_windows, Ls[0].shape[0], cfg['channel']).astype(np.float32)
     labels = rs.randint(0, 21, n_windows)
+
+    tnet = TR.TorchNet([Ls[0]] * len(cfg['F']), cfg['F'], cfg['K'], cfg['p'], cfg['M'], channel=cfg['channel'], brelu='b2relu',
+                       regularization=5e-4)
+    tparams = {k: torch.tensor(v) for k, v in params.items()}
+    tx, ty, tstate = torch.tensor(x), torch.tensor(labels), {}
+    t_all = time.time()
+    tnet.train_step(tparams, tx, ty, tstate)                    # warm-up (first-touch page faults, thread pools)
+    times = []
+    for _ in range(repeats):
+        t0 = time.time()
+        tnet.train_step(tparams, tx, ty, tstate)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    t_torch = time.time() - t_all
+
+    def scipy_step():
+        logits, cache = net.forward(params, x)
+        loss, dlogits = net.loss(params, logits, labels)
+        grads = net.backward(params, cache, dlogits)
+        R.adam_tf_step(params, grads, {})
+    t_all = time.time()
+    scipy_step()
     t0 = time.time()
-    logits, cache = net.forward(params, x)
-    loss, dlogits = net.loss(params, logits, labels)
-    grads = net.backward(params, cache, dlogits)
-    R.adam_tf_step(params, grads, {})
-    dt = time.time() - t0
-    return {'value': n_windows / dt, 'unit': 'windows/s', 'cores': int(threads), 'kind': 'port',
-            'sample': '%d windows, full 6-layer fwd+loss+bwd+Adam, NumPy/SciPy oracle (SciPy SpMM is single-threaded, '
-                      'BLAS uses %d threads), %.1f s' % (n_windows, threads, dt)}
+    scipy_step()
+    dt_scipy = time.time() - t0
+    t_scipy = time.time() - t_all
+    return {'value': n_windows / med, 'unit': 'windows/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': '%d windows per step, full 6-layer fwd+loss+bwd+Adam; torch-CPU restatement (oracle/torch_cpu_ref.py, '
+                      'torch.sparse_csr SpMM, %d torch threads of %d host CPUs): 1 warm-up + median of %d steps, %.1f s in all'
+                      % (n_windows, torch.get_num_threads(), os.cpu_count() or 0, repeats, t_torch),
+            'step_s_median': med, 'step_s_all': [float(t) for t in times],
+            'scipy': {'value': n_windows / dt_scipy, 'unit': 'windows/s', 'cores': 1, 'blas_threads': int(blas_threads),
+                      'sample': '%d windows, NumPy/SciPy oracle (oracle/layers_ref.py; SciPy SpMM is single-threaded, BLAS uses '
+                                '%d threads): 1 warm-up + 1 timed step, %.1f s in all' % (n_windows, blas_threads, t_scipy)}}
+
+
+def kernel_leg(lib_graph, B, Fin, K, launches, what):
+    """HIP-event timing of the recurrence kernels alone at a shape BASELINE.json names (the
+    north-star shape K=5 / Fin=32 / batch 256, configs[3] K=25 / Fin=Fout=64): ``launches``
+    back-to-back launches each, events recorded on the launch stream, algorithmic bytes per
+    SURVEY.md 8(d): forward 4*M*Fin*K per window (T_0 in place, as the model runs it; the copy of
+    x adds one slab), adjoint 4*M*Fin*(K+1)."""
+    import torch
+    from gcn_fmri_decoding_amd import _lib, ops
+    g = lib_graph
+    lib = _lib.lib()
+    dev = g.device
+    stack = torch.randn((K, B, Fin, g.Mp), device=dev)
+    gstack = torch.randn((K, B, Fin, g.Mp), device=dev)
+    dx = torch.empty((B, Fin, g.Mp), device=dev)
+    xcopy = stack[0].clone()
+    st, P = ops._stream(), ops._p
+    calls = {
+        'recurrence_fwd': (lambda: lib.chebgcn_recurrence_fwd(g.handle, P(stack), P(stack), B, Fin, K, st), 4.0 * g.M * Fin * K * B),
+        'recurrence_fwd_copy_x': (lambda: lib.chebgcn_recurrence_fwd(g.handle, P(xcopy), P(stack), B, Fin, K, st),
+                                  4.0 * g.M * Fin * (K + 1) * B),
+        'recurrence_bwd': (lambda: lib.chebgcn_recurrence_bwd(g.handle, P(gstack), P(dx), B, Fin, K, st), 4.0 * g.M * Fin * (K + 1) * B),
+    }
+    out = {'shape': {'B': B, 'Fin': Fin, 'K': K, 'M': g.M}, 'launches': launches, 'what': what,
+           'timing': 'HIP events around each launch on the launch stream, mean over the launches after 3 warm-up launches'}
+    for name, (fn, nbytes) in calls.items():
+        for _ in range(3):
+            _lib.check(fn(), name)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for s, e in evs:
+            s.record()
+            _lib.check(fn(), name)
+            e.record()
+        torch.cuda.synchronize()
+        ms = [s.elapsed_time(e) for s, e in evs]
+        avg = float(np.mean(ms))
+        out[name] = {'avg_ms': avg, 'min_ms': float(np.min(ms)), 'algorithmic_bytes': nbytes, 'GBps': nbytes / avg / 1e6,
+                     'frac': nbytes / avg / 1e6 / HBM_PEAK_GBS}
+    del stack, gstack, dx, xcopy
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -84,6 +161,9 @@ def main():
     ap.add_argument('--korder', type=int, default=5)
     ap.add_argument('--block-dura', type=int, default=15)
     ap.add_argument('--cpu-windows', type=int, default=16, help='0 disables the CPU baseline leg')
+    ap.add_argument('--kernel-legs', type=int, default=1,
+                    help='1: also time the recurrence kernels alone at the north-star shape (K=5, Fin=32, batch 256) and at '
+                         'configs[3] (K=25, Fin=64, batch 64); N=1 only')
     ap.add_argument('--no-timers', action='store_true')
     ap.add_argument('--overlap-bwd-w', type=int, default=0, help='experiment: contract_bwd_w on a second stream')
     ap.add_argument('--timer-every', type=int, default=4,
@@ -185,6 +265,8 @@ def main():
                 traffic = json.load(open(tpath)).get(dom)
             line['roofline'] = {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                                'traffic_source': 'profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                                                  'tools/pmc_traffic.sh at this shape, not measured in this run)',
                                 'avg_launch_ms': d['avg_ms'], 'launches': d['launches'],
                                 'algorithmic_bytes_per_launch': d['bytes'] / d['launches']}
             line['kernels'] = {k: {'avg_ms': v['avg_ms'], 'launches': v['launches'],
@@ -193,6 +275,11 @@ def main():
                                    'share_of_step': v['total_ms'] / max(sampled, 1) / (1e3 * dt / args.steps)}
                                for k, v in kern.items()}
             line['kernel_timing'] = 'HIP events around every launch of these kernels on %d of the %d timed steps' % (sampled, args.steps)
+        if world == 1 and args.kernel_legs:
+            g0 = net.graphs[0]
+            line['northstar'] = kernel_leg(g0, 256, 32, 5, 50, 'north-star shape of BASELINE.json: K=5 recurrence, Fin=32, batch 256, '
+                                                               'M=10466; target frac >= 0.40')
+            line['config4'] = kernel_leg(g0, 64, 64, 25, 20, 'BASELINE configs[3]: K=25, Fin=Fout=64, batch 64 (SpMM-bound regime)')
         if world == 1 and args.cpu_windows > 0:
             line['cpu_baseline'] = cpu_baseline(Ls[:1], cfg, args.cpu_windows)
         print(json.dumps(line))

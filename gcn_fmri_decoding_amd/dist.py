@@ -4,23 +4,26 @@ averaged with RCCL (``torch.distributed`` backend "nccl" on ROCm) over xGMI.
 The reference is single-process; this is new.  Every hot-path op is
 independent per window, so each rank runs the whole network on its shard and the only
 exchange is the gradient all-reduce.  All parameters live in one flat fp32 buffer laid out
-``[head | conv weights | conv biases]`` (models_gcn.build_graph):
+``[head | conv weights | conv biases]`` (models_gcn.build_graph), conv variables in layer
+order inside their regions.  Backward runs head -> conv_n -> ... -> conv_1, so gradients
+are reduced in that order, in few large messages (xGMI is point-to-point, 7 links per GPU:
+a ring is per-link bound and wants big messages):
 
-* bucket 0 = the FC head (71 % of the bytes at the benchmark config; its gradients are
-  complete first because backward runs head -> conv6 -> ... -> conv1).  Its all-reduce is
+* bucket 0 = the FC head (71 % of the bytes at the benchmark config).  Its all-reduce is
   issued from a post-accumulate hook as soon as the last head gradient lands and overlaps
   the whole convolutional backward on RCCL's own stream.
-* bucket 1 = conv weights + biases, reduced after backward.
-
-Two large collectives instead of many small ones: xGMI is point-to-point (7 links per GPU),
-so a ring is per-link bound and wants big messages.
+* conv buckets = groups of consecutive layers, last layers first (default: two groups).  The
+  conv layers write their gradients straight into the flat buffer (ops.ChebConv, no autograd
+  hook fires), so ``ChebConv.backward`` reports a finished layer through ``layer_done``; when
+  the first layer of a group is done, the group's weight and bias slices (one contiguous range
+  each) go out while the earlier layers still run.  Only the last group is exposed.
 """
 import torch
 import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, conv_groups=2):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.model = model
@@ -34,8 +37,35 @@ class DataParallel:
         for name in self._head_names:
             p = model._params[name]
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_head_grad))
+        self._plan_conv_buckets(conv_groups)
         model._dp = self
         self.broadcast_parameters()
+
+    # -------------------------------------------------------------------------- buckets
+    def _plan_conv_buckets(self, conv_groups):
+        """Split the conv layers into ``conv_groups`` runs of consecutive layers; a run is sent
+        when its FIRST layer (the last one backward reaches) reports done.  Each run is one
+        contiguous slice of the conv-weight region and one of the conv-bias region."""
+        m = self.model
+        slices = getattr(m, '_slices', None)
+        layers = sorted({int(s.name.split('/')[0][4:]) for s in m._spec_list if s.group in ('convw', 'convb')})
+        self._buckets = []          # (trigger layer, [(a, b), ...]) in sending order
+        self._sent = set()
+        if not layers or slices is None:
+            return
+        n = max(1, min(int(conv_groups), len(layers)))
+        per = -(-len(layers) // n)
+        runs = [layers[i:i + per] for i in range(0, len(layers), per)]
+        for run in reversed(runs):
+            ranges = []
+            for leaf in ('weights', 'bias'):
+                names = ['conv%d/%s' % (i, leaf) for i in run if 'conv%d/%s' % (i, leaf) in slices]
+                if names:
+                    a, b = min(slices[k][0] for k in names), max(slices[k][1] for k in names)
+                    if b - a != sum(slices[k][1] - slices[k][0] for k in names):
+                        raise AssertionError('conv variables of layers %s are not contiguous in the flat buffer' % run)
+                    ranges.append((a, b))
+            self._buckets.append((run[0], ranges))
 
     def broadcast_parameters(self, src=0):
         """Start every rank from rank ``src``'s variables and optimizer state."""
@@ -43,24 +73,46 @@ class DataParallel:
         for buf in (m._flat, m._adam_m, m._adam_v):
             dist.broadcast(buf, src, group=self.group)
 
+    def barrier(self):
+        dist.barrier(group=self.group)
+
     # called by cgcnn.train_step -----------------------------------------------------
     def begin_step(self):
         self._pending = len(self._head_names)
         self._work = []
+        self._sent = set()
+
+    def _reduce(self, a, b):
+        g = self.model._grad[a:b]
+        self._work.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_head_grad(self, _param):
         self._pending -= 1
         if self._pending == 0:
-            g = self.model._grad[:self.model._n_head]
-            self._work.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._reduce(0, self.model._n_head)
+
+    def layer_done(self, layer):
+        """Conv layer ``layer`` (1-based) has enqueued its gradient kernels (ops.ChebConv.backward)."""
+        for i, (trigger, ranges) in enumerate(self._buckets):
+            if trigger == layer and i not in self._sent:
+                self._sent.add(i)
+                for a, b in ranges:
+                    self._reduce(a, b)
 
     def finish_step(self):
         """Reduce what is left, wait, and return the scale that turns sums into means."""
         m = self.model
         if self._pending != 0:          # head hook did not fire (e.g. frozen head): reduce it now
-            self._work.append(dist.all_reduce(m._grad[:m._n_head], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        if m._n_total > m._n_head:
-            self._work.append(dist.all_reduce(m._grad[m._n_head:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._reduce(0, m._n_head)
+            self._pending = 0
+        if self._buckets:
+            for i, (_, ranges) in enumerate(self._buckets):
+                if i not in self._sent:
+                    self._sent.add(i)
+                    for a, b in ranges:
+                        self._reduce(a, b)
+        elif m._n_total > m._n_head:
+            self._reduce(m._n_head, m._n_total)
         for w in self._work:
             w.wait()
         self._work = []

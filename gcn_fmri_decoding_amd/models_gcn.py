@@ -62,6 +62,7 @@ class base_model(object):
         self._specs = None              # filled during the build pass
         self._params = {}
         self._dp = None                 # optional data-parallel helper (dist.DataParallel)
+        self.record_fit = False         # keep the sampled indices and the loss_average series of fit()
 
     # ---------------------------------------------------------------- run-time API
 
@@ -126,7 +127,6 @@ class base_model(object):
         import sklearn.metrics
         if not isTrain:
             self._restore_latest()
-        t_process, t_wall = time.process_time(), time.time()
         labels = np.asarray(labels)
         predictions, loss = self.predict(data, labels, sess)
         if target_name is not None:
@@ -142,8 +142,8 @@ class base_model(object):
         f1 = 100 * sklearn.metrics.f1_score(labels, predictions, average='weighted')
         string = 'accuracy: {:.2f} ({:d} / {:d}), f1 (weighted): {:.2f}, loss: {:.2e}'.format(
             accuracy, ncorrects, len(labels), f1, loss)
-        if sess is None:
-            string += '\ntime: {:.0f}s (wall {:.0f}s)'.format(time.process_time() - t_process, time.time() - t_wall)
+        # (the reference appends a 'time:' line only ``if sess is None``, which never holds there:
+        # its local ``sess`` comes out of ``_get_session`` and is always a session, :88, :107-109)
         return string, accuracy, f1, loss
 
     def fit(self, train_data, train_labels, val_data, val_labels, best_checkpoint_dir=None):
@@ -152,14 +152,21 @@ class base_model(object):
         validation set every ``eval_frequency`` steps, top-3 checkpoints by validation
         accuracy.  Returns (accuracies, losses, t_step)."""
         t_process, t_wall = time.process_time(), time.time()
-        shutil.rmtree(self._get_path('checkpoints'), ignore_errors=True)
-        os.makedirs(self._get_path('checkpoints'), exist_ok=True)
+        # data parallel (dist.DataParallel): rank 0 owns the checkpoint directory, and every rank
+        # restarts from rank 0's freshly drawn variables (the reference re-runs op_init here, :123)
+        rank0 = self._dp is None or self._dp.rank == 0
+        if rank0:
+            shutil.rmtree(self._get_path('checkpoints'), ignore_errors=True)
+            os.makedirs(self._get_path('checkpoints'), exist_ok=True)
         self._init_variables()
+        if self._dp is not None:
+            self._dp.broadcast_parameters()
         train_dev, val_dev = self.stage(train_data), self.stage(val_data)
         train_labels = np.asarray(train_labels)
         labels_dev = torch.as_tensor(train_labels.astype(np.int64)).to(self.device)
         accuracies, losses = [], []
         best = []
+        self.fit_log = {'idx': [], 'loss_average': []}     # filled when ``record_fit`` is set (tests)
         indices = collections.deque()
         n_train = train_dev.shape[0]
         num_steps = int(self.num_epochs * n_train / self.batch_size)
@@ -172,6 +179,9 @@ class base_model(object):
             idx_dev = torch.as_tensor(np.asarray(idx, np.int32)).to(self.device)
             x = self._gather(train_dev, idx_dev)
             learning_rate, loss_average = self.train_step(x, labels_dev[idx_dev.long()])
+            if self.record_fit:
+                self.fit_log['idx'].append(np.asarray(idx))
+                self.fit_log['loss_average'].append(loss_average)
             if step % self.eval_frequency == 0 or step == num_steps:
                 loss_average = float(loss_average)
                 if np.isnan(loss_average) or np.isinf(loss_average):
@@ -179,16 +189,27 @@ class base_model(object):
                 epoch = step * self.batch_size / n_train
                 print('step {} / {} (epoch {:.2f} / {}):'.format(step, num_steps, epoch, self.num_epochs))
                 print('  learning_rate = {:.2e}, loss_average = {:.2e}'.format(learning_rate, loss_average))
-                string, accuracy, f1, loss = self.evaluate(val_dev, val_labels, self.sess, isTrain=True)
+                # a session is passed, as in the reference (:157): evaluate() then leaves its own time line out
+                string, accuracy, f1, loss = self.evaluate(val_dev, val_labels, self._session(), isTrain=True)
                 accuracies.append(accuracy)
                 losses.append(loss)
                 print('  validation {}'.format(string))
                 print('  time: {:.0f}s (wall {:.0f}s)'.format(time.process_time() - t_process, time.time() - t_wall))
-                self._save_best(accuracy, step, best)
+                if rank0:
+                    self._save_best(accuracy, step, best)
+                if self._dp is not None:
+                    self._dp.barrier()          # checkpoint files are complete before any rank restores
         print('validation accuracy: peak = {:.2f}, mean = {:.2f}'.format(max(accuracies), np.mean(accuracies[-10:])))
         torch.cuda.synchronize(self.device)
+        if self.record_fit:
+            self.fit_log['loss_average'] = [float(v) for v in self.fit_log['loss_average']]
         t_step = (time.time() - t_wall) / num_steps
         return accuracies, losses, t_step
+
+    def _session(self):
+        """Stand-in for the ``tf.Session`` the reference hands around (``sess`` arguments): there is
+        no session here, callers only test it against None."""
+        return self.sess if self.sess is not None else self
 
     def get_var(self, name):
         """Value of a variable by its TF name, in the reference's shape (:186-191)."""
@@ -357,48 +378,104 @@ class base_model(object):
         root = os.environ.get('CHEBGCN_HOME', os.getcwd())
         return os.path.join(root, folder, self.dir_name)
 
+    def _ref_view(self, flat, name):
+        """The slice of a flat buffer (variables, Adam moments) that belongs to ``name``, viewed in
+        the reference's variable shape."""
+        a, b = self._slices[name]
+        spec = next(s for s in self._spec_list if s.name == name)
+        t = flat[a:b].view(spec.shape)
+        if spec.group == 'convb':
+            return t[:, :spec.ref_shape[1]].t().unsqueeze(0) if len(spec.shape) == 2 else t.view(spec.ref_shape)
+        return t
+
     def state_dict(self):
-        return {'flat': self._flat.detach().cpu(), 'adam_m': self._adam_m.cpu(), 'adam_v': self._adam_v.cpu(),
-                'global_step': self.global_step, 'names': self.variables()}
+        """Checkpoint contents, keyed by the reference's variable names and in its shapes
+        (``conv1/weights`` [Fin*K, Fout], ``conv1/bias`` [1, M, F] ...), the Adam moments under
+        ``adam_m/<name>`` / ``adam_v/<name>`` (TF: ``<name>/Adam``, ``<name>/Adam_1``), and the step
+        counter.  Independent of the internal flat layout."""
+        sd = {'global_step': int(self.global_step), 'names': self.variables()}
+        arch = getattr(self, '_architecture', None)
+        if arch is not None:
+            sd['architecture'] = arch()
+        for name in self.variables():
+            sd[name] = self._ref_view(self._flat, name).detach().cpu().contiguous()
+            sd['adam_m/' + name] = self._ref_view(self._adam_m, name).cpu().contiguous()
+            sd['adam_v/' + name] = self._ref_view(self._adam_v, name).cpu().contiguous()
+        return sd
 
     def load_state_dict(self, sd):
+        """Restore by variable name; shapes are checked.  Optimizer state is optional (a file that
+        holds only variables -- e.g. converted from a TF checkpoint -- restores the weights)."""
+        missing = [n for n in self.variables() if n not in sd]
+        if missing:
+            raise KeyError('checkpoint lacks variables %s' % missing)
         with torch.no_grad():
-            self._flat.copy_(sd['flat'].to(self.device))
-            self._adam_m.copy_(sd['adam_m'].to(self.device))
-            self._adam_v.copy_(sd['adam_v'].to(self.device))
-        self.global_step = int(sd['global_step'])
+            for name in self.variables():
+                for prefix, flat in (('', self._flat), ('adam_m/', self._adam_m), ('adam_v/', self._adam_v)):
+                    if prefix + name not in sd:
+                        continue
+                    dst = self._ref_view(flat, name)
+                    src = torch.as_tensor(np.asarray(sd[prefix + name], np.float32))
+                    if tuple(src.shape) != tuple(dst.shape):
+                        raise ValueError('checkpoint variable %s%s has shape %s, the model wants %s'
+                                         % (prefix, name, tuple(src.shape), tuple(dst.shape)))
+                    dst.copy_(src.to(self.device))
+        self.global_step = int(sd.get('global_step', 0))
 
     def _save_best(self, accuracy, step, best, num_to_keep=3):
-        """Keep the ``num_to_keep`` best checkpoints by validation accuracy, with the policy and
-        the on-disk index of checkmat.BestCheckpointSaver (checkmat.py:8-118, used at
-        models_gcn.py:127, 175): a JSON file ``best_checkpoints`` mapping ``best.ckpt-<step>`` to
-        its value; a new value replaces the worst kept one unless every kept value is >= it.  The
-        weights themselves are a torch file ``best.ckpt-<step>.pt`` (variable names and shapes as
-        in the reference), found by ``get_best_checkpoint``."""
+        """checkmat.BestCheckpointSaver.handle (checkmat.py:43-84, used at models_gcn.py:127, 175):
+        keep the ``num_to_keep`` best checkpoints by validation accuracy.  On disk, in
+        ``checkpoints/<dir_name>/model``: the JSON index ``best_checkpoints`` mapping
+        ``best.ckpt-<step>`` to its value; the text file ``checkpoint`` in tf.train.Saver's format
+        (``model_checkpoint_path`` = last one saved, then one ``all_model_checkpoint_paths`` line
+        per kept checkpoint in the saver's order: survivors best first, then the new one,
+        checkmat.py:70-84) -- the reference's readers parse both (models_gcn.py:89-90, 968-969);
+        the weights as a torch file ``best.ckpt-<step>.pt`` holding ``state_dict()`` (variables
+        by their reference names and shapes, Adam moments, step, architecture).
+        ``best`` is the saver's ordered list of kept checkpoint names (state between calls)."""
         path = os.path.join(self._get_path('checkpoints'), 'model')
         os.makedirs(path, exist_ok=True)
-        if len(best) >= num_to_keep and all(a >= accuracy for a, _ in best):
-            return
-        fname = os.path.join(path, 'best.ckpt-%d.pt' % step)
-        torch.save(self.state_dict(), fname)
-        best.append((accuracy, fname))
-        best.sort(key=lambda t: -t[0])
-        for _, old in best[num_to_keep:]:
-            if os.path.exists(old):
-                os.remove(old)
-        del best[num_to_keep:]
-        with open(os.path.join(path, 'best_checkpoints'), 'w') as f:
-            json.dump({os.path.basename(p)[:-3]: float(a) for a, p in best}, f, indent=3)
+        index = os.path.join(path, 'best_checkpoints')
+        current, value = 'best.ckpt-%d' % step, float(accuracy)
+        if not os.path.exists(index):
+            table = {current: value}
+        else:
+            with open(index) as f:
+                table = json.load(f)
+            if len(table) < num_to_keep:
+                table[current] = value
+            elif not all(v >= value for v in table.values()):
+                ranked = sorted(table, key=table.get, reverse=True)          # stable, like the reference's
+                worst = ranked.pop(-1)
+                for fname in (os.path.join(path, 'checkpoint'), os.path.join(path, worst + '.pt')):
+                    if os.path.exists(fname):
+                        os.remove(fname)
+                best[:] = ranked
+                table = {k: table[k] for k in ranked}
+                table[current] = value
+            else:
+                return
+        with open(index, 'w') as f:
+            json.dump(table, f, indent=3)
+        torch.save(self.state_dict(), os.path.join(path, current + '.pt'))
+        if current in best:
+            best.remove(current)
+        best.append(current)
+        with open(os.path.join(path, 'checkpoint'), 'w') as f:
+            f.write('model_checkpoint_path: "%s"\n' % current)
+            for name in best:
+                f.write('all_model_checkpoint_paths: "%s"\n' % name)
 
     def _restore_latest(self):
+        """``saver.restore(sess, tf.train.latest_checkpoint(...))`` (:89-90, :326-327): the last
+        checkpoint the saver wrote, named by the first line of the ``checkpoint`` file."""
         path = os.path.join(self._get_path('checkpoints'), 'model')
-        if not os.path.isdir(path):
+        state = os.path.join(path, 'checkpoint')
+        if not os.path.exists(state):
             return
-        files = [f for f in os.listdir(path) if f.endswith('.pt')]
-        if not files:
-            return
-        latest = max(files, key=lambda f: int(f.split('-')[-1].split('.')[0]))
-        self.load_state_dict(torch.load(os.path.join(path, latest)))
+        with open(state) as f:
+            latest = f.readline().rstrip('\n').replace('"', '').split(' ')[-1].split('/')[-1]
+        self.load_state_dict(torch.load(os.path.join(path, latest + '.pt'), weights_only=True))
 
     @contextlib.contextmanager
     def variable_scope(self, name):
@@ -488,7 +565,40 @@ class cgcnn(base_model):
         self.initial = initial
         self.channel = channel
         self.graphs = [ops.graph_for(Li, self.device) for Li in self.L] if self.device.type == 'cuda' else []
+        self._ctor = dict(L=list(L), F=list(F), K=list(K), p=list(p), M=list(M), filter=filter, brelu=brelu, pool=pool,
+                          initial=initial, channel=channel, num_epochs=num_epochs, learning_rate=learning_rate,
+                          decay_rate=decay_rate, decay_steps=decay_steps, momentum=momentum,
+                          regularization=regularization, dropout=dropout, batch_size=batch_size,
+                          eval_frequency=eval_frequency, dir_name=dir_name)
         self.build_graph((M_0, channel))
+
+    def _architecture(self):
+        """What a checkpoint needs to rebuild this model without the script that made it (the
+        reference's checkpoints carry a TF meta-graph for the same purpose, :775-776, :979):
+        the constructor arguments, the Laplacians as CSR arrays."""
+        import scipy.sparse as sp
+        arch = {k: v for k, v in self._ctor.items() if k != 'L'}
+        arch = {k: ([int(x) if float(x).is_integer() else float(x) for x in v] if isinstance(v, list) else v)
+                for k, v in arch.items()}
+        arch['L'] = []
+        for Li in self._ctor['L']:
+            Li = sp.csr_matrix(Li)
+            arch['L'].append({'indptr': torch.as_tensor(Li.indptr.astype(np.int64)),
+                              'indices': torch.as_tensor(Li.indices.astype(np.int64)),
+                              'data': torch.as_tensor(np.asarray(Li.data)), 'shape': [int(Li.shape[0]), int(Li.shape[1])]})
+        return arch
+
+    @classmethod
+    def from_checkpoint(cls, sd, config=None, **overrides):
+        """Rebuild the model a checkpoint (``state_dict()``) describes and load its variables."""
+        import scipy.sparse as sp
+        arch = dict(sd['architecture'])
+        Ls = [sp.csr_matrix((np.asarray(l['data']), np.asarray(l['indices']), np.asarray(l['indptr'])), shape=tuple(l['shape']))
+              for l in arch.pop('L')]
+        arch.update(overrides)
+        model = cls(config, Ls, verbose=False, **arch)
+        model.load_state_dict(sd)
+        return model
 
     def _describe(self, M_0, F, K, p, M, brelu):
         L = self.L
@@ -616,10 +726,11 @@ class cgcnn(base_model):
                 out = next_stack[0]
             # training: the layer's gradients go straight into the flat (zeroed) gradient buffer
             direct = self.training_mode and W.grad is not None and b.grad is not None and torch.is_grad_enabled()
+            done = (lambda layer=i + 1: self._dp.layer_done(layer)) if (direct and self._dp is not None) else None
             x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
                               BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out,
                               dW=W.grad if direct else None, dbias=b.grad if direct else None,
-                              precision=self.contraction)
+                              precision=self.contraction, done=done)
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
         return self._head(ops.FeatureMean.apply(x, M_last), dropout)
@@ -629,8 +740,8 @@ class cgcnn(base_model):
         for i, Mi in enumerate(self.M[:-1]):
             with self.variable_scope('fc{}'.format(i + 1)):
                 x = self.fc(x, Mi)
-                if not x.is_meta and self.training_mode and dropout != 1:
-                    x = Fnn.dropout(x, p=1.0 - float(dropout), training=True)   # tf.nn.dropout(x, keep_prob)
+                if not x.is_meta and dropout != 1:
+                    x = Fnn.dropout(x, p=1.0 - float(dropout), training=True)   # tf.nn.dropout(x, keep_prob), :677
         with self.variable_scope('logits'):
             x = self.fc(x, self.M[-1], relu=False)
         return x
@@ -669,3 +780,102 @@ class model_perf(object):
         print('\ntest  {}\n'.format(string))
         s.names.add(name)
         return s
+
+    def predict(s, ckp_path, test_data, test_labels, target_name=None, batch_size=128, trial_dura=17,
+                flag_starttr=False, sub_name=None, model=None, config=None):
+        """Restore a trained model from ``<ckp_path>/model/`` and score a dataset (:960-1088; call
+        site predict_states.py:102-108).  Like the reference it takes the checkpoint named on line 1
+        of the saver's ``checkpoint`` file (:968-969), pads the last batch with zeros, SUMS the batch
+        losses, and flattens the stacked logits before truncating them (:1022-1023).  The model is
+        rebuilt from the checkpoint's architecture record (the reference imports the TF meta-graph,
+        :979), or ``model`` is used.  Returns (pred_logits, pred_labels, pred_loss, test_acc)."""
+        import sklearn.metrics
+        ckp_path = str(ckp_path) + '/' + 'model/'
+        lines = [line.rstrip('\n') for line in open(os.path.join(ckp_path, 'checkpoint'))]
+        model_name = lines[1].replace('"', '').split(' ')[-1].split('/')[-1]
+        print(ckp_path + model_name + '.pt')
+        sd = torch.load(ckp_path + model_name + '.pt', weights_only=True)
+        if model is None:
+            model = cgcnn.from_checkpoint(sd, config=config, batch_size=batch_size)
+        else:
+            model.load_state_dict(sd)
+        test_labels = np.asarray(test_labels)
+        data_dev = model.stage(test_data)
+        data_size = data_dev.shape[0]
+        pred_logits, pred_labels, pred_loss = [], [], 0
+        model.training_mode = False
+        for begin in range(0, data_size, batch_size):
+            end = min([begin + batch_size, data_size])
+            idx = torch.arange(begin, end, dtype=torch.int32, device=model.device)
+            x = model._gather(data_dev, idx)
+            if end - begin < batch_size:
+                pad = ops.plane_empty(batch_size, x.shape[1], data_dev.shape[1], model.device, zero=True)
+                pad[:end - begin] = x
+                x = pad
+            batch_labels = np.zeros(batch_size, np.int64)
+            batch_labels[:end - begin] = test_labels[begin:end]
+            with torch.no_grad():
+                logits = model._inference_storage(x, 1)
+                loss = model.loss(logits, torch.as_tensor(batch_labels).to(model.device), model.regularization)[0]
+            pred_logits.append(logits.cpu().numpy())
+            pred_labels.append(model.prediction(logits).cpu().numpy())
+            pred_loss += float(loss)
+        pred_labels = np.stack(pred_labels, axis=0).flatten()[:len(test_labels)]
+        pred_logits = np.stack(pred_logits, axis=0).flatten()[:len(test_labels)]
+        if target_name is not None:
+            print(sklearn.metrics.classification_report(test_labels, pred_labels, labels=range(len(target_name)),
+                                                        target_names=target_name))
+            print('Confusion Matrix:')
+            print(sklearn.metrics.confusion_matrix(test_labels, pred_labels, labels=range(len(target_name))))
+        test_acc = []
+        ncorrects = int(sum(pred_labels == test_labels))
+        accuracy = 100 * sklearn.metrics.accuracy_score(test_labels, pred_labels)
+        f1 = 100 * sklearn.metrics.f1_score(test_labels, pred_labels, average='weighted')
+        print('accuracy: {:.2f} ({:d} / {:d}), f1 (weighted): {:.2f}, loss: {:.2e}'.format(
+            accuracy, ncorrects, len(test_labels), f1, pred_loss))
+        test_acc.append(accuracy)
+        if sub_name is not None:
+            # per-subject weighted F1 per condition and overall (:1040-1064), written like the reference
+            import pandas as pd
+            try:
+                y_pred = np.array(np.split(pred_labels, len(sub_name)))
+                y_label = np.array(np.split(test_labels, len(sub_name)))
+            except ValueError:
+                sub_used = pred_labels.shape[0] // len(sub_name) * len(sub_name)
+                y_pred = np.array(np.split(pred_labels[:sub_used], len(sub_name)))
+                y_label = np.array(np.split(test_labels[:sub_used], len(sub_name)))
+            test_acc = np.zeros((len(sub_name), len(target_name) + 1))
+            for subi in range(len(sub_name)):
+                for li in range(len(target_name)):
+                    mask = y_label[subi, :] == li
+                    test_acc[subi, li] = sklearn.metrics.f1_score(y_label[subi, mask], y_pred[subi, mask], average='weighted')
+                test_acc[subi, -1] = sklearn.metrics.f1_score(y_label[subi, :], y_pred[subi, :], average='weighted')
+            result_df = pd.DataFrame()
+            result_df['subject'] = sub_name
+            for li, task in enumerate(target_name):
+                result_df[task] = test_acc[:, li]
+            result_df['avg'] = test_acc[:, -1]
+            os.makedirs('train_logs', exist_ok=True)
+            result_df.to_csv('train_logs/' + target_name[0].split('_')[-1] + '_f1score_testacc_' + str(len(sub_name)) +
+                             'subjects.csv', sep='\t', encoding='utf-8', index=False)
+        if flag_starttr:
+            # accuracy as a function of the window's position inside its trial (:1066-1087)
+            y_pred = np.reshape(pred_labels, (-1, trial_dura))
+            y_label = np.reshape(test_labels, (-1, trial_dura))
+            test_acc = np.zeros((len(target_name), trial_dura))
+            for li in range(len(target_name)):
+                print('\n', target_name[li], ':')
+                for ti in range(trial_dura):
+                    mask = y_label[:, ti] == li
+                    nc = int(sum(y_pred[mask, ti] == y_label[mask, ti]))
+                    acc = 100 * sklearn.metrics.accuracy_score(y_label[mask, ti], y_pred[mask, ti])
+                    f1 = 100 * sklearn.metrics.f1_score(y_label[mask, ti], y_pred[mask, ti], average='weighted')
+                    print('start_tr {:d} accuracy: {:.2f} ({:d} / {:d}), f1 (weighted): {:.2f}'.format(ti, acc, nc, int(np.sum(mask)), f1))
+                    test_acc[li, ti] = acc
+            print('\ntotal:')
+            for ti in range(trial_dura):
+                nc = int(sum(y_pred[:, ti] == y_label[:, ti]))
+                acc = 100 * sklearn.metrics.accuracy_score(y_label[:, ti], y_pred[:, ti])
+                f1 = 100 * sklearn.metrics.f1_score(y_label[:, ti], y_pred[:, ti], average='weighted')
+                print('start_tr {:d} accuracy: {:.2f} ({:d} / {:d}), f1 (weighted): {:.2f}'.format(ti, acc, nc, len(y_pred), f1))
+        return pred_logits, pred_labels, pred_loss, test_acc

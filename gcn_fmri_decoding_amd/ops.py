@@ -326,6 +326,7 @@ class ChebConv(torch.autograd.Function):
         ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
+        ctx.done = bufs.done if bufs is not None else None
         return out
 
     @staticmethod
@@ -342,7 +343,7 @@ class ChebConv(torch.autograd.Function):
         if bias_kind != BIAS_NONE and ctx.needs_input_grad[2]:
             if dbias_buf is not None:
                 _check_grad_buffer(dbias_buf, ctx.bias_shape, 'dbias')
-                dbias = dbias_buf                 # zeroed by the owner; the kernel accumulates
+                dbias = dbias_buf                 # overwritten, like dW: one use per step
             else:
                 dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
         Mo = M // pool
@@ -385,6 +386,8 @@ class ChebConv(torch.autograd.Function):
             # joined before this layer's buffers (stack, dy, workspace) can be reused and before
             # anything consumes dW
             torch.cuda.current_stream(dev).wait_stream(side)
+        if ctx.done is not None:
+            ctx.done()                            # e.g. dist.DataParallel.layer_done: this layer's gradients are enqueued
         # gradients written into the caller's buffers are not handed to autograd a second time
         return (dx, None if dW_buf is not None else dW, None if dbias_buf is not None else dbias,
                 None, None, None, None, None, None, None)
@@ -392,22 +395,24 @@ class ChebConv(torch.autograd.Function):
 
 class Buffers:
     """Preallocated buffers for ``cheb_conv`` (plain object, not a tensor).  ``stack`` / ``out``:
-    see ChebConv.  ``dW`` / ``dbias``: gradient buffers the backward pass ACCUMULATES into in place
-    of returning the gradients to autograd -- the model hands over views of its flat, zeroed
-    gradient buffer and saves an add (and a zero fill) per variable and step."""
-    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision')
+    see ChebConv.  ``dW`` / ``dbias``: gradient buffers the backward pass WRITES (overwrites, it
+    does not accumulate: one use of a variable per step) in place of returning the gradients to
+    autograd -- the model hands over views of its flat gradient buffer and saves an add per
+    variable and step.  ``done``: called at the end of the layer's backward, once its gradient
+    kernels are enqueued (dist.DataParallel starts the layer's all-reduce from it)."""
+    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done')
 
-    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32'):
-        self.stack, self.out, self.dW, self.dbias, self.precision = stack, out, dW, dbias, precision
+    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None):
+        self.stack, self.out, self.dW, self.dbias, self.precision, self.done = stack, out, dW, dbias, precision, done
 
 
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
-              dW=None, dbias=None, precision='f32'):
+              dW=None, dbias=None, precision='f32', done=None):
     """``precision``: arithmetic of the forward contraction ('f32', 'bf16', 'bf16x3'); the
     recurrence and every gradient stay fp32."""
     bufs = None
-    if stack is not None or out is not None or dW is not None or dbias is not None or precision != 'f32':
-        bufs = Buffers(stack, out, dW, dbias, precision)
+    if stack is not None or out is not None or dW is not None or dbias is not None or precision != 'f32' or done is not None:
+        bufs = Buffers(stack, out, dW, dbias, precision, done)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 

@@ -19,6 +19,10 @@ What it is: a NumPy/SciPy restatement of the algorithm of
                         b2relu, mpool1, apool1, fc, _inference), ``:253-276``
                         (loss), ``:278-313`` (Adam step, TF form) with an
                         explicit hand-derived backward pass.
+* ``loop_ref``       -- ``lib_new/models_gcn.py:31-184`` (predict / evaluate /
+                        fit: the callers of the path) around ``layers_ref.Net``.
+* ``torch_cpu_ref``  -- the same network on torch CPU tensors (all host cores);
+                        exists only as the timed CPU baseline B2 of bench.py.
 
 Parity pinning (DESIGN.md "Oracle"):
 * ``graph_ref`` and ``coarsening_ref`` are pinned against the reference's own

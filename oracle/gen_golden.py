@@ -331,6 +331,13 @@ def main():
     run_inference('inference_config1_n512', L512[:1], F=[32], K=[1], p=[1],
                   Mfc=[512, 256, 22], channel=1, brelu='b2relu', N=4)
 
+    # the pooling ChebNet of the legacy monolith (HCP_task_fmri_gcn_test8.py:1633-1636, 2071):
+    # six coarsening levels, p = [1,4,1,4,1,4], K = [20,10,10,10,5,5], F = [32,32,64,64,128,128], b2relu
+    g512_6, _ = _quiet(_with_stable, rcoarse, lambda: rcoarse.coarsen(A512, 6, False))
+    L512_6 = [rgraph.laplacian(G, normalized=True) for G in g512_6]
+    run_inference('inference_pool6_n512', L512_6, F=[32, 32, 64, 64, 128, 128], K=[20, 10, 10, 10, 5, 5],
+                  p=[1, 4, 1, 4, 1, 4], Mfc=[64, 22], channel=3, brelu='b2relu', N=2)
+
     # -------------------------------------------- the N=10000 bench graph
     if args.big:
         z, d, idx, A = knn_graph(10000, 8, 0, np.float32)

@@ -79,7 +79,7 @@ def test_cpu_tensor_is_rejected():
             models_gcn.cgcnn(None, [sp.identity(8, format='csr')], [2], [2], [1], [3], verbose=False)
 
 
-@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512'])
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512', 'inference_pool6_n512'])
 def test_variable_layout_matches_reference(name):
     """Shape-only build (device='meta'): variable names and TF shapes equal the reference's
     (golden 'param:*' entries come from the reference's own _inference run)."""
@@ -139,3 +139,9 @@ def test_best_checkpoint_policy_matches_checkmat(tmp_path):
     assert index == {'best.ckpt-50': 0.6, 'best.ckpt-20': 0.5, 'best.ckpt-70': 0.5}
     assert sorted(f for f in os.listdir(path) if f.endswith('.pt')) == ['best.ckpt-20.pt', 'best.ckpt-50.pt', 'best.ckpt-70.pt']
     assert M.get_best_checkpoint(path) == os.path.join(path, 'best.ckpt-50')
+    # tf.train.Saver's state file as checkmat leaves it (checkmat.py:70-84): last save first, then the
+    # survivors best-first followed by the new checkpoint; models_gcn.py:968-969 reads line 1
+    assert open(os.path.join(path, 'checkpoint')).read().splitlines() == [
+        'model_checkpoint_path: "best.ckpt-70"', 'all_model_checkpoint_paths: "best.ckpt-50"',
+        'all_model_checkpoint_paths: "best.ckpt-20"', 'all_model_checkpoint_paths: "best.ckpt-70"']
+    assert best == ['best.ckpt-50', 'best.ckpt-20', 'best.ckpt-70']

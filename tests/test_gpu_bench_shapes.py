@@ -1,0 +1,315 @@
+"""Parity of the kernel instantiations the BENCHMARK runs -- the shapes of BASELINE.json
+configs[1] and configs[3] on the full-size graph (M = 10466) -- against the CPU oracle,
+through the C ABI.  Needs an MI355X: ``-m gpu``.
+
+The layer tests of test_gpu_parity.py run on the N = 212 fixture graphs, where the
+dispatchers pick other template instantiations (Fin*K <= 75 there).  Here every case names
+the kernels it reaches:
+
+=====================================  =========================================================
+case                                   instantiations (contract.hip / pointwise.hip / recurrence.hip)
+=====================================  =========================================================
+layer 32 -> 32, K=5, b2relu (config 2) contract_fwd<1> over 21 column blocks, bwd_x<HOLD>,
+                                       bwd_w<RT=5>, brelu_pool_bwd<VERTEX, PARTS=1>, on-chip
+                                       recurrence forward + adjoint at the bench shape
+layer 15 -> 32 (first layer)           bwd_w<RT=3>, no dx
+layer 64 -> 64, K=25 (config 4)        contract_fwd<2>, bwd_x<!HOLD>, bwd_w<RT=5> with gy = 10
+RT sweep on the N=212 graph            bwd_w<RT=1..5> and gy = 2, value comparison
+PARTS sweep                            brelu_pool_bwd PARTS = 1 / 4 / 8 for all three bias kinds
+6-layer configs[1] net, B = 2          everything above in sequence: logits, loss, 3 Adam steps
+=====================================  =========================================================
+
+Tolerance: max|hip - ref| <= 1e-5 * max|ref| forward (north star: 1e-5 relative fp32);
+2e-5 for gradients (two chained fp32 reductions of up to B*M = 2e4 terms), stated per assert.
+The oracle's backward has no runnable reference counterpart (TF autodiff): it is checked
+against torch.autograd in float64 by tests/test_oracle_layers.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import csr_from, load_golden
+from oracle import layers_ref as R
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+GREL = 2e-5
+
+
+def close(got, ref, rel=REL, what=''):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(got - ref).max() / scale
+    assert err <= rel, '%s: rel err %.3e > %.1e' % (what, err, rel)
+    return err
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gcn_fmri_decoding_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope='module')
+def bench_graph():
+    """The N=10000 benchmark graph (levels = 1): built by the product's host code, which
+    tests/test_host_golden.py pins bit-exactly to the reference's output."""
+    import bench
+    Ls, perm = bench.load_graph(10000, 1, 0, 1, None)
+    assert Ls[0].shape[0] == 10466
+    return Ls[0]
+
+
+def to_storage(ops, x_bmf, dev):
+    B, M, F = x_bmf.shape
+    st = torch.full((B, F, ops.plane_stride(M)), float('nan'), device=dev)
+    st[:, :, :M] = torch.as_tensor(np.ascontiguousarray(x_bmf.transpose(0, 2, 1))).to(dev)
+    return st
+
+
+def from_storage(st, M):
+    return st[:, :, :M].permute(0, 2, 1).cpu().numpy()
+
+
+def run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3):
+    """One conv layer forward + backward, HIP against oracle.  Returns the error dict."""
+    M = L.shape[0]
+    g = ops.graph_for(L, dev)
+    rs = np.random.RandomState(seed)
+    x = rs.randn(B, M, Fin).astype(np.float32)
+    W = (rs.randn(Fin * K, Fout) * wscale / np.sqrt(Fin * K / 15.0)).astype(np.float32)
+    if bias == 1:
+        b = (rs.randn(1, 1, Fout) * 0.5).astype(np.float32)
+    elif bias == 2:
+        b = (rs.randn(1, M, Fout) * 0.5).astype(np.float32)
+    else:
+        b = np.zeros((1, 1, Fout), np.float32)
+    relu = bias != 0
+    y, T = R.chebyshev5_fwd(x, L, W, K, return_stack=True)
+    a = R.brelu_fwd(y, b) if relu else y + b
+    if pool_kind == 0:
+        o, arg = R.mpool1_fwd(a, p)
+    else:
+        o, arg = R.apool1_fwd(a, p), None
+    do = rs.randn(*o.shape).astype(np.float32)
+    da = R.mpool1_bwd(do, arg, p, M) if pool_kind == 0 else (np.repeat(do, p, axis=1) / p if p > 1 else do)
+    if relu:
+        dy, db = R.brelu_bwd(da, a, b.shape)
+    else:
+        dy, db = da, None
+    dx_ref, dW_ref = R.chebyshev5_bwd(dy.astype(np.float32), L, W, K, T, need_dx=need_dx)
+
+    xs = to_storage(ops, x, dev).requires_grad_(need_dx)
+    Wd = torch.as_tensor(W).to(dev).requires_grad_(True)
+    if bias == 1:
+        bd = torch.as_tensor(b.reshape(-1)).to(dev).requires_grad_(True)
+        kind = ops.BIAS_FILTER
+    elif bias == 2:
+        bd = torch.zeros((Fout, g.Mp), device=dev)
+        bd[:, :M] = torch.as_tensor(b[0].T.copy()).to(dev)
+        bd.requires_grad_(True)
+        kind = ops.BIAS_VERTEX
+    else:
+        bd, kind = None, ops.BIAS_NONE
+    out = ops.cheb_conv(xs, Wd, bd, g, K, pool=p, pool_kind=pool_kind, relu=relu, bias_kind=kind)
+    errs = {'out': close(from_storage(out.detach(), M // p), o, what='out')}
+    gout = torch.full(out.shape, float('nan'), device=dev)
+    gout[:, :, :M // p] = torch.as_tensor(np.ascontiguousarray(do.transpose(0, 2, 1))).to(dev)
+    out.backward(gout)
+    if need_dx:
+        errs['dx'] = close(from_storage(xs.grad, M), dx_ref, what='dx', rel=GREL)
+    else:
+        assert xs.grad is None
+    errs['dW'] = close(Wd.grad.cpu().numpy(), dW_ref, what='dW', rel=GREL)
+    if bias == 1:
+        errs['db'] = close(bd.grad.cpu().numpy(), db.reshape(-1), what='db1', rel=GREL)
+    elif bias == 2:
+        errs['db'] = close(bd.grad[:, :M].t().cpu().numpy(), db[0], what='db2', rel=GREL)
+        assert float(bd.grad[:, M:].abs().sum()) == 0.0
+    return errs
+
+
+# ---------------------------------------------------------------------------------------
+# single layers at M = 10466
+# ---------------------------------------------------------------------------------------
+
+def test_config2_layer_32_32_k5(ops, dev, bench_graph):
+    """Layers 2-6 of configs[1]: Fin = Fout = 32, K = 5, b2relu, no pooling."""
+    errs = run_layer(ops, dev, bench_graph, B=3, Fin=32, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=1)
+    print('config2 layer errors', errs)
+
+
+def test_config2_first_layer_15_32_k5(ops, dev, bench_graph):
+    """Layer 1 of configs[1]: block_dura = 15 input features, no gradient wrt the input."""
+    run_layer(ops, dev, bench_graph, B=2, Fin=15, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=2, need_dx=False)
+
+
+def test_config4_layer_64_64_k25(ops, dev, bench_graph):
+    """configs[3]: K = 25, Fin = Fout = 64 -- Fin*K = 1600 (50 row tiles -> gy = 10 in bwd_w),
+    Fout = 64 (two filter tiles in contract_fwd, dy streamed instead of held in bwd_x)."""
+    run_layer(ops, dev, bench_graph, B=1, Fin=64, Fout=64, K=25, p=1, pool_kind=0, bias=2, seed=3)
+
+
+def test_pooled_layer_full_size(ops, dev, bench_graph):
+    """p = 2 on the full-size graph with per-filter biases (brelu_pool_bwd<FILTER>, argmax path)."""
+    run_layer(ops, dev, bench_graph, B=2, Fin=4, Fout=32, K=3, p=2, pool_kind=0, bias=1, seed=4)
+
+
+# ---------------------------------------------------------------------------------------
+# dispatcher sweeps on the small fixture graph (cheap), value comparisons
+# ---------------------------------------------------------------------------------------
+
+def levels(name='layers_n212'):
+    z = load_golden(name)
+    return [csr_from(z, 'L%d' % i) for i in range(4)]
+
+
+@pytest.mark.parametrize('Fin,K,rt,gy', [(4, 5, 1, 1), (8, 5, 2, 1), (13, 7, 3, 1), (32, 4, 4, 1), (32, 5, 5, 1),
+                                          (11, 17, 5, 2), (64, 25, 5, 10)])
+def test_bwd_w_row_tile_sweep(ops, dev, Fin, K, rt, gy):
+    """contract_bwd_w_kernel<RT> for RT = 1..5 and several row-tile groups (gy > 1)."""
+    ntiles = (Fin * K + 31) // 32
+    assert min(ntiles, 5) == rt and (ntiles + rt - 1) // rt == gy      # the dispatcher's arithmetic (contract.hip bw_rt)
+    run_layer(ops, dev, levels()[0], B=2, Fin=Fin, Fout=40, K=K, p=1, pool_kind=0, bias=2, seed=Fin + K)
+
+
+@pytest.mark.parametrize('lvl,F,parts', [(0, 256, 4), (0, 24, 8), (2, 33, 8)])
+@pytest.mark.parametrize('bias', [0, 1, 2])
+def test_brelu_pool_bwd_parts_small_graph(ops, dev, lvl, F, parts, bias):
+    """brelu_pool_bwd_kernel<BIAS, PARTS> with PARTS = 4 / 8 (small graphs), all bias kinds, with
+    pooling.  (PARTS = 1 needs ceil(M/256)*F >= 1024: the M = 10466 tests above and below.)"""
+    L = levels()[lvl]
+    M = L.shape[0]
+    got = 1 if ((M + 255) // 256) * F >= 1024 else 4 if ((M + 63) // 64) * F >= 1024 else 8
+    assert got == parts                                                # the dispatcher's arithmetic (pointwise.hip)
+    run_layer(ops, dev, L, B=5, Fin=2, Fout=F, K=2, p=2, pool_kind=0, bias=bias, seed=F + bias)
+
+
+@pytest.mark.parametrize('bias,p,pool_kind', [(0, 1, 0), (1, 1, 0), (2, 4, 0), (2, 2, 1)])
+def test_brelu_pool_bwd_parts1_full_size(ops, dev, bench_graph, bias, p, pool_kind):
+    """PARTS = 1 (41 * 32 >= 1024 blocks) for the bias kinds / pooling forms not covered above."""
+    run_layer(ops, dev, bench_graph, B=2, Fin=3, Fout=32, K=2, p=p, pool_kind=pool_kind, bias=bias, seed=10 * bias + p)
+
+
+# ---------------------------------------------------------------------------------------
+# the whole configs[1] network at full size
+# ---------------------------------------------------------------------------------------
+
+def test_config2_network_b2_vs_oracle(ops, dev, bench_graph):
+    """BASELINE configs[1] (6 x [K=5, F=32, p=1, b2relu], FC 512-256-22, block_dura 15) with a
+    batch of 2 windows: logits, loss and three TF-form Adam steps against the oracle."""
+    from gcn_fmri_decoding_amd import models_gcn
+    L = bench_graph
+    M = L.shape[0]
+    F, K, p, Mfc, channel, B = [32] * 6, [5] * 6, [1] * 6, [512, 256, 22], 15, 2
+    reg = 5e-4
+    net = models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1',
+                           initial='he', channel=channel, regularization=reg, dropout=1, batch_size=B, verbose=False)
+    onet = R.Net([L], F, K, p, Mfc, channel=channel, brelu='b2relu', regularization=reg)
+    rs = np.random.RandomState(0)
+    params = {}
+    for k, s in onet.param_shapes().items():
+        params[k] = ((0.2 + 0.05 * rs.randn(*s)) if k.endswith('bias') else rs.randn(*s) * np.sqrt(2.0 / s[0])).astype(np.float32)
+        net.set_variable(k, params[k])
+    x = rs.randn(B, M, channel).astype(np.float32)
+    labels = np.array([3, 17])
+    xs = to_storage(ops, x, dev)
+    ld = torch.as_tensor(labels).to(dev)
+    with torch.no_grad():
+        logits = net._inference_storage(xs, 1).cpu().numpy()
+    ologits, _ = onet.forward(params, x)
+    close(logits, ologits, rel=GREL, what='logits')
+    state, ill = {}, {}
+    for step in range(3):
+        ologits, cache = onet.forward(params, x)
+        loss, dlogits = onet.loss(params, ologits, labels)
+        grads = onet.backward(params, cache, dlogits)
+        _, loss_avg = net.train_step(xs, ld)
+        if step == 0:
+            assert abs(float(loss_avg) - loss) <= GREL * abs(loss)
+            for k in params:
+                spec = next(s for s in net._spec_list if s.name == k)
+                gk = net._params[k].grad
+                if spec.group == 'convb':
+                    gk = gk[:, :spec.ref_shape[1]].t().unsqueeze(0)
+                ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
+                close(gk.cpu().numpy(), ref, rel=5e-5, what='grad ' + k)
+        R.adam_tf_step(params, grads, state)
+        for k in params:
+            # Adam moments are linear / quadratic in the gradient: tight bounds
+            a, b = net._slices[k]
+            spec = next(s for s in net._spec_list if s.name == k)
+
+            def ref_shape(flat):
+                t = flat[a:b].view(spec.shape)
+                return (t[:, :spec.ref_shape[1]].t().unsqueeze(0) if spec.group == 'convb' else t).cpu().numpy()
+            close(ref_shape(net._adam_m), state['m/' + k], rel=5e-5, what='step %d m %s' % (step, k))
+            close(ref_shape(net._adam_v), state['v/' + k], rel=1e-4, what='step %d v %s' % (step, k))
+            # The update lr_t * m / (sqrt(v) + eps) is ~ +-lr whenever the gradient RMS is >> eps and
+            # ill-conditioned where it is ~ eps = 1e-8 .. 1e-6 (there an fp32 round-off in g changes
+            # the quotient): 2e-5 on the well-conditioned elements (RMS gradient > 1e-5, or exactly
+            # zero), and nothing moves by more than one learning rate per step anywhere.
+            got, ref = net.get_var(k).astype(np.float64), params[k].astype(np.float64)
+            d = np.abs(got - ref)
+            scale = np.abs(ref).max()
+            rms = np.sqrt(state['v/' + k].astype(np.float64) / (1 - 0.999 ** (step + 1)))
+            ill[k] = ill.get(k, False) | ~((rms > 1e-5) | (rms == 0))      # once off, an element stays off
+            well = ~ill[k]
+            assert well.mean() > 0.3, (k, well.mean())
+            assert d[well].max() <= GREL * scale, 'step %d %s: rel err %.3e' % (step, k, d[well].max() / scale)
+            assert d.max() <= 1.1e-3 * (step + 1), 'step %d %s: max diff %.3e' % (step, k, d.max())
+
+
+# ---------------------------------------------------------------------------------------
+# the pooling ChebNet of the legacy monolith at full size
+# ---------------------------------------------------------------------------------------
+
+def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
+    """HCP_task_fmri_gcn_test8.py:1633-1636, 2071: six coarsening levels of the N = 10000 graph
+    (M = 12672 / 6336 / ... / 198), p = [1,4,1,4,1,4], K = [20,10,10,10,5,5], F = [32,32,64,64,128,128],
+    b2relu, block_dura 15, batch 2: logits, loss and the gradients of one training step against
+    the oracle (layers at M = 12672, 3168 and 792 vertices with Fout up to 128 and max pooling 4)."""
+    import bench
+    from gcn_fmri_decoding_amd import models_gcn
+    Ls, perm = bench.load_graph(10000, 6, 0, 1, None)
+    assert [L.shape[0] for L in Ls] == [12672, 6336, 3168, 1584, 792, 396, 198] and len(perm) == 12672
+    F, K, p, Mfc, channel, B = [32, 32, 64, 64, 128, 128], [20, 10, 10, 10, 5, 5], [1, 4, 1, 4, 1, 4], [512, 256, 22], 15, 2
+    reg = 5e-4
+    net = models_gcn.cgcnn({'device': dev}, Ls, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1',
+                           initial='he', channel=channel, regularization=reg, dropout=1, batch_size=B, verbose=False)
+    assert [g.M for g in net.graphs] == [12672, 12672, 3168, 3168, 792, 792]
+    onet = R.Net(Ls, F, K, p, Mfc, channel=channel, brelu='b2relu', regularization=reg)
+    rs = np.random.RandomState(5)
+    params = {}
+    for k, s in onet.param_shapes().items():
+        params[k] = ((0.2 + 0.05 * rs.randn(*s)) if k.endswith('bias') else rs.randn(*s) * np.sqrt(2.0 / s[0])).astype(np.float32)
+        net.set_variable(k, params[k])
+    # input through the product's staging path: perm_data_3d on the device
+    raw = rs.randn(B, 10000, channel).astype(np.float32)
+    from oracle import coarsening_ref as CR
+    x = CR.perm_data_3d(raw, perm.tolist()).astype(np.float32)
+    xs = ops.perm_data(torch.as_tensor(raw).to(dev), torch.as_tensor(perm.astype(np.int32)).to(dev))
+    assert np.array_equal(from_storage(xs, 12672), x)
+    labels = np.array([20, 4])
+    with torch.no_grad():
+        logits = net._inference_storage(xs, 1).cpu().numpy()
+    ologits, cache = onet.forward(params, x)
+    close(logits, ologits, rel=GREL, what='logits')
+    loss, dlogits = onet.loss(params, ologits, labels)
+    grads = onet.backward(params, cache, dlogits)
+    _, loss_avg = net.train_step(xs, torch.as_tensor(labels).to(dev))
+    assert abs(float(loss_avg) - loss) <= GREL * abs(loss)
+    for k in params:
+        spec = next(s for s in net._spec_list if s.name == k)
+        gk = net._params[k].grad
+        if spec.group == 'convb':
+            gk = gk[:, :spec.ref_shape[1]].t().unsqueeze(0)
+        ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
+        close(gk.cpu().numpy(), ref, rel=5e-5, what='grad ' + k)

@@ -1,0 +1,232 @@
+"""The callers of the hot path on the GPU:
+
+* ``fit`` / ``predict`` / ``evaluate`` against the oracle's restatement of the reference loop
+  (oracle/loop_ref.py <- lib_new/models_gcn.py:31-184): sampled index sequence, EMA loss
+  series, validation accuracies / losses, the zero-padded last batch;
+* the checkpoint flow of ``model_perf.predict`` (models_gcn.py:960-1088, checkmat.py);
+* the real ``cgcnn`` under ``dist.DataParallel``: two processes on one GPU (gloo accepts
+  device tensors) against one process on the whole batch.
+
+Needs an MI355X: ``-m gpu``.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, csr_from, load_golden
+from oracle import layers_ref as R
+from oracle import loop_ref as LR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def seeded_model(z, dev, params, **kw):
+    """cgcnn whose ``_init_variables`` (run again by fit(), like the reference's op_init) ends with
+    the given variables instead of fresh random draws."""
+    from gcn_fmri_decoding_amd import models_gcn
+
+    class Seeded(models_gcn.cgcnn):
+        seed_params = None
+
+        def _init_variables(self):
+            super()._init_variables()
+            if self.seed_params is not None and self.device.type == 'cuda':
+                for k, v in self.seed_params.items():
+                    self.set_variable(k, v)
+
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    net = Seeded({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                 channel=int(z['channel']), brelu=str(z['brelu']), verbose=False, **kw)
+    net.seed_params = {k: v.copy() for k, v in params.items()}
+    net._init_variables()
+    return net, Ls
+
+
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212'])
+def test_fit_predict_loop_vs_oracle(dev, name, tmp_path, monkeypatch):
+    """models_gcn.py:112-184 / :31-71 with dropout keep_prob = 1 (the only dropout setting an oracle
+    can follow): 2.5 epochs over 23 windows in batches of 4 (the deque is refilled mid-batch), an
+    evaluation every 3 steps on a validation set whose size (10) is not a multiple of the batch."""
+    monkeypatch.setenv('CHEBGCN_HOME', str(tmp_path))
+    z = load_golden(name)
+    params = {k[len('param:'):]: z[k].copy() for k in z.files if k.startswith('param:')}
+    batch, epochs, every, reg = 4, 2.5, 3, 5e-4
+    net, Ls = seeded_model(z, dev, params, num_epochs=epochs, eval_frequency=every, batch_size=batch,
+                           regularization=reg, dropout=1, dir_name='loop')
+    onet = R.Net(Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(), channel=int(z['channel']),
+                 brelu=str(z['brelu']), regularization=reg)
+    M0, C = Ls[0].shape[0], int(z['channel'])
+    rs = np.random.RandomState(42)
+    S, Sv, nclass = 23, 10, int(z['M'][-1])
+    data = rs.randn(S, M0, C)                                    # float64, like perm_data_3d's output
+    labels = rs.randint(0, nclass, S)
+    vdata = rs.randn(Sv, M0, C)
+    vlabels = rs.randint(0, nclass, Sv)
+
+    # oracle
+    oparams = {k: v.copy() for k, v in params.items()}
+    np.random.seed(2024)
+    log = LR.fit(onet, oparams, data, labels, vdata, vlabels, epochs, batch, every)
+    assert log['num_steps'] == int(epochs * S / batch) == 14 and log['eval_steps'] == [3, 6, 9, 12, 14]
+
+    # product
+    net.record_fit = True
+    np.random.seed(2024)
+    acc, losses, t_step = net.fit(data, labels, vdata, vlabels)
+    assert net.global_step == log['num_steps']
+    assert [i.tolist() for i in net.fit_log['idx']] == [i.tolist() for i in log['idx']]      # same samples, same order
+    np.testing.assert_allclose(net.fit_log['loss_average'], log['loss_average'], rtol=5e-5)
+    np.testing.assert_allclose(losses, log['losses'], rtol=5e-5)                              # incl. the padded last batch
+    assert acc == pytest.approx(log['accuracies'], abs=1e-9)
+    for k in oparams:
+        got, ref = net.get_var(k), oparams[k]
+        # 14 Adam steps: elements whose gradient is ~eps are ill-conditioned (see test_gpu_bench_shapes)
+        d = np.abs(got.astype(np.float64) - ref)
+        assert np.median(d) <= 5e-5 * np.abs(ref).max() and d.max() <= 14 * 1.1e-3, k
+
+    # predict / evaluate on the trained model: padded last batch, loss scaling (:68)
+    pred, ploss = net.predict(vdata, vlabels)
+    opred, oloss = LR.predict(onet, oparams, vdata, vlabels, batch)
+    assert np.array_equal(pred, opred) and ploss == pytest.approx(oloss, rel=5e-5)
+    assert np.array_equal(net.predict(vdata), opred)
+    string, accuracy, f1, loss = net.evaluate(vdata, vlabels)    # restores the last checkpoint saved (= step 14 or earlier best)
+    assert 'accuracy' in string and '\ntime' not in string
+
+
+def test_checkpoint_flow_model_perf_predict(dev, tmp_path, monkeypatch):
+    """fit -> best-3 checkpoints (checkmat policy) -> ``model_perf.predict`` rebuilding the model
+    from the checkpoint alone (predict_states.py:102-108 flow), against the live model."""
+    from gcn_fmri_decoding_amd import models_gcn
+    monkeypatch.setenv('CHEBGCN_HOME', str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    z = load_golden('inference_pool_n212')
+    params = {k[len('param:'):]: z[k].copy() for k in z.files if k.startswith('param:')}
+    net, Ls = seeded_model(z, dev, params, num_epochs=4, eval_frequency=2, batch_size=4, regularization=5e-4,
+                           dropout=0.5, dir_name='ckpt')
+    M0, C, nclass = Ls[0].shape[0], int(z['channel']), int(z['M'][-1])
+    rs = np.random.RandomState(1)
+    data, labels = rs.randn(12, M0, C), rs.randint(0, nclass, 12)
+    test, tlabels = rs.randn(9, M0, C), rs.randint(0, nclass, 9)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    net.fit(data, labels, data[:6], labels[:6])
+    path = os.path.join(str(tmp_path), 'checkpoints', 'ckpt')
+    lines = open(os.path.join(path, 'model', 'checkpoint')).read().splitlines()
+    assert lines[0].startswith('model_checkpoint_path: "best.ckpt-') and len(lines) <= 4
+    chosen = lines[1].split('"')[1]
+    sd = torch.load(os.path.join(path, 'model', chosen + '.pt'), weights_only=True)
+    assert set(params) <= set(sd) and tuple(sd['conv1/weights'].shape) == params['conv1/weights'].shape
+    assert tuple(sd['adam_m/conv1/bias'].shape) == params['conv1/bias'].shape
+    # the live model restored to the same checkpoint
+    net.load_state_dict(sd)
+    pred_live, loss_live = net.predict(test, tlabels)
+    names = ['c%d' % i for i in range(nclass)]
+    perf = models_gcn.model_perf()
+    logits, pred, loss_sum, acc = perf.predict(path, test, tlabels, target_name=names, batch_size=4,
+                                               config={'device': dev})
+    assert np.array_equal(pred, pred_live)
+    assert loss_sum * 4 / 9 == pytest.approx(loss_live, rel=1e-6)     # the reference sums batch losses (:1018)
+    assert logits.shape == (9,)                                        # flattened, then truncated (:1023)
+    # a checkpoint with variables only (e.g. converted from TF) restores; a wrong shape is refused
+    net.load_state_dict({k: sd[k] for k in params})
+    bad = {k: sd[k] for k in params}
+    bad['conv1/weights'] = sd['conv1/weights'][:-1]
+    with pytest.raises(ValueError):
+        net.load_state_dict(bad)
+
+
+# ---------------------------------------------------------------------------------------
+# real cgcnn under data parallelism: two processes, one GPU
+# ---------------------------------------------------------------------------------------
+
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['CHEBGCN_ROOT']); sys.path.insert(0, os.path.join(os.environ['CHEBGCN_ROOT'], 'tests'))
+from conftest import csr_from, load_golden
+from gcn_fmri_decoding_amd import models_gcn, ops, dist as gdist
+rank, world, out = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), os.environ['CHEBGCN_OUT']
+dev = torch.device('cuda:0')
+torch.cuda.set_device(dev)
+if world > 1:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+z = load_golden(os.environ['CHEBGCN_FIXTURE'])
+Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+B = 4
+torch.manual_seed(100 + rank)                      # ranks draw DIFFERENT initial variables: the broadcast must fix that
+net = models_gcn.cgcnn({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                       channel=int(z['channel']), brelu=str(z['brelu']), batch_size=B // world, regularization=5e-4,
+                       dropout=1, initial='he', verbose=False)
+if world > 1:
+    dp = gdist.DataParallel(net)
+net._init_variables()                              # what fit() does after wrapping (the reference re-runs op_init) ...
+if world > 1:
+    dp.broadcast_parameters()                      # ... followed by this (models_gcn.fit): rank 0's second draw wins
+rs = np.random.RandomState(3)
+x = rs.randn(B, Ls[0].shape[0], int(z['channel'])).astype(np.float32)
+labels = rs.randint(0, int(z['M'][-1]), B)
+lo, hi = rank * B // world, (rank + 1) * B // world
+xs = ops.plane_storage(torch.as_tensor(x[lo:hi]).to(dev))
+ld = torch.as_tensor(labels[lo:hi]).to(dev)
+flat0 = net._flat.detach().cpu().numpy().copy()
+grads = []
+for step in range(3):
+    net.train_step(xs, ld)
+    grads.append(net._grad.detach().cpu().numpy().copy())
+torch.cuda.synchronize()
+np.savez(out % rank, flat0=flat0, flat=net._flat.detach().cpu().numpy(), g0=grads[0], g2=grads[2],
+         sent=np.array(sorted(net._dp._sent) if world > 1 else []), nb=len(net._dp._buckets) if world > 1 else 0)
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def _run_ranks(world, fixture, tmp_path, tag):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_WORKER)
+    out = str(tmp_path / (tag + '_%d.npz'))
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   CHEBGCN_ROOT=ROOT, CHEBGCN_OUT=out, CHEBGCN_FIXTURE=fixture, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return [np.load(out % r) for r in range(world)]
+
+
+@pytest.mark.parametrize('fixture', ['inference_flat_n212', 'inference_pool_n212'])
+def test_cgcnn_data_parallel_two_ranks_one_gpu(dev, fixture, tmp_path):
+    """cgcnn.train_step under dist.DataParallel on halves of a batch of 4 (world 2, both ranks on
+    cuda:0, backend gloo) against one process on the whole batch: identical start (rank 0's draw),
+    averaged gradients equal to the full-batch gradients, same variables after three Adam steps.
+    Exercises what the stand-in test cannot: conv gradients written straight into the flat buffer
+    (no autograd hook), reported per layer through ``layer_done``, reduced in two conv buckets."""
+    two = _run_ranks(2, fixture, tmp_path, 'w2')
+    one = _run_ranks(1, fixture, tmp_path, 'w1')[0]
+    a, b = two
+    assert np.array_equal(a['flat0'], b['flat0'])                   # re-initialised, then broadcast from rank 0
+    assert np.array_equal(a['flat0'], one['flat0'])                 # = rank 0's seed (100)
+    assert int(a['nb']) == 2 and a['sent'].tolist() == [0, 1]       # both conv buckets went out
+    assert np.array_equal(a['g0'], b['g0']) and np.array_equal(a['flat'], b['flat'])
+    scale = np.abs(one['g0']).max()
+    # _grad holds the SUM over ranks of per-rank mean gradients; the mean over the whole batch is half of it
+    assert np.abs(0.5 * a['g0'] - one['g0']).max() <= 2e-5 * scale
+    assert np.abs(0.5 * a['g2'] - one['g2']).max() <= 1e-3 * np.abs(one['g2']).max()     # after two Adam steps (ill-conditioned elements)
+    d = np.abs(a['flat'] - one['flat'])
+    assert np.quantile(d, 0.99) <= 2e-5 * np.abs(one['flat']).max() and d.max() <= 3 * 1.1e-3

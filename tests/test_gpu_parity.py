@@ -380,7 +380,7 @@ def build_model(z, dev, **kw):
     return net, Ls, params
 
 
-@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512'])
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512', 'inference_pool6_n512'])
 def test_inference_vs_reference_vectors(ops, dev, name):
     z = load_golden(name)
     net, Ls, params = build_model(z, dev)
@@ -407,7 +407,7 @@ def test_inference_vs_reference_vectors(ops, dev, name):
     close(logits2.cpu().numpy(), logits.cpu().numpy(), rel=1e-6, what='unfused logits')
 
 
-@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212'])
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_pool6_n512'])
 def test_train_step_vs_oracle(ops, dev, name):
     """Gradients of the full network and three TF-form Adam steps against the oracle."""
     z = load_golden(name)

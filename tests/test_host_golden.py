@@ -84,3 +84,20 @@ def test_bench_graph_matches_reference_recipe():
     assert len(dat) == int(z['l1_Lr_nnz']) == 93880
     assert sha(ind.astype(np.int64)) == str(z['l1_Lr_indices_sha256'])
     assert sha(dat) == str(z['l1_Lr_data_sha256'])
+
+
+def test_bench_graph_six_levels_matches_reference_recipe():
+    """The same graph coarsened six times (the pooling ChebNet of the legacy monolith,
+    HCP_task_fmri_gcn_test8.py:1633-1636, 2071): level sizes, nnz and checksums of the permutation
+    and of the rescaled level-0 Laplacian as the reference's own functions produce them."""
+    import hashlib
+    z = load_golden('bench_graph_n10000')
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    Ls, perm, graphs = G.synthetic_graph(10000, k=8, levels=6)
+    assert [g.shape[0] for g in graphs] == z['l6_sizes'].tolist() == [12672, 6336, 3168, 1584, 792, 396, 198]
+    assert [g.nnz for g in graphs] == z['l6_nnz'].tolist()
+    assert sha(np.array(perm, np.int64)) == str(z['l6_perm_sha256'])
+    ptr, ind, dat = G.rescaled_laplacian_csr(Ls[0])
+    assert len(dat) == int(z['l6_Lr_nnz'])
+    assert sha(ind.astype(np.int64)) == str(z['l6_Lr_indices_sha256'])
+    assert sha(dat) == str(z['l6_Lr_data_sha256'])

@@ -91,7 +91,7 @@ def test_layers_vs_reference_source():
             np.testing.assert_allclose(R.apool1_fwd(y2, p), z['cheb_%s_ap%d' % (tag, p)], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512'])
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212', 'inference_config1_n512', 'inference_pool6_n512'])
 def test_inference_vs_reference_source(name):
     z = load_golden(name)
     Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]

@@ -94,3 +94,28 @@ def test_adam_tf_form():
         v = 0.999 * v + 0.001 * g * g
         ref = ref - 0.001 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-8)
         np.testing.assert_allclose(params['w'], ref, rtol=1e-12)
+
+
+def test_torch_cpu_restatement_matches_oracle():
+    """oracle/torch_cpu_ref.py (the multi-threaded CPU baseline B2 that bench.py times) computes
+    what oracle/layers_ref.py computes: logits, loss and one TF-form Adam step, fp32."""
+    from oracle import torch_cpu_ref as TR
+    z = load_golden('inference_pool_n212')
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    cfg = (z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist())
+    net = R.Net(Ls, *cfg, channel=int(z['channel']), brelu=str(z['brelu']), regularization=5e-4)
+    tnet = TR.TorchNet(Ls, *cfg, channel=int(z['channel']), brelu=str(z['brelu']), regularization=5e-4)
+    params = {k[len('param:'):]: z[k].copy() for k in z.files if k.startswith('param:')}
+    tparams = {k: torch.tensor(v) for k, v in params.items()}
+    x, labels = z['x'], np.arange(z['x'].shape[0]) % cfg[3][-1]
+    logits, cache = net.forward(params, x)
+    with torch.no_grad():
+        tl = tnet.forward(tparams, torch.tensor(x)).numpy()
+    np.testing.assert_allclose(tl, logits, rtol=2e-5, atol=2e-5 * np.abs(logits).max())
+    loss, dlogits = net.loss(params, logits, labels)
+    grads = net.backward(params, cache, dlogits)
+    R.adam_tf_step(params, grads, {})
+    tloss = tnet.train_step(tparams, torch.tensor(x), torch.tensor(labels), {})
+    assert abs(tloss - loss) <= 2e-5 * abs(loss)
+    for k in params:
+        np.testing.assert_allclose(tparams[k].detach().numpy(), params[k], rtol=0, atol=2e-5 * np.abs(params[k]).max() + 1.1e-3 * 0)
