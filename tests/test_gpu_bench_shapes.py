@@ -192,7 +192,7 @@ def test_brelu_pool_bwd_parts_small_graph(ops, dev, lvl, F, parts, bias):
     run_layer(ops, dev, L, B=5, Fin=2, Fout=F, K=2, p=2, pool_kind=0, bias=bias, seed=F + bias)
 
 
-@pytest.mark.parametrize('bias,p,pool_kind', [(0, 1, 0), (1, 1, 0), (2, 4, 0), (2, 2, 1)])
+@pytest.mark.parametrize('bias,p,pool_kind', [(0, 1, 0), (1, 1, 0), (2, 2, 0), (2, 2, 1)])     # M = 10466 = 2 * 5233
 def test_brelu_pool_bwd_parts1_full_size(ops, dev, bench_graph, bias, p, pool_kind):
     """PARTS = 1 (41 * 32 >= 1024 blocks) for the bias kinds / pooling forms not covered above."""
     run_layer(ops, dev, bench_graph, B=2, Fin=3, Fout=32, K=2, p=p, pool_kind=pool_kind, bias=bias, seed=10 * bias + p)
