@@ -28,6 +28,7 @@ SIGNATURES = {
     'chebgcn_last_error': (C.c_char_p, []),
     'chebgcn_plane_stride': (_i, [_i]),
     'chebgcn_graph_create': (_i, [_i, _i64, _p, _p, _p, C.POINTER(_p)]),
+    'chebgcn_graph_create_planes': (_i, [_i, _i64, _p, _p, _p, _i, C.POINTER(_p)]),
     'chebgcn_graph_destroy': (None, [_p]),
     'chebgcn_graph_query': (_i, [_p, _i, C.POINTER(_i64)]),
     'chebgcn_recurrence_fwd': (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -76,7 +76,10 @@ static inline EllView view(const Ell& e) {
 
 struct chebgcn_graph;
 namespace chebgcn {
-// recurrence4.hip: four-plane kernel for graphs beyond 2048 ranked rows
+// recurrence.hip: the generic on-chip kernel carries four planes for graphs of at most 2048 ranked
+// rows and 768 linear pieces (its largest 256-thread shapes: 8 rows and 3 pieces per thread)
+inline bool generic4_fits(int rows, int Mq) { return rows <= 2048 && Mq <= 768; }
+// recurrence4.hip: four-plane kernel beyond
 bool onchip4_fits(int lds_entries, int rows, int Mq);
 template <bool ADJ>
 int dispatch_onchip4(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K, int copy_t0,

@@ -39,8 +39,6 @@ static void free_ell(Ell& e) {
 }
 
 constexpr int kLdsBytes = 160 * 1024;     // LDS per workgroup on gfx950
-int g_prefer_planes = 0;                  // chebgcn_tune(1, planes): 0 = automatic, 2 or 4 forced; see graph_create
-int g_slot_order = -1;                    // chebgcn_tune(2, x): experiments, -1 = automatic
 
 // Planes per workgroup for an image of n vertices (+ zero and trash slot, rounded to 4 entries):
 // 4 if 16 B per vertex fit the LDS, else 2 if 8 B fit, else 0 (no on-chip path).
@@ -52,9 +50,10 @@ static int planes_for(int n) {
     return 0;
 }
 
-// CSR (host) -> device Ell.  Entry order inside a row is preserved, so the on-chip kernel
-// sums a row in the order the caller gave (ascending column after tf.sparse_reorder in the
-// reference).  `active[v]` marks vertices whose row or column is non-empty.
+// CSR (host) -> device Ell.  Entry order inside a row is NOT the caller's: positions are chosen
+// below so that the 64 rows of a group hit different LDS banks (a row sum has <= ~17 terms; the
+// order is fixed per graph, so results are deterministic).  `active[v]` marks vertices whose row
+// or column is non-empty.
 static int build_ell(int M, int Mp, int planes, const std::vector<char>& active, const std::vector<int32_t>& rowptr,
                      const std::vector<int32_t>& col, const std::vector<float>& val, Ell* out) {
     int rc;
@@ -75,11 +74,8 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     int nslot = 0;
     int nactive = 0;
     for (int v = 0; v < M; ++v) nactive += active[v] != 0;
-    // ... except for the four-plane kernel of recurrence4.hip (more than 2048 rows), whose linear
-    // phases give every lane ONE vertex: there slots follow the vertex order.
-    const bool vertex_major = g_slot_order >= 0 ? g_slot_order == 1 : planes == 4 && ((nactive + 63) / 64) * 64 > 2048;
-    for (int i = 0; i < (vertex_major ? 1 : 4); ++i)
-        for (int v = i; v < M; v += (vertex_major ? 1 : 4))
+    for (int i = 0; i < 4; ++i)
+        for (int v = i; v < M; v += 4)
             if (planes == 2 || active[v]) {
                 nodeslot[v] = (uint16_t)nslot++;
                 order.push_back(v);
@@ -265,7 +261,13 @@ extern "C" int chebgcn_plane_stride(int M) { return plane_stride(M); }
 
 extern "C" int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                                     const float* vals, chebgcn_graph** out) {
+    return chebgcn_graph_create_planes(M, nnz, rowptr, colidx, vals, 0, out);
+}
+
+extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                                           const float* vals, int want_planes, chebgcn_graph** out) {
     CG_REQUIRE(out != nullptr, "graph_create: out is NULL");
+    CG_REQUIRE(want_planes == 0 || want_planes == 2 || want_planes == 4, "graph_create: planes must be 0, 2 or 4");
     *out = nullptr;
     CG_REQUIRE(M > 0 && nnz >= 0 && rowptr && (nnz == 0 || (colidx && vals)), "graph_create: bad arguments");
     CG_REQUIRE(rowptr[0] == 0 && rowptr[M] == nnz, "graph_create: rowptr[0] != 0 or rowptr[M] != nnz");
@@ -309,15 +311,18 @@ extern "C" int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr, c
     int planes = 0;
     if ((size_t)kLdsBytes <= (size_t)prop.maxSharedMemoryPerMultiProcessor) {
         // 2 planes per workgroup keep every vertex on chip; 4 planes (only the active vertices on
-        // chip) halve the operator instructions per plane.  Measured on MI355X: up to 2048 rows
-        // (the sizes of real brain atlases, 246..1000 nodes) the generic kernel with 4 planes is
-        // 1.1-2x faster; beyond, the four-plane kernel of recurrence4.hip loses (registers), so
-        // there 4 planes are opt-in: chebgcn_tune(1, 4)
+        // chip, 16 bytes each) halve the operator stream per plane.  Measured on MI355X, 4 planes win
+        // wherever a four-plane kernel shape exists: the generic kernel up to 2048 rows (the sizes of
+        // real brain atlases, 246..1000 nodes: 1.1-2x), the kernel of recurrence4.hip beyond (the
+        // benchmark graph, 10000 active vertices).
         planes = planes_for(M) >= 2 ? 2 : 0;
-        if (g_prefer_planes != 2 && planes_for(nactive) == 4) {
-            const int rows = ((nactive + 63) / 64) * 64, entries = (nactive + 2 + 3) & ~3;
-            if (rows <= 2048 || (g_prefer_planes == 4 && onchip4_fits(entries, rows, g->Mp / 4))) planes = 4;
+        const int rows = ((nactive + 63) / 64) * 64, entries = (nactive + 2 + 3) & ~3;
+        const bool four_ok = planes_for(nactive) == 4 && (generic4_fits(rows, g->Mp / 4) || onchip4_fits(entries, rows, g->Mp / 4));
+        if (want_planes == 4 && !four_ok) {
+            delete g;
+            return fail(CHEBGCN_EUNSUPPORTED, "graph_create: no four-plane kernel for %d active of %d vertices", nactive, M);
         }
+        if (want_planes != 2 && four_ok) planes = 4;
     }
     g->lds_ok = planes != 0;
     int rc = build_ell(M, g->Mp, planes, active, rp, ci, va, &g->fwd);

@@ -37,8 +37,6 @@
 namespace chebgcn {
 
 int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
-extern int g_prefer_planes;
-extern int g_slot_order;
 int g_stagger = 0;          // chebgcn_tune(4, x): 0 = automatic
 int g_wide = 0;            // chebgcn_tune(3, 1): prefer the 1024-thread shape (experiment)
 
@@ -661,19 +659,20 @@ static int step_global(const chebgcn_graph* g, const Ell& ell, const float* src,
 
 using namespace chebgcn;
 
-// Undeclared tuning hook for tools/kbench.py (not part of the ABI in include/chebgcn.h).
+#ifdef CG_EXPERIMENT
+// Experiment builds only (tools/xbuild.sh, -DCG_EXPERIMENT): knobs for tools/kbench.py.  The shipped
+// library does not export them (tests/test_abi_and_host.py checks the export list both ways).
 extern "C" int chebgcn_debug_stamps(long long* out) {       // CG_X & 64 builds only (tools/kbench.py --stamps)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(chebgcn::g_dbg), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : -1;
 }
 
 extern "C" int chebgcn_tune(int key, int value) {
     if (key == 0) { g_ablate = value; return 0; }
-    if (key == 1 && (value == 0 || value == 2 || value == 4)) { g_prefer_planes = value; return 0; }   // for graphs created afterwards; 0 = automatic
-    if (key == 2) { g_slot_order = value; return 0; }
     if (key == 3) { g_wide = value; return 0; }
     if (key == 4) { g_stagger = value & 0xFF; return 0; }
     return -1;
 }
+#endif
 
 extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, float* stack, int B,
                                       int Fin, int K, chebgcn_stream stream_) {

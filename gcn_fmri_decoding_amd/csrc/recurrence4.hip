@@ -1,43 +1,80 @@
-// Chebyshev recurrence on chip, FOUR planes per workgroup (gfx950) -- the variant for graphs of
-// roughly 2k..10k active vertices, where 16 bytes per active vertex still fit the 160 KB LDS.
+// Chebyshev recurrence on chip, FOUR planes per workgroup (gfx950) -- graphs of roughly 2k..10k
+// active vertices, where 16 bytes per ACTIVE vertex still fit the 160 KB of LDS.  This is the
+// kernel the benchmark graph (N = 10000 -> M = 10466, 10000 active vertices) runs.
 //
-// Same algorithm and data formats as recurrence.hip (see there and common.h); what differs:
-//   * an LDS entry holds the four planes of one vertex, so one operator entry (2 B slot id +
-//     4 B value, streamed from L2) and one 16-byte ds_read_b128 serve four planes: half the
-//     operator stream, half the address arithmetic and half the LDS instructions per plane;
-//   * only ACTIVE vertices (non-empty row or column of the operator) have an LDS slot.  An
-//     isolated vertex obeys T_k = -T_{k-2}: T_k = 0 for odd k and (-1)^(k/2) x for even k; the
-//     copy-out code patches those lanes from x (adjoint: dx = G_0 - G_2 + G_4 - ...);
-//   * 512 threads with up to 256 VGPRs each: 20 rows x 4 planes of T_{k-2} state per thread;
-//   * the LDS image is a static array (its address folds into the ds_read, the slot id becomes
-//     a byte offset with one SDWA shift), all streaming addresses are uniform base + 32-bit
-//     lane offset.
-// Reference semantics: lib_new/models_gcn.py:587-617 (chebyshev5), forward; the adjoint is the
-// Clenshaw form of its gradient (see recurrence.hip).
+//   forward  (lib_new/models_gcn.py:598-610):  T_0 = x, T_1 = L T_0, T_k = 2 L T_{k-1} - T_{k-2}
+//   adjoint  (TF autodiff of the above):       c_{K-1} = G_{K-1}, c_j = G_j + 2 L^T c_{j+1} - c_{j+2},
+//                                              dx = G_0 + L^T c_1 - c_2
+//
+// Same algorithm, operator format (common.h) and phase structure as the two-plane kernel of
+// recurrence.hip; why four planes: what paces the two-plane kernel is the operator stream --
+// every workgroup re-reads all (value, slot id) entries from L2 once per step, 551 KB against
+// 84 KB of plane payload, and the L2 -> CU path delivers 64 B per clock and CU.  One operator
+// entry and one 16-byte ds_read_b128 serve four planes here: half the operator bytes, half the
+// address arithmetic and half the LDS instructions per plane.  What it costs, and how it is paid:
+//   * LDS: only ACTIVE vertices (non-empty row or column of the operator) have a slot.  An
+//     isolated vertex ("fake" vertices of the coarsening) obeys T_k = -T_{k-2}: T_k = 0 for odd k
+//     and (-1)^(k/2) x for even k.  Its even slabs are written once, when the input is staged
+//     (4-byte stores); copy-outs of even slabs store the other vertices of such a piece
+//     component-wise, so nothing in the gather loop ever loads (adjoint: dx = G_0 - G_2 + ...
+//     is gathered from the gradient slabs when dx goes out).
+//   * registers: 512 threads (two waves per SIMD) with up to 256 VGPRs: 20 rows x 4 planes of
+//     T_{k-2} state per thread (80), the operator ring (40), and -- only while those are idle -- the
+//     96 staging registers of the next input.  The rotate exchanges registers and LDS in chunks
+//     of five rows (a slot is touched by its own thread only).
+//   * no spare LDS for a second image: the copy-out of a group's last slab and the staging of the
+//     next group's input are ONE pass -- a thread reads the old entries of its linear pieces and
+//     overwrites them with the new input, no barrier in between; the input was requested behind
+//     the barrier that ended the last gather, so its HBM latency hides under the last rotate.
 #include "common.h"
 
 namespace chebgcn {
 
 extern int g_ablate;
-__device__ long long g_dbg4[16 * 64];            // phase stamps of CG_X & 64 builds (tools/kbench.py --stamps)
-
-namespace {
+extern int g_stagger;
 
 #ifndef CG_X
-#define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
+#define CG_X 0               // timing experiments only (tools/xbuild.sh)
 #endif
-#ifndef CG_ABL
-#define CG_ABL 0
-#endif
-
-constexpr int QMAX = kQuadMin;   // quads stored for every group and requested one group ahead
-
+// In-kernel phase stamps (CG_X & 64, tools/xbuild.sh): lane 0 of every wave of workgroup 37 records the
+// cycle counter at the phase boundaries of its SECOND plane group (tools/kbench.py --stamps).
+__device__ long long g_dbg4[16 * 64];
 #define CG_STAMP(id)                                                                          \
     do {                                                                                      \
         if ((CG_X & 64) && (id) < 64 && lane == 0 && blockIdx.x == 37 && grp == (int)(blockIdx.x + gridDim.x)) \
             g_dbg4[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();                \
     } while (0)
 
+namespace {
+
+constexpr int QMAX = kQuadMin;       // quads stored for every group and requested two groups ahead
+constexpr int NT4 = 512;             // threads per workgroup
+constexpr int NW4 = NT4 / 64;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Plane accesses are buffer instructions: the descriptor of one slab (SGPRs), a uniform byte offset
+// (plane + piece, an SGPR) and ONE per-thread offset register (tid * 16) -- no 64-bit per-lane
+// address arithmetic, no address registers per (piece, plane).  Planes are read once and written
+// once: streaming (nt) accesses keep them from pushing the operator out of the XCD's L2.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t slab_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ldp(rsrc_t r, unsigned voff, unsigned soff) {
+    const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stp(rsrc_t r, unsigned voff, unsigned soff, float4 v) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 2);
+    // gfx950 (measured: lanes 12..15 of every 16 stored the NEXT value of the first data register): a
+    // 16-byte buffer store still reads its data registers while the following instructions issue.
+    // hipcc pads that hazard for the immediate-offset form only, not for an SGPR soffset.  The asm
+    // reads the data (so nothing overwrites the registers before it) and supplies the wait states.
+    asm volatile("s_nop 1" : : "v"(t) : "memory");
+}
 // byte offset of the 16-byte LDS entry named by the low / high 16 bits of w: one VALU op
 __device__ __forceinline__ unsigned ofs_lo(unsigned w) {
     unsigned r;
@@ -49,215 +86,326 @@ __device__ __forceinline__ unsigned ofs_hi(unsigned w) {
     asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(w));
     return r;
 }
-// uniform base + 32-bit byte offset: global_load/store with an SGPR base
-__device__ __forceinline__ float4 ldg4(const float* ubase, unsigned byteoff) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ubase) + byteoff);
-}
-__device__ __forceinline__ void stg4(float* ubase, unsigned byteoff, float4 v) {
-    *reinterpret_cast<float4*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
-}
-__device__ __forceinline__ float ldg1(const float* ubase, unsigned byteoff) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + byteoff);
-}
-__device__ __forceinline__ void stg1(float* ubase, unsigned byteoff, float v) {
-    *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byteoff) = v;
-}
-__device__ __forceinline__ unsigned slot_of(uint2 c, int i) {
-    const unsigned w = (i & 2) ? c.y : c.x;
-    return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
-}
-__device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-__device__ __forceinline__ void set_comp(float4& v, int i, float x) {
-    if (i == 0) v.x = x; else if (i == 1) v.y = x; else if (i == 2) v.z = x; else v.w = x;
+__device__ __forceinline__ float comp(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+__device__ __forceinline__ void add_comp(float4& v, int i, float x) {
+    if (i == 0) v.x += x; else if (i == 1) v.y += x; else if (i == 2) v.z += x; else v.w += x;
 }
 // Identity the optimiser cannot see through: keeps values DERIVED from the small per-thread
-// tables (unpacked slot ids, flags) from being hoisted out of the plane-group loop, where they
-// would occupy ~80 registers for the whole kernel and spill.
+// tables (unpacked slot ids) from being hoisted out of the plane-group loop, where they would
+// occupy registers for the whole kernel.
 __device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ uint2 opaque(uint2 x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); return x; }
-__device__ __forceinline__ float4 fma4(float s, float4 t, float4 a) {
+__device__ __forceinline__ float4 fma4(float s, const float4& t, const float4& a) {
     return make_float4(fmaf(s, t.x, a.x), fmaf(s, t.y, a.y), fmaf(s, t.z, a.z), fmaf(s, t.w, a.w));
 }
+// plane p of the four vertices whose entries are t[0..3]
+__device__ __forceinline__ float4 plane_of_entries(const float4 (&t)[4], int p) {
+    return make_float4(comp(t[0], p), comp(t[1], p), comp(t[2], p), comp(t[3], p));
+}
 
-// ENT = LDS entries (16 B each), NJ = row slices per thread, NV = vertices per thread in the
-// linear (streaming) phases, NTHR = workgroup size.
-//
-// Streaming phases: lane l of the workgroup owns the vertices v = tid + u*NTHR (u < NV).  A wave
-// therefore touches 64 consecutive vertices of a plane with one 4-byte access per lane (256 B,
-// two full cache lines) and -- slots being numbered in vertex order -- 64 consecutive LDS
-// entries with one conflict-free 16-byte access per lane.  No transposes, no per-component
-// branches: a vertex without a slot is handled by predicating its lane.
-template <int ENT, int NJ, int NV, int NTHR, bool ADJ>
-__global__ void __launch_bounds__(NTHR)
-cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, int M, int Mp, int nplanes,
-             int K, size_t slab, int flags) {
+// ENT = LDS entries (16 B each), NJ = row slices per thread (ceil(groups / 8)), NQ = linear
+// 16-byte pieces per thread and plane (ceil(Mp/4 / 512)).
+template <int ENT, int NJ, int NQ, bool ADJ>
+__global__ void __launch_bounds__(NT4)
+cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, int M, int Mp, int nplanes, int K,
+             size_t slab, int flags) {
     __shared__ float4 T[ENT];                        // slot-indexed: the four planes of one vertex
-    constexpr int nwaves = NTHR >> 6;
-    static_assert(NJ <= 64 && NV <= 2 * NJ, "shape");
+    static_assert(NJ <= 64 && NQ <= NJ && (NJ % 2) == 0, "shape");
     const int copy_t0 = flags & 1;
-    const int abl = CG_ABL ? flags >> 8 : 0;         // tools/kbench.py (xbuild only): 1 no stores, 2 no gather, 16 no loads
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Mq = Mp >> 2;
     const int ngrp = (nplanes + 3) >> 2;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned zslot = (unsigned)e.zero_slot;    // always 0; zslot + 1 = trash (written, never read as data)
     auto lds = [&](unsigned byteoff) -> float4 {
         return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(T) + byteoff);
     };
 
     // ---- per-thread tables, loaded once -----------------------------------------------------
-    constexpr int NJ2 = (NJ + 1) / 2;
-    unsigned rowreg[NJ2];                            // LDS slot of the own row of slice j (two per register)
+    unsigned rowreg[NJ / 2];                         // LDS slot of the own row of slice j (two per register, 0xFFFF = none)
 #pragma unroll
-    for (int j2 = 0; j2 < NJ2; ++j2) {
+    for (int j2 = 0; j2 < NJ / 2; ++j2) {
         unsigned r = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int g = (2 * j2 + h) * nwaves + wave;
-            const unsigned id = (2 * j2 + h < NJ && g < e.ngroups) ? e.rowslot[g * 64 + lane] : 0xFFFFu;
+            const int g = (2 * j2 + h) * NW4 + wave;
+            const unsigned id = g < e.ngroups ? e.rowslot[g * 64 + lane] : 0xFFFFu;
             r |= id << (16 * h);
         }
         rowreg[j2] = r;
     }
-    constexpr int NV2 = (NV + 1) / 2;
-    unsigned vsreg[NV2];                             // LDS slot of the own vertex u (two per register), 0xFFFF = none
+    uint2 nsreg[NQ];                                 // LDS slots of the 4 vertices of every linear piece of this thread
 #pragma unroll
-    for (int u2 = 0; u2 < NV2; ++u2) {
-        unsigned r = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int v = tid + (2 * u2 + h) * NTHR;
-            const unsigned id = (2 * u2 + h < NV && v < Mp) ? e.nodeslot[v] : 0xFFFFu;
-            r |= id << (16 * h);
-        }
-        vsreg[u2] = r;
+    for (int u = 0; u < NQ; ++u) {
+        const int q = tid + u * NT4;
+        nsreg[u] = (q < Mq) ? reinterpret_cast<const uint2*>(e.nodeslot)[q] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     }
-    auto vslot = [&](int u) -> unsigned { return (opaque(vsreg[u >> 1]) >> (16 * (u & 1))) & 0xFFFFu; };
-    int2 gtab = make_int2(0, 0);                     // lane j: {quad offset, length} of group j*nwaves + wave
-    if (lane < NJ && lane * nwaves + wave < e.ngroups) gtab = e.ginfo[lane * nwaves + wave];
-    if (tid == 0) T[e.zero_slot] = zero4;            // never written again
-    // no slot (id 0xFFFF): read the zero slot, write the trash slot -- straight-line LDS code
-    auto rd_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot : id; };
-    auto wr_slot = [&](unsigned id) -> unsigned { return id == 0xFFFFu ? (unsigned)e.zero_slot + 1u : id; };
-    if (!(abl & 32)) {                               // spread the workgroups of an XCD over one step
-        // ... scaled with the number of groups a workgroup works through
+    int2 gtab = make_int2(0, 0);                     // lane j: {quad offset, length} of group j*8 + wave
+    if (lane < NJ && lane * NW4 + wave < e.ngroups) gtab = e.ginfo[lane * NW4 + wave];
+    const __amdgpu_buffer_rsrc_t colo_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colo, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valp, 0, 0x7FFFFFFF, 0x00020000);
+    if (tid == 0) T[zslot] = zero4;                  // never written again
+    {   // one-off stagger of the workgroups of an XCD (see recurrence.hip)
         const int gpw = (ngrp + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int sx = (flags >> 20) & 0xFF;
         const int m8 = gpw <= 4 ? 8 : gpw >= 16 ? 16 : 8 + (8 * (gpw - 4)) / 12;
-        const int reps = ((blockIdx.x >> 3) & 31) * m8 / 8;
+        const int reps = ((blockIdx.x >> 3) & 31) * (sx ? sx - 1 : m8) / 8;
         for (int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(10);
     }
     const size_t in_base = ADJ ? (size_t)(K - 1) * slab : 0;
-    __syncthreads();
 
-    for (int grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
-        // uniform plane offsets; planes beyond nplanes alias the last one and are never stored
-        size_t pl[4];
-        bool pv[4];
+    // plane offsets of a group (uniform); planes beyond nplanes alias the last one and are never stored
+    const unsigned slab_bytes = (unsigned)(slab * sizeof(float));     // < 4 GB (checked by the dispatcher)
+    const unsigned vb = (unsigned)tid * 16u;                            // this thread's byte offset inside a run of 512 pieces
+    auto plane_off = [&](int g, int p, int u) -> unsigned {             // uniform: plane p of group g, piece run u
+        const int i = g * 4 + p;
+        return (unsigned)(i < nplanes ? i : nplanes - 1) * (unsigned)Mp * 4u + (unsigned)u * (NT4 * 16u);
+    };
+    const rsrc_t rs_t0 = slab_rsrc(dst, slab_bytes);                    // forward: slab 0 of the stack (T_0)
+    // (a partial last group computes its missing planes as copies of the last one and stores them to the
+    // same addresses: identical values, no branch per plane)
+    auto ids_of_piece = [&](int u, unsigned (&id)[4]) {
+        const uint2 nq = opaque(nsreg[u]);
+        id[0] = nq.x & 0xFFFFu; id[1] = nq.x >> 16; id[2] = nq.y & 0xFFFFu; id[3] = nq.y >> 16;
+    };
+
+    // linear staging registers: the next group's input, G_j of the adjoint.  Live only while the
+    // operator ring and (between groups) the row state are idle.
+    float4 gx[NQ][4];
+    auto load_planes = [&](const float* base, int g, int u0 = 0, int u1 = NQ) {
+        const rsrc_t rs = slab_rsrc(base, slab_bytes);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int i = grp * 4 + p;
-            pv[p] = i < nplanes;
-            pl[p] = (size_t)(pv[p] ? i : nplanes - 1) * Mp;
+        for (int u = u0; u < u1; ++u) {
+            const int q = tid + u * NT4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) gx[u][p] = zero4;
+            if (q < Mq) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) gx[u][p] = ldp(rs, vb, plane_off(g, p, u));
+            }
         }
-        // LDS image -> the four planes of slab `out` (forward).  A vertex without a slot reads
-        // the zero slot; isolated vertices were stored into the even slabs when the input was
-        // staged, so there (`keep`) their lanes do not store.
-        auto copy_out = [&](int u, float* out, bool keep) {
-            const int v = tid + u * NTHR;
-            const unsigned vb = opaque((unsigned)v * 4u);
-            if (v < Mp && !(abl & 1)) {
-                const unsigned id = vslot(u);
-                const bool none = id == 0xFFFFu;
-                const float4 t = T[none ? (unsigned)e.zero_slot : id];
-                if (!(keep && none && v < M)) {
+    };
+    auto clear_planes = [&]() {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (pv[p]) stg1(out + pl[p], vb, comp(t, p));
-                }
-            }
-        };
+        for (int u = 0; u < NQ; ++u)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) gx[u][p] = zero4;
+    };
 
-        // ---- input planes -> LDS image (forward: and straight to slab 0) --------------------
-        CG_STAMP(0);
-        constexpr int NVH = (NV + 1) / 2;            // two batches: half the staging registers
+    // Stores the four planes of one linear piece of a forward slab.  t[i] = LDS entry of vertex 4q+i
+    // (zero for a vertex without a slot: pads, and isolated vertices in odd slabs).  In an even slab an
+    // isolated vertex holds iso_sign * x: such a piece re-reads its 16 bytes of T_0 (slab 0 of dst).
+    auto store_piece = [&](rsrc_t out, int g, int u, const unsigned (&id)[4], const float4 (&t)[4], float iso_sign) {
+        const int q = tid + u * NT4;
+        unsigned iso = 0;
 #pragma unroll
-        for (int u0 = 0; u0 < NV; u0 += NVH) {
-            float4 x[NVH];
+        for (int i = 0; i < 4; ++i)
+            if (id[i] == 0xFFFFu && 4 * q + i < M) iso |= 1u << i;
+        float4 o[4];
 #pragma unroll
-            for (int uu = 0; uu < NVH; ++uu) {
-                const int v = tid + (u0 + uu) * NTHR;
-                const unsigned vb = opaque((unsigned)v * 4u);
-                x[uu] = zero4;
-                if (u0 + uu < NV && v < Mp && !(abl & 16))
-                    x[uu] = make_float4(ldg1(src + in_base + pl[0], vb), ldg1(src + in_base + pl[1], vb),
-                                        ldg1(src + in_base + pl[2], vb), ldg1(src + in_base + pl[3], vb));
+        for (int p = 0; p < 4; ++p) o[p] = plane_of_entries(t, p);
+        if (iso_sign != 0.f && iso != 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float4 x = ldp(rs_t0, vb, plane_off(g, p, u));
+                if (iso & 1u) o[p].x = iso_sign * x.x;
+                if (iso & 2u) o[p].y = iso_sign * x.y;
+                if (iso & 4u) o[p].z = iso_sign * x.z;
+                if (iso & 8u) o[p].w = iso_sign * x.w;
             }
+        }
 #pragma unroll
-            for (int uu = 0; uu < NVH; ++uu) {
-                const int v = tid + (u0 + uu) * NTHR;
-                const unsigned vb = opaque((unsigned)v * 4u);
-                if (u0 + uu < NV && v < Mp) {
-                    const unsigned id = vslot(u0 + uu);
-                    T[wr_slot(id)] = x[uu];
-                    if (!ADJ && !(abl & 1)) {
-                        if (copy_t0) {
+        for (int p = 0; p < 4; ++p) stp(out, vb, plane_off(g, p, u), o[p]);
+    };
+
+    // The pass between two groups: the final image of group `pg` (forward: slab K-1; adjoint: dx)
+    // goes out and the input of group `ng` (in gx) takes its place, piece by piece, by the thread
+    // that owns the piece in every linear phase -- no barrier between the read and the overwrite.
+    auto turn_over = [&](bool have_prev, int pg, bool have_next, int ng) {
+        const rsrc_t rs_out = slab_rsrc(ADJ ? dst : dst + (size_t)(K - 1) * slab, slab_bytes);   // dx / slab K-1
 #pragma unroll
-                            for (int p = 0; p < 4; ++p)
-                                if (pv[p]) stg1(dst + pl[p], vb, comp(x[uu], p));
-                        }
-                        // an isolated vertex has T_k = (-1)^(k/2) x in the even slabs: stored here, once
-                        if (id == 0xFFFFu && v < M) {
-                            float sgn = -1.f;
-                            for (int k = 2; k < K; k += 2, sgn = -sgn) {
+        for (int u = 0; u < NQ; ++u) {
+            const int q = tid + u * NT4;
+            if (q < Mq) {
+                unsigned id[4];
+                ids_of_piece(u, id);
+                if (have_prev) {
+                    float4 t[4];
 #pragma unroll
-                                for (int p = 0; p < 4; ++p)
-                                    if (pv[p]) stg1(dst + (size_t)k * slab + pl[p], vb, sgn * comp(x[uu], p));
+                    for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
+                    if (!ADJ) {
+                        const int ko = K - 1;
+                        store_piece(rs_out, pg, u, id, t, (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f));
+                    } else {
+                        float4 o[4];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) o[p] = plane_of_entries(t, p);
+                        unsigned iso = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (id[i] == 0xFFFFu && 4 * q + i < M) iso |= 1u << i;
+                        if (iso != 0) {              // an isolated vertex has dx = G_0 - G_2 + G_4 - ...
+                            float sgn = 1.f;
+                            for (int m = 0; m < K; m += 2, sgn = -sgn) {
+                                const rsrc_t rs_g = slab_rsrc(src + (size_t)m * slab, slab_bytes);
+#pragma unroll
+                                for (int p = 0; p < 4; ++p) {
+                                    const float4 xg = ldp(rs_g, vb, plane_off(pg, p, u));
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if (iso & (1u << i)) add_comp(o[p], i, sgn * comp(xg, i));
+                                }
                             }
                         }
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) stp(rs_out, vb, plane_off(pg, p, u), o[p]);
+                    }
+                }
+                if (have_next) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        T[id[i] == 0xFFFFu ? zslot + 1u : id[i]] =
+                            make_float4(comp(gx[u][0], i), comp(gx[u][1], i), comp(gx[u][2], i), comp(gx[u][3], i));
+                    if (!ADJ && copy_t0) {           // T_0 = x goes straight to slab 0
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) stp(rs_t0, vb, plane_off(ng, p, u), gx[u][p]);
                     }
                 }
             }
         }
+    };
+
+    int grp = blockIdx.x;
+    __syncthreads();
+    if (grp < ngrp) load_planes(src + in_base, grp); else clear_planes();
+    turn_over(false, 0, grp < ngrp, grp);
+    for (; grp < ngrp; grp += gridDim.x) {
         CG_STAMP(1);
-        __syncthreads();
+        __syncthreads();                             // the image of this group is complete
         CG_STAMP(2);
 
         float4 st[NJ];                               // T_{k-2} of the own rows, replaced by T_k in place
 #pragma unroll
         for (int j = 0; j < NJ; ++j) st[j] = zero4;
 
+        // Closes step `sdone`: once every wave has finished its gather, LDS <- T_k and the registers
+        // <- T_{k-1} of the own rows (adjoint: then c_j += G_j).  Runs at the top of the next step and,
+        // for the last step (where the next group's input is requested), after the loop -- kept out of
+        // the loop so that the staging registers are not live across a gather.
+        auto finish_step = [&](int sdone, bool last) {
+            CG_STAMP(4 * sdone + 0);
+            __syncthreads();                         // every gather (and copy-out read) of this step is done
+            CG_STAMP(4 * sdone + 1);
+            // HBM requests only now, behind the barrier: queued while other waves still gather they
+            // would hold up those waves' operator loads (the vector memory pipeline returns in order)
+            // Registers: the row state (4*NJ) and all 16*NQ staging registers do not fit together, so
+            // the first half of G_j is requested before the rotate and the second half behind it; after
+            // the last step the old T_{k-1} of the own rows is not needed any more (write-only rotate),
+            // and the next group's input is requested once the state is dead.
+            const int nxt = grp + (int)gridDim.x;
+            constexpr int NH = NQ / 3;                     // a third before the rotate (its chunk registers are live), the rest behind
+            const float* gj = src + (size_t)(K - 1 - sdone) * slab;                // G_j of the finished step (adjoint)
+            if (ADJ) load_planes(gj, grp, 0, NH);
+            // rotate: LDS <- T_k, registers <- T_{k-1} of the own rows; a slot belongs to one thread
+            constexpr int RC = 5;
+#pragma unroll
+            for (int j0 = 0; j0 < NJ; j0 += RC) {
+                float4 prev[RC];
+                if (!last) {
+#pragma unroll
+                    for (int j = j0; j < j0 + RC && j < NJ; ++j) {
+                        const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                        prev[j - j0] = T[r == 0xFFFFu ? zslot : r];
+                    }
+                }
+#pragma unroll
+                for (int j = j0; j < j0 + RC && j < NJ; ++j) {
+                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
+                    T[r == 0xFFFFu ? zslot + 1u : r] = st[j];
+                    if (!last) st[j] = prev[j - j0];
+                }
+            }
+            if (ADJ) load_planes(gj, grp, NH, NQ);
+            else if (last) { if (nxt < ngrp) load_planes(src, nxt); else clear_planes(); }
+            CG_STAMP(4 * sdone + 2);
+            __syncthreads();
+            CG_STAMP(4 * sdone + 3);
+            if (ADJ) {
+                // c_j += G_j: every linear piece by its owner
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    const int q = tid + u * NT4;
+                    if (q < Mq) {
+                        unsigned id[4];
+                        ids_of_piece(u, id);
+                        float4 t[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            t[i].x += comp(gx[u][0], i);
+                            t[i].y += comp(gx[u][1], i);
+                            t[i].z += comp(gx[u][2], i);
+                            t[i].w += comp(gx[u][3], i);
+                            T[id[i] == 0xFFFFu ? zslot + 1u : id[i]] = t[i];
+                        }
+                    }
+                }
+                if (last) { if (nxt < ngrp) load_planes(src + in_base, nxt); else clear_planes(); }
+                __syncthreads();
+            }
+        };
         for (int step = 1; step < K; ++step) {
+            if (step > 1) finish_step(step - 1, false);
             const float f = ADJ ? (step == K - 1 ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
             // forward: slab step-1 is written out while this step gathers
             const bool do_out = !ADJ && step > 1;
-            float* out_slab = dst + (size_t)(step - 1) * slab;
-            const bool keep = ((step - 1) & 1) == 0;           // even slab: isolated vertices already stored
+            const rsrc_t out_slab = slab_rsrc(dst + (size_t)(step - 1) * slab, slab_bytes);
+            const int ko = step - 1;
+            const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);     // isolated vertex: T_k = 0 (odd k), (-1)^(k/2) x
 
             // ---- gather: st <- f * (A T_{k-1})[own rows] - st -----------------------------------
-            // Operator entries travel through a ring of RING quads (4 entries of each of the 64
-            // rows): every group stores QMAX zero-padded quads, quad n = QMAX*j + q lives in ring
-            // slot n % RING and is requested RING quads (two groups) before it is gathered -- one
-            // group of lead does not cover the L2 latency.  Requests are unconditional, so the
-            // compiler can count the loads in flight (s_waitcnt vmcnt(N), N > 0).
+            // Operator entries travel through a ring of RING quads (4 entries of each of the 64 rows):
+            // every group stores QMAX zero-padded quads, quad n = QMAX*j + q lives in ring slot
+            // n % RING and is requested two groups before it is gathered.  The slot ids come eight
+            // per lane and record (one 16-byte load per two quads); a third quad of at most two
+            // entries carries its ids in the unused half of its value record (graph.hip).
             constexpr int RING = 2 * QMAX;
-            uint2 rc[RING];
+            constexpr int QO = (QMAX + 1) / 2;
+            constexpr int ORING = 2 * QO;
+            uint4 ro[ORING];
             float4 rv[RING];
             auto group_info = [&](int j, int& qoff, int& len) {
                 qoff = __builtin_amdgcn_readlane(gtab.x, j);
                 len = __builtin_amdgcn_readlane(gtab.y, j);
-                if (abl & 2) { qoff = 0; len = 0; }
-                if (CG_X & 1) qoff = 0;
             };
-            auto request = [&](int j, int q) {                   // quad q of group j -> its ring slot
+            auto request_ids = [&](int j, int o) {
                 int qoff, len;
                 group_info(j, qoff, len);
-                if ((CG_X & 4) && j > 1) return;               // experiment: no operator loads after the prologue
-                rc[(QMAX * j + q) % RING] = e.colq[(size_t)(qoff + q) * 64 + lane];
-                rv[(QMAX * j + q) % RING] = e.valq[(size_t)(qoff + q) * 64 + lane];
+                if (o >= 1 && len <= 10) return;
+                const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(colo_rsrc, lane * 16, ((qoff >> 1) + o) * 1024, 0);
+                ro[(QO * j + o) % ORING] = make_uint4(c.x, c.y, c.z, c.w);
+            };
+            auto request = [&](int j, int q) {
+                int qoff, len;
+                group_info(j, qoff, len);
+                if (q >= 2 && len <= 8) return;
+                const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(valq_rsrc, lane * 16, (qoff + q) * 1024, 0);
+                rv[(QMAX * j + q) % RING] = make_float4(v.x, v.y, v.z, v.w);
+            };
+            auto ids_of = [&](int j, int q) {
+                const uint4 o = ro[(QO * j + (q >> 1)) % ORING];
+                return (q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y);
+            };
+            auto pair = [&](const unsigned c, const float v0, const float v1, float4& acc) {
+                const float4 t0 = lds(ofs_lo(c)), t1 = lds(ofs_hi(c));
+                acc = fma4(v0, t0, acc);
+                acc = fma4(v1, t1, acc);
             };
             auto quad = [&](const uint2 c, const float4 v, float4& acc) {
-                unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
-                if (CG_X & 2) { a0 = lane * 16; a1 = a0 + 1024; a2 = a0 + 2048; a3 = a0 + 3072; }
+                const unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
                 const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3);
                 acc = fma4(v.x, t0, acc);
                 acc = fma4(v.y, t1, acc);
@@ -265,143 +413,93 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 acc = fma4(v.w, t3, acc);
             };
 #pragma unroll
-            for (int n = 0; n < RING; ++n)
-                if (n / QMAX < NJ) request(n / QMAX, n % QMAX);
+            for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+                for (int o = 0; o < QO; ++o) request_ids(jj, o);
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) request(jj, q);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (do_out) {
-                    // the vertices u in [j*NV/NJ, (j+1)*NV/NJ) go out with this group: small store
-                    // packets spread over the whole gather
-                    const int ua = j * NV / NJ, ub = (j + 1) * NV / NJ;
-                    if (ua < ub) copy_out(ua, out_slab, keep);
-                    if (ua + 1 < ub) copy_out(ua + 1, out_slab, keep);
+                // waves that are ahead yield to the ones behind (see recurrence.hip)
+                if (j == 0 || (4 * j) / NJ != (4 * (j - 1)) / NJ) {
+                    const int pr = 3 - (4 * j) / NJ;
+                    if (pr == 3) __builtin_amdgcn_s_setprio(3);
+                    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
                 }
                 int qoff, len;
                 group_info(j, qoff, len);
                 float4 acc = zero4;
-                const bool gather = !(abl & 2);
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
                     // the first two quads always (zero-padded), the third for rows beyond 8 entries
-                    if (gather && (q < 2 || len > 8)) quad(rc[(QMAX * j + q) % RING], rv[(QMAX * j + q) % RING], acc);
-                    if (j + 2 < NJ) request(j + 2, q);           // refill the slot just consumed
+                    if (q == 2 && len > 8 && len <= 10) {
+                        const float4 v = rv[(QMAX * j + q) % RING];
+                        pair(__float_as_uint(v.z), v.x, v.y, acc);
+                    } else if (q < 2 || len > 10) quad(ids_of(j, q), rv[(QMAX * j + q) % RING], acc);
+                    if (j + 2 < NJ) {
+                        request(j + 2, q);                       // refill the slots just consumed
+                        if ((q & 1) || q == QMAX - 1) request_ids(j + 2, q >> 1);
+                    }
                 }
-                if (gather && len > 4 * QMAX) {
-                    for (int q = QMAX; 4 * q < len; ++q) {           // rows longer than 4*QMAX entries (rare)
-                        const uint2 c = e.colq[(size_t)(qoff + q) * 64 + lane];
+                if (len > 4 * QMAX) {
+                    for (int q = QMAX; 4 * q < len; ++q) {       // rows longer than 4*QMAX entries (rare)
+                        const uint4 o = e.colo[(size_t)((qoff >> 1) + (q >> 1)) * 64 + lane];
                         const float4 v = e.valq[(size_t)(qoff + q) * 64 + lane];
-                        quad(c, v, acc);
+                        quad((q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y), v, acc);
                     }
                 }
                 st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
                                     fmaf(f, acc.w, -st[j].w));
             }
-            float4 gj[ADJ ? NV : 1];                 // G_j of the adjoint, added after the rotate
-            if (ADJ) {
-                const float* gs = src + (size_t)(K - 1 - step) * slab;
+            CG_STAMP(24 + step);
+            // forward: slab step-1 (the image the gather just read) goes out now, before the barrier --
+            // waves that finish their rows early stream while the others still gather; kept out of the
+            // gather loop: its 40-odd temporaries do not fit next to the row state and the operator ring
+            if (do_out) {
 #pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const int v = tid + u * NTHR;
-                    const unsigned vb = opaque((unsigned)v * 4u);
-                    gj[u] = zero4;
-                    if (v < Mp && !(abl & 16))
-                        gj[u] = make_float4(ldg1(gs + pl[0], vb), ldg1(gs + pl[1], vb), ldg1(gs + pl[2], vb),
-                                            ldg1(gs + pl[3], vb));
-                }
-            }
-            CG_STAMP(4 * step + 0);
-            __syncthreads();                         // every gather (and copy-out read) of this step is done
-            CG_STAMP(4 * step + 1);
-            // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows ------------------------
-            {
-                float4 prev[NJ];
+                for (int u = 0; u < NQ; ++u) {
+                    const int q = tid + u * NT4;
+                    if (q < Mq) {
+                        unsigned id[4];
+                        ids_of_piece(u, id);
+                        float4 t[4];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
-                    prev[j] = T[rd_slot(r)];
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const unsigned r = (opaque(rowreg[j >> 1]) >> (16 * (j & 1))) & 0xFFFFu;
-                    T[wr_slot(r)] = st[j];
-                    st[j] = prev[j];
-                }
-            }
-            CG_STAMP(4 * step + 2);
-            __syncthreads();
-            CG_STAMP(4 * step + 3);
-            if (ADJ) {
-                // ---- c_j += G_j, linear ---------------------------------------------------------
-#pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const unsigned id = vslot(u);
-                    float4 t = T[rd_slot(id)];
-                    t.x += gj[u].x;
-                    t.y += gj[u].y;
-                    t.z += gj[u].z;
-                    t.w += gj[u].w;
-                    T[wr_slot(id)] = t;
-                }
-                __syncthreads();
-            }
-        }
-
-        // ---- stream the last image out ---------------------------------------------------------
-        if (!ADJ) {
-            const int ko = K - 1;
-#pragma unroll
-            for (int u = 0; u < NV; ++u) copy_out(u, dst + (size_t)ko * slab, (ko & 1) == 0);
-        } else {
-            // dx; an isolated vertex has dx = G_0 - G_2 + G_4 - ...
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const int v = tid + u * NTHR;
-                const unsigned vb = opaque((unsigned)v * 4u);
-                if (v < Mp && !(abl & 1)) {
-                    const unsigned id = vslot(u);
-                    const bool none = id == 0xFFFFu;
-                    float4 t = T[none ? (unsigned)e.zero_slot : id];
-                    if (none && v < M) {
-                        float sgn = 1.f;
-                        for (int m = 0; m < K; m += 2, sgn = -sgn) {
-                            const float* gs = src + (size_t)m * slab;
-                            t.x += sgn * ldg1(gs + pl[0], vb);
-                            t.y += sgn * ldg1(gs + pl[1], vb);
-                            t.z += sgn * ldg1(gs + pl[2], vb);
-                            t.w += sgn * ldg1(gs + pl[3], vb);
-                        }
+                        for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
+                        store_piece(out_slab, grp, u, id, t, iso_sign);
                     }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        if (pv[p]) stg1(dst + pl[p], vb, comp(t, p));
                 }
             }
         }
+        finish_step(K - 1, true);
+        // ---- the final image goes out, the next group's input comes in -------------------------
         CG_STAMP(40);
-        __syncthreads();                             // LDS reads done before the image is overwritten
+        turn_over(true, grp, grp + (int)gridDim.x < ngrp, grp + (int)gridDim.x);
         CG_STAMP(41);
     }
 }
 
-template <int ENT, int NJ, int NV, int NTHR, bool ADJ>
+template <int ENT, int NJ, int NQ, bool ADJ>
 int launch4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
             hipStream_t stream) {
-    const int per_cu = (160 * 1024) / (ENT * 16);
     const int ngrp = (nplanes + 3) / 4;
-    int grid = g->num_cus * (per_cu < 1 ? 1 : per_cu);
+    int grid = g->num_cus * ((160 * 1024) / (ENT * 16) < 1 ? 1 : (160 * 1024) / (ENT * 16));
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
-    hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NV, NTHR, ADJ>), dim3(grid), dim3(NTHR), 0, stream, view(ell), src, dst,
-                       g->M, g->Mp, nplanes, K, slab, copy_t0 | (g_ablate << 8));
+    hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, ADJ>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M, g->Mp,
+                       nplanes, K, slab, copy_t0 | (g_stagger << 20));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
 
-// shape 0 = none, 1 = 5120 entries, 512 threads x 10 rows, 2 = 10240 entries, 768 threads x 14 rows
+// shape 0 = none; shapes: {entries, rows per thread, linear pieces per thread}
 int shape4(int lds_entries, int rows, int Mq) {
-    if (rows <= 2048) return 0;                      // small graphs: the generic kernel of recurrence.hip
-    if (lds_entries <= 5120 && rows <= 10 * 512 && Mq * 4 <= 12 * 512) return 1;
-    if (lds_entries <= 10240 && rows <= 14 * 768 && Mq * 4 <= 14 * 768) return 2;
+    if (generic4_fits(rows, Mq)) return 0;           // small graphs: the generic kernel of recurrence.hip
+    const int nq = (Mq + NT4 - 1) / NT4;
+    if (lds_entries <= 5120 && rows <= 10 * NT4 && nq <= 4) return nq <= 3 ? 1 : 2;
+    if (lds_entries <= 10240 && rows <= 20 * NT4 && nq <= 7) return nq <= 6 ? 3 : 4;
     return 0;
 }
 
@@ -413,9 +511,14 @@ template <bool ADJ>
 int dispatch_onchip4(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K, int copy_t0,
                      hipStream_t stream) {
     const Ell& ell = ADJ ? g->adj : g->fwd;
+    // one slab is addressed through one buffer descriptor (32-bit offsets): larger batches go in chunks of planes
+    const int max_planes = (int)((0xFFFF0000ull / ((size_t)g->Mp * sizeof(float))) & ~3ull);
+    if (nplanes > max_planes) return fail(CHEBGCN_EUNSUPPORTED, "recurrence: %d planes of %d vertices exceed 4 GB per slab", nplanes, g->Mp);
     switch (shape4(ell.lds_entries, ell.ngroups * 64, g->Mp / 4)) {
-        case 1: return launch4<5120, 10, 12, 512, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
-        case 2: return launch4<10240, 14, 14, 768, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 1: return launch4<5120, 10, 3, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 2: return launch4<5120, 10, 4, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 3: return launch4<10240, 20, 6, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 4: return launch4<10240, 20, 7, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
         default: break;
     }
     return fail(CHEBGCN_EUNSUPPORTED, "recurrence: no four-plane kernel shape for %d rows", ell.ngroups * 64);
@@ -426,6 +529,8 @@ template int dispatch_onchip4<true>(const chebgcn_graph*, const float*, float*, 
 
 }  // namespace chebgcn
 
-extern "C" int chebgcn_debug_stamps4(long long* out) {      // CG_X & 64 builds only
+#ifdef CG_EXPERIMENT
+extern "C" int chebgcn_debug_stamps4(long long* out) {      // CG_X & 64 builds only (tools/kbench.py --stamps)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(chebgcn::g_dbg4), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : -1;
 }
+#endif

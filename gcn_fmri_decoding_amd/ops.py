@@ -104,7 +104,9 @@ class Graph:
     """Device image of one Laplacian: ``rescale_L(L, lmax=2)`` and its transpose, as the
     constant sparse operand of the recurrence (models_gcn.py:590-596)."""
 
-    def __init__(self, L, device=None):
+    def __init__(self, L, device=None, planes=0):
+        """``planes``: planes a recurrence workgroup carries on chip -- 0 = automatic, 2 or 4
+        (chebgcn_graph_create_planes; a choice of speed, not of results)."""
         self.M = int(L.shape[0])
         self.Mp = plane_stride(self.M)
         indptr, indices, data = _graph.rescaled_laplacian_csr(L)
@@ -112,9 +114,9 @@ class Graph:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            rc = _lib.lib().chebgcn_graph_create(self.M, self.nnz, indptr.ctypes.data_as(C.c_void_p),
-                                                 indices.ctypes.data_as(C.c_void_p),
-                                                 data.ctypes.data_as(C.c_void_p), C.byref(handle))
+            rc = _lib.lib().chebgcn_graph_create_planes(self.M, self.nnz, indptr.ctypes.data_as(C.c_void_p),
+                                                        indices.ctypes.data_as(C.c_void_p),
+                                                        data.ctypes.data_as(C.c_void_p), int(planes), C.byref(handle))
         _lib.check(rc, 'graph_create')
         self.handle = handle
         self._finalizer = weakref.finalize(self, _lib.lib().chebgcn_graph_destroy, handle)

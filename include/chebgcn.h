@@ -59,16 +59,28 @@ int chebgcn_plane_stride(int M);
 /* ---- graph: the constant operand of tf.sparse_tensor_dense_matmul ---------------
  * Replaces models_gcn.py:593-596 (tf.SparseTensor + tf.sparse_reorder of the
  * rescaled Laplacian).  Takes L~ = rescale_L(L, lmax=2) (lib_new/graph.py:146-152)
- * as host CSR (row-major, any column order inside a row; summation follows the given
- * order), builds device-side length-sorted sliced-ELL images of L~ and of L~^T (the
- * adjoint used by the gradient of SparseTensorDenseMatMul).  The host arrays are
- * copied; the caller keeps ownership. */
+ * as host CSR (row-major, any column order inside a row), builds device-side
+ * length-sorted sliced-ELL images of L~ and of L~^T (the adjoint used by the gradient of
+ * SparseTensorDenseMatMul).  The order in which the entries of a row are summed is chosen
+ * by the library (LDS bank placement), not the caller's: a row sum is an fp32 fmaf chain
+ * over its <= ~17 entries in that fixed order, deterministic from run to run.  The host
+ * arrays are copied; the caller keeps ownership. */
 int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr /*host [M+1]*/,
                          const int32_t* colidx /*host [nnz]*/, const float* vals /*host [nnz]*/,
                          chebgcn_graph** out);
+/* The same, with the number of planes (window x feature columns) a recurrence workgroup carries
+ * on chip chosen by the caller: 0 = automatic (what chebgcn_graph_create does: 4 where 16 bytes
+ * per active vertex fit the LDS, else 2), 2, or 4 (CHEBGCN_EUNSUPPORTED if 4 do not fit).  The
+ * choice affects speed and the order of the terms inside a row sum (results agree to fp32
+ * round-off). */
+int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
+                                const float* vals, int planes, chebgcn_graph** out);
 void chebgcn_graph_destroy(chebgcn_graph* g);
 /* what: 0 = M, 1 = nnz, 2 = plane stride Mp, 3 = 1 if the on-chip (LDS) recurrence
- * kernel is used for this graph, 4 = padded ELL slots of L~, 5 = max row length. */
+ * kernel is used for this graph, 4 = padded ELL slots of L~, 5 = max row length,
+ * 6 = planes per workgroup (0, 2, 4), 7 = rows held in the LDS image, 8 = LDS bytes of the
+ * image, 9 / 10 / 11 = modelled LDS cycles of one gather pass in the caller's entry order /
+ * after the library's bank-aware placement / without any conflict. */
 int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* value);
 
 /* ---- Chebyshev recurrence, forward: models_gcn.py:598-610 -----------------------

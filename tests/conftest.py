@@ -39,3 +39,21 @@ def assert_csr_equal(A, B, exact=True, rtol=0.0, atol=0.0):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+def assert_adam_params_close(got, ref, v_ref, step, ill, key, rel=2e-5, lr=1e-3):
+    """Variables after ``step + 1`` TF-form Adam steps (lr 1e-3) against the oracle's.  The update
+    lr_t * m / (sqrt(v) + eps) is ~ +-lr whenever the gradient RMS is >> eps = 1e-8 and ill-conditioned
+    where it is 1e-8 .. 1e-6 (there an fp32 round-off in g changes the quotient): ``rel`` relative to
+    max|ref| on the well-conditioned elements (RMS gradient > 1e-5, or exactly zero; once an element was
+    ill-conditioned it stays excluded -- ``ill`` carries that mask between steps), and nothing moves by
+    more than one learning rate per step anywhere."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    d = np.abs(got - ref)
+    scale = max(np.abs(ref).max(), 1e-30)
+    rms = np.sqrt(np.asarray(v_ref, np.float64) / (1 - 0.999 ** (step + 1)))
+    ill[key] = ill.get(key, False) | ~((rms > 1e-5) | (rms == 0))
+    well = ~ill[key]
+    if well.any():
+        assert d[well].max() <= rel * scale, 'step %d %s: rel err %.3e' % (step, key, d[well].max() / scale)
+    assert d.max() <= 1.1 * lr * (step + 1), 'step %d %s: max diff %.3e' % (step, key, d.max())

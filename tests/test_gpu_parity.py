@@ -9,7 +9,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from conftest import csr_from, load_golden
+from conftest import assert_adam_params_close, csr_from, load_golden
 from oracle import coarsening_ref as CR
 from oracle import graph_ref as GR
 from oracle import layers_ref as R
@@ -420,7 +420,7 @@ def test_train_step_vs_oracle(ops, dev, name):
     labels = np.arange(x.shape[0]) % int(z['M'][-1])
     xs = to_storage(ops, x, dev)
     ld = torch.as_tensor(labels).to(dev)
-    state = {}
+    state, ill = {}, {}
     for step in range(3):
         logits, cache = onet.forward(params, x)
         loss, dlogits = onet.loss(params, logits, labels)
@@ -435,7 +435,7 @@ def test_train_step_vs_oracle(ops, dev, name):
             assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
         R.adam_tf_step(params, grads, state)
         for k in params:
-            close(net.get_var(k), params[k], rel=2e-5, what='step %d %s' % (step, k))
+            assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], step, ill, k, rel=2e-5 if step == 0 else 1e-4)
 
 
 def test_second_stream_for_bwd_w_is_bit_identical(ops, dev):
@@ -514,20 +514,14 @@ def _run_fwd_bwd(ops, g, x, G, K):
 
 @pytest.mark.parametrize('lvl,B,Fin,K', [(0, 3, 3, 5), (1, 2, 5, 6), (3, 1, 1, 2)])
 def test_four_plane_kernel_matches_two_plane(ops, dev, lvl, B, Fin, K):
-    """chebgcn_tune(1, 4): only active vertices on chip, isolated ("fake") vertices patched
-    in by the streaming code.  Same summation order as the default kernel, so the two agree
+    """chebgcn_graph_create_planes(..., 4): only active vertices on chip, isolated ("fake") vertices
+    patched in by the streaming code.  Same summation order as the default kernel, so the two agree
     to the last few ulps."""
-    from gcn_fmri_decoding_amd import _lib
     L = levels()[lvl]
     M = L.shape[0]
     torch.manual_seed(lvl)
-    _lib.lib().chebgcn_tune(1, 2)
-    try:
-        g2 = ops.Graph(L, dev)
-        _lib.lib().chebgcn_tune(1, 4)
-        g4 = ops.Graph(L, dev)
-    finally:
-        _lib.lib().chebgcn_tune(1, 0)
+    g2 = ops.Graph(L, dev, planes=2)
+    g4 = ops.Graph(L, dev, planes=4)
     assert g2.query(6) == 2
     assert g4.query(6) == 4 and g4.query(7) <= M
     assert ops.Graph(L, dev).query(6) == 4               # the automatic choice for a small graph
@@ -551,14 +545,11 @@ def test_four_plane_large_graph_kernel(ops, dev, nodes, B, Fin, K):
     Ls, perm, _ = graph.synthetic_graph(nodes, k=8, levels=1)
     L = Ls[0]
     M = L.shape[0]
-    g2 = ops.Graph(L, dev)
+    g2 = ops.Graph(L, dev, planes=2)
     assert g2.query(6) == 2
-    _lib.lib().chebgcn_tune(1, 4)
-    try:
-        g4 = ops.Graph(L, dev)
-    finally:
-        _lib.lib().chebgcn_tune(1, 0)
+    g4 = ops.Graph(L, dev, planes=4)
     assert g4.query(6) == 4 and 2048 < g4.query(7) < M        # some vertices are isolated
+    assert ops.Graph(L, dev).query(6) == 4                    # and four planes are the automatic choice
     torch.manual_seed(nodes + K)
     x = torch.randn(B, Fin, g2.Mp, device=dev)
     G = torch.randn(K, B, Fin, g2.Mp, device=dev)
@@ -583,17 +574,20 @@ def test_four_plane_large_graph_kernel(ops, dev, nodes, B, Fin, K):
     assert torch.equal(s4b[:, :, :, :M], s4[:, :, :, :M])
 
 
+@pytest.mark.parametrize('planes', [2, 0])
 @pytest.mark.parametrize('nodes', [1500, 2600, 6000, 13000])
-def test_recurrence_other_kernel_shapes(ops, dev, nodes):
-    """Graph sizes that select the other workgroup shapes of the on-chip kernel (256/512/768 threads,
-    8..24 rows per thread, with and without LDS-resident id records): forward against the oracle on
-    two planes, adjoint by the identity <T(x), G> = <x, T*(G)>."""
+def test_recurrence_other_kernel_shapes(ops, dev, nodes, planes):
+    """Graph sizes that select the other workgroup shapes of the on-chip kernels -- two planes
+    (256/512/768 threads, 8..32 rows per thread, with and without LDS-resident id records) and four
+    planes (generic kernel up to 2048 rows; recurrence4.hip with 10 or 20 rows per thread beyond):
+    forward against the oracle on two planes, adjoint by the identity <T(x), G> = <x, T*(G)>."""
     from gcn_fmri_decoding_amd import _lib, graph
     Ls, perm, _ = graph.synthetic_graph(nodes, k=8, levels=1)
     L = Ls[0]
     M = L.shape[0]
-    g = ops.Graph(L, dev)
-    assert g.query(3) == 1 and g.query(6) == (4 if nodes <= 1500 else 2)      # automatic: 4 planes up to 2048 rows
+    g = ops.Graph(L, dev, planes=planes)
+    # automatic: four planes wherever 16 bytes per active vertex fit the LDS (up to ~10.2k active vertices)
+    assert g.query(3) == 1 and g.query(6) == (2 if planes == 2 or nodes > 10000 else 4)
     B, Fin, K = 2, 3, 5
     torch.manual_seed(nodes)
     x = torch.randn(B, Fin, g.Mp, device=dev)

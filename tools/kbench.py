@@ -31,8 +31,7 @@ def main():
                                                      'contract_bwd_w', 'contract_bwd_x', 'brelu_pool_bwd'])
     ap.add_argument('--ablate', type=int, nargs='+', default=[0])
     ap.add_argument('--json', default=None)
-    ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (chebgcn_tune(1, P))')
-    ap.add_argument('--slot-order', type=int, default=-1, help='chebgcn_tune(2, x): 0 component-major, 1 vertex-major slots')
+    ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (0 = automatic, 2, 4)')
     ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
     ap.add_argument('--stagger', type=int, default=0, help='chebgcn_tune(4, x): start stagger override (x-1 eighths), 0 = automatic')
     ap.add_argument('--wide', type=int, default=0, help='chebgcn_tune(3, x): 1 = 1024-thread recurrence shape')
@@ -44,11 +43,15 @@ def main():
     dev = torch.device('cuda:0')
     Ls, perm = bench.load_graph(10000, 1, 0, 1, None)
     lib = _lib.lib()
-    lib.chebgcn_tune(1, args.planes)
-    lib.chebgcn_tune(2, args.slot_order)
-    lib.chebgcn_tune(3, args.wide)
-    lib.chebgcn_tune(4, args.stagger)
-    g = ops.Graph(Ls[0], dev)
+    import ctypes
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    tune = getattr(handle, 'chebgcn_tune', None)          # experiment builds only (tools/xbuild.sh, CHEBGCN_LIB=...)
+    if tune is None and (args.wide or args.stagger or args.ablate != [0] or args.stamps):
+        raise SystemExit('--wide / --stagger / --ablate / --stamps need an experiment build (tools/xbuild.sh)')
+    if tune is not None:
+        tune(3, args.wide)
+        tune(4, args.stagger)
+    g = ops.Graph(Ls[0], dev, planes=args.planes)
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
           g.query(11), flush=True)
     M, Mp = g.M, g.Mp
@@ -114,17 +117,18 @@ def main():
             fn, nbytes, flops = calls[name]
             abls = args.ablate if name.startswith('recurrence') else [0]
             for abl in abls:
-                lib.chebgcn_tune(0, abl)
+                if tune is not None:
+                    tune(0, abl)
                 med, best = timeit(lambda: _lib.check(fn(), name), args.iters)
-                lib.chebgcn_tune(0, 0)
+                if tune is not None:
+                    tune(0, 0)
                 r = {'kernel': name, 'B': B, 'Fin': Fin, 'Fout': Fout, 'K': K, 'ablate': abl, 'median_ms': med,
                      'min_ms': best, 'GBps': nbytes / med / 1e6, 'frac_hbm': nbytes / med / 1e6 / 8000.0,
                      'TFLOPs': flops / med / 1e9}
                 results.append(r)
                 if args.stamps and name.startswith('recurrence'):
-                    import ctypes
                     buf = (ctypes.c_longlong * (16 * 64))()
-                    assert (lib.chebgcn_debug_stamps4 if g.query(6) == 4 else lib.chebgcn_debug_stamps)(buf) == 0
+                    assert (handle.chebgcn_debug_stamps4 if g.query(6) == 4 and g.query(7) > 2048 else handle.chebgcn_debug_stamps)(buf) == 0
                     t = np.array(buf, dtype=np.int64).reshape(16, 64)
                     t0 = t[:, 0][t[:, 0] > 0].min()
                     print('   stamps (cycle counter ticks since the first wave entered the group), one row per wave:')
