@@ -74,6 +74,7 @@ __device__ __forceinline__ void set_comp(float4& v, int i, float x) {
 // would occupy registers for the whole kernel and spill.
 __device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ uint2 opaque(uint2 x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); return x; }
+__device__ __forceinline__ float4 opaque(float4 x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); return x; }
 
 // LDS entries a workgroup shape can hold: one per ranked row (+ zero slot, rounded), capped by
 // the 160 KB of a CU.  For P = 4 the image holds only active vertices, all of them ranked.
@@ -509,11 +510,15 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
                     // the first two quads always (zero-padded), the third for rows beyond 8 entries
+                    // (the ring value passes through an opaque identity at its use: without it hipcc hoists the
+                    // copy that prepares .w as a v_pk_fma operand into the block of the CONDITIONAL third-quad
+                    // request, where it needs `s_waitcnt vmcnt(0)` right behind the load -- the whole operator
+                    // ring drained once per level)
                     if (gather && q == 2 && len > 8 && len <= 10) {
                         // a third quad of two entries: their ids are the .z word of the value record
-                        const float4 v = rv[(QMAX * j + q) % RING];
+                        const float4 v = opaque(rv[(QMAX * j + q) % RING]);
                         pair(__float_as_uint(v.z), v.x, v.y, acc);
-                    } else if (gather && (q < 2 || len > 10)) quad(ids_of(j, q), rv[(QMAX * j + q) % RING], acc);
+                    } else if (gather && (q < 2 || len > 10)) quad(ids_of(j, q), opaque(rv[(QMAX * j + q) % RING]), acc);
                     if (j + 2 < NJ) {
                         request(j + 2, q);                       // refill the slots just consumed
                         if ((q & 1) || q == QMAX - 1) request_ids(j + 2, q >> 1);

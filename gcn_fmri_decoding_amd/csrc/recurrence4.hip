@@ -95,6 +95,7 @@ __device__ __forceinline__ void add_comp(float4& v, int i, float x) {
 // occupy registers for the whole kernel.
 __device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ uint2 opaque(uint2 x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); return x; }
+__device__ __forceinline__ float4 opaque(float4 x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); return x; }
 __device__ __forceinline__ float4 fma4(float s, const float4& t, const float4& a) {
     return make_float4(fmaf(s, t.x, a.x), fmaf(s, t.y, a.y), fmaf(s, t.z, a.z), fmaf(s, t.w, a.w));
 }
@@ -141,6 +142,15 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     for (int u = 0; u < NQ; ++u) {
         const int q = tid + u * NT4;
         nsreg[u] = (q < Mq) ? reinterpret_cast<const uint2*>(e.nodeslot)[q] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+    unsigned isomask = 0;                            // bit 4u+i: vertex i of piece u is isolated (inside the graph, no slot)
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int q = tid + u * NT4;
+        const unsigned w[2] = {nsreg[u].x, nsreg[u].y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (((w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) == 0xFFFFu && 4 * q + i < M) isomask |= 1u << (4 * u + i);
     }
     int2 gtab = make_int2(0, 0);                     // lane j: {quad offset, length} of group j*8 + wave
     if (lane < NJ && lane * NW4 + wave < e.ngroups) gtab = e.ginfo[lane * NW4 + wave];
@@ -194,76 +204,111 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             for (int p = 0; p < 4; ++p) gx[u][p] = zero4;
     };
 
-    // Stores the four planes of one linear piece of a forward slab.  t[i] = LDS entry of vertex 4q+i
-    // (zero for a vertex without a slot: pads, and isolated vertices in odd slabs).  In an even slab an
-    // isolated vertex holds iso_sign * x: such a piece re-reads its 16 bytes of T_0 (slab 0 of dst).
-    auto store_piece = [&](rsrc_t out, int g, int u, const unsigned (&id)[4], const float4 (&t)[4], float iso_sign) {
-        const int q = tid + u * NT4;
-        unsigned iso = 0;
+    // Forward: x (= T_0, read from src) of the pieces that hold isolated vertices, for the even slabs,
+    // where such a vertex is (-1)^(k/2) x.  Lanes whose piece has none address beyond the slab: zeros,
+    // no memory access.  All requests of a batch of pieces are issued together (one latency).
+    auto load_patch = [&](float4 (*px)[4], int g, int u0, int u1) {
+        const rsrc_t rs = slab_rsrc(src, slab_bytes);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (id[i] == 0xFFFFu && 4 * q + i < M) iso |= 1u << i;
+        for (int u = u0; u < u1; ++u) {
+            const unsigned vo = ((isomask >> (4 * u)) & 15u) ? vb : 0x80000000u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) px[u - u0][p] = ldp(rs, vo, plane_off(g, p, u));
+        }
+    };
+    // Stores the four planes of one linear piece of a forward slab.  t[i] = LDS entry of vertex 4q+i
+    // (zero for a vertex without a slot: pads, and isolated vertices in odd slabs); x = the patch.
+    auto store_piece = [&](rsrc_t out, int g, int u, const float4 (&t)[4], float iso_sign, const float4 (&x)[4]) {
+        const unsigned iso = (isomask >> (4 * u)) & 15u;
         float4 o[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) o[p] = plane_of_entries(t, p);
-        if (iso_sign != 0.f && iso != 0) {
+        if (iso_sign != 0.f) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const float4 x = ldp(rs_t0, vb, plane_off(g, p, u));
-                if (iso & 1u) o[p].x = iso_sign * x.x;
-                if (iso & 2u) o[p].y = iso_sign * x.y;
-                if (iso & 4u) o[p].z = iso_sign * x.z;
-                if (iso & 8u) o[p].w = iso_sign * x.w;
+                if (iso & 1u) o[p].x = iso_sign * x[p].x;
+                if (iso & 2u) o[p].y = iso_sign * x[p].y;
+                if (iso & 4u) o[p].z = iso_sign * x[p].z;
+                if (iso & 8u) o[p].w = iso_sign * x[p].w;
             }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) stp(out, vb, plane_off(g, p, u), o[p]);
     };
-
-    // The pass between two groups: the final image of group `pg` (forward: slab K-1; adjoint: dx)
-    // goes out and the input of group `ng` (in gx) takes its place, piece by piece, by the thread
-    // that owns the piece in every linear phase -- no barrier between the read and the overwrite.
-    auto turn_over = [&](bool have_prev, int pg, bool have_next, int ng) {
-        const rsrc_t rs_out = slab_rsrc(ADJ ? dst : dst + (size_t)(K - 1) * slab, slab_bytes);   // dx / slab K-1
+    // One slab of the forward stack from the LDS image, pieces [u0, u1), patch values in px
+    auto copy_out = [&](rsrc_t out, int g, float iso_sign, float4 (*px)[4], int u0, int u1) {
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) {
+        for (int u = u0; u < u1; ++u) {
             const int q = tid + u * NT4;
             if (q < Mq) {
                 unsigned id[4];
                 ids_of_piece(u, id);
-                if (have_prev) {
+                float4 t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
+                store_piece(out, g, u, t, iso_sign, px[u - u0]);
+            }
+        }
+    };
+
+    // The pass between two groups: the final image of group `pg` (forward: slab K-1; adjoint: dx)
+    // goes out and the input of group `ng` (already in gx) takes its place.  Every linear piece is read
+    // and then overwritten by the thread that owns it in every linear phase: no barrier in between.
+    auto turn_over = [&](bool have_prev, int pg, bool have_next, int ng) {
+        const rsrc_t rs_out = slab_rsrc(ADJ ? dst : dst + (size_t)(K - 1) * slab, slab_bytes);   // dx / slab K-1
+        if (have_prev && !ADJ) {
+            const int ko = K - 1;
+            const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);
+            constexpr int NB = (NQ + 1) / 2;
+#pragma unroll
+            for (int u0 = 0; u0 < NQ; u0 += NB) {
+                const int u1 = u0 + NB < NQ ? u0 + NB : NQ;
+                if (iso_sign != 0.f) load_patch(gx, pg, u0, u1);
+                copy_out(rs_out, pg, iso_sign, gx, u0, u1);
+            }
+        }
+        if (have_prev && ADJ) {
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int q = tid + u * NT4;
+                if (q < Mq) {
+                    unsigned id[4];
+                    ids_of_piece(u, id);
                     float4 t[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
-                    if (!ADJ) {
-                        const int ko = K - 1;
-                        store_piece(rs_out, pg, u, id, t, (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f));
-                    } else {
-                        float4 o[4];
+                    float4 o[4];
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) o[p] = plane_of_entries(t, p);
-                        unsigned iso = 0;
+                    for (int p = 0; p < 4; ++p) o[p] = plane_of_entries(t, p);
+                    const unsigned iso = (isomask >> (4 * u)) & 15u;
+                    if (iso != 0) {                  // an isolated vertex has dx = G_0 - G_2 + G_4 - ...
+                        float sgn = 1.f;
+                        for (int m = 0; m < K; m += 2, sgn = -sgn) {
+                            const rsrc_t rs_g = slab_rsrc(src + (size_t)m * slab, slab_bytes);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (id[i] == 0xFFFFu && 4 * q + i < M) iso |= 1u << i;
-                        if (iso != 0) {              // an isolated vertex has dx = G_0 - G_2 + G_4 - ...
-                            float sgn = 1.f;
-                            for (int m = 0; m < K; m += 2, sgn = -sgn) {
-                                const rsrc_t rs_g = slab_rsrc(src + (size_t)m * slab, slab_bytes);
+                            for (int p = 0; p < 4; ++p) {
+                                const float4 xg = ldp(rs_g, vb, plane_off(pg, p, u));
 #pragma unroll
-                                for (int p = 0; p < 4; ++p) {
-                                    const float4 xg = ldp(rs_g, vb, plane_off(pg, p, u));
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        if (iso & (1u << i)) add_comp(o[p], i, sgn * comp(xg, i));
-                                }
+                                for (int i = 0; i < 4; ++i)
+                                    if (iso & (1u << i)) add_comp(o[p], i, sgn * comp(xg, i));
                             }
                         }
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) stp(rs_out, vb, plane_off(pg, p, u), o[p]);
                     }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) stp(rs_out, vb, plane_off(pg, p, u), o[p]);
                 }
-                if (have_next) {
+            }
+        }
+        if (have_next) {
+            // (requested only now: the staging registers were the patch buffer of the copy-out above;
+            // one exposed HBM latency per group of four planes, ~2 % of its time)
+            load_planes(src + in_base, ng);
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int q = tid + u * NT4;
+                if (q < Mq) {
+                    unsigned id[4];
+                    ids_of_piece(u, id);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         T[id[i] == 0xFFFFu ? zslot + 1u : id[i]] =
@@ -279,9 +324,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
 
     int grp = blockIdx.x;
     __syncthreads();
-    if (grp < ngrp) load_planes(src + in_base, grp); else clear_planes();
     turn_over(false, 0, grp < ngrp, grp);
     for (; grp < ngrp; grp += gridDim.x) {
+        CG_STAMP(0);
         CG_STAMP(1);
         __syncthreads();                             // the image of this group is complete
         CG_STAMP(2);
@@ -304,7 +349,6 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             // the first half of G_j is requested before the rotate and the second half behind it; after
             // the last step the old T_{k-1} of the own rows is not needed any more (write-only rotate),
             // and the next group's input is requested once the state is dead.
-            const int nxt = grp + (int)gridDim.x;
             constexpr int NH = NQ / 3;                     // a third before the rotate (its chunk registers are live), the rest behind
             const float* gj = src + (size_t)(K - 1 - sdone) * slab;                // G_j of the finished step (adjoint)
             if (ADJ) load_planes(gj, grp, 0, NH);
@@ -328,7 +372,6 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 }
             }
             if (ADJ) load_planes(gj, grp, NH, NQ);
-            else if (last) { if (nxt < ngrp) load_planes(src, nxt); else clear_planes(); }
             CG_STAMP(4 * sdone + 2);
             __syncthreads();
             CG_STAMP(4 * sdone + 3);
@@ -353,7 +396,6 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                         }
                     }
                 }
-                if (last) { if (nxt < ngrp) load_planes(src + in_base, nxt); else clear_planes(); }
                 __syncthreads();
             }
         };
@@ -384,14 +426,14 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             auto request_ids = [&](int j, int o) {
                 int qoff, len;
                 group_info(j, qoff, len);
-                if (o >= 1 && len <= 10) return;
+                if (o >= 1 && len <= 10) return;               // the second record only beyond 10 entries
                 const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(colo_rsrc, lane * 16, ((qoff >> 1) + o) * 1024, 0);
                 ro[(QO * j + o) % ORING] = make_uint4(c.x, c.y, c.z, c.w);
             };
             auto request = [&](int j, int q) {
                 int qoff, len;
                 group_info(j, qoff, len);
-                if (q >= 2 && len <= 8) return;
+                if (q >= 2 && len <= 8) return;                // the third quad only where a row needs it
                 const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(valq_rsrc, lane * 16, (qoff + q) * 1024, 0);
                 rv[(QMAX * j + q) % RING] = make_float4(v.x, v.y, v.z, v.w);
             };
@@ -435,10 +477,13 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
                     // the first two quads always (zero-padded), the third for rows beyond 8 entries
+                    // (ring values pass through an opaque identity at their use: otherwise hipcc hoists a copy
+                    // of a component into the block of the conditional request, with `s_waitcnt vmcnt(0)` right
+                    // behind the load -- see recurrence.hip)
                     if (q == 2 && len > 8 && len <= 10) {
-                        const float4 v = rv[(QMAX * j + q) % RING];
+                        const float4 v = opaque(rv[(QMAX * j + q) % RING]);
                         pair(__float_as_uint(v.z), v.x, v.y, acc);
-                    } else if (q < 2 || len > 10) quad(ids_of(j, q), rv[(QMAX * j + q) % RING], acc);
+                    } else if (q < 2 || len > 10) quad(ids_of(j, q), opaque(rv[(QMAX * j + q) % RING]), acc);
                     if (j + 2 < NJ) {
                         request(j + 2, q);                       // refill the slots just consumed
                         if ((q & 1) || q == QMAX - 1) request_ids(j + 2, q >> 1);
@@ -459,17 +504,12 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             // waves that finish their rows early stream while the others still gather; kept out of the
             // gather loop: its 40-odd temporaries do not fit next to the row state and the operator ring
             if (do_out) {
+                constexpr int NB = (NQ + 1) / 2;     // two batches: the patch of all pieces does not fit next to the row state
 #pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const int q = tid + u * NT4;
-                    if (q < Mq) {
-                        unsigned id[4];
-                        ids_of_piece(u, id);
-                        float4 t[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
-                        store_piece(out_slab, grp, u, id, t, iso_sign);
-                    }
+                for (int u0 = 0; u0 < NQ; u0 += NB) {
+                    const int u1 = u0 + NB < NQ ? u0 + NB : NQ;
+                    if (iso_sign != 0.f) load_patch(gx, grp, u0, u1);      // gx is idle during the steps of the forward pass
+                    copy_out(out_slab, grp, iso_sign, gx, u0, u1);
                 }
             }
         }
