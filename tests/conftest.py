@@ -41,7 +41,7 @@ def golden():
     return load_golden
 
 
-def assert_adam_params_close(got, ref, v_ref, step, ill, key, rel=2e-5, lr=1e-3):
+def assert_adam_params_close(got, ref, v_ref, step, ill, key, rel=2e-5, lr=1e-3, quantile=1.0):
     """Variables after ``step + 1`` TF-form Adam steps (lr 1e-3) against the oracle's.  The update
     lr_t * m / (sqrt(v) + eps) is ~ +-lr whenever the gradient RMS is >> eps = 1e-8 and ill-conditioned
     where it is 1e-8 .. 1e-6 (there an fp32 round-off in g changes the quotient): ``rel`` relative to
@@ -55,5 +55,7 @@ def assert_adam_params_close(got, ref, v_ref, step, ill, key, rel=2e-5, lr=1e-3)
     ill[key] = ill.get(key, False) | ~((rms > 1e-5) | (rms == 0))
     well = ~ill[key]
     if well.any():
-        assert d[well].max() <= rel * scale, 'step %d %s: rel err %.3e' % (step, key, d[well].max() / scale)
+        # quantile < 1 (later steps): a ReLU flipping on one side only moves single elements by a whole update
+        worst = d[well].max() if quantile >= 1.0 else np.quantile(d[well], quantile)
+        assert worst <= rel * scale, 'step %d %s: rel err %.3e' % (step, key, worst / scale)
     assert d.max() <= 1.1 * lr * (step + 1), 'step %d %s: max diff %.3e' % (step, key, d.max())

@@ -435,7 +435,7 @@ def test_train_step_vs_oracle(ops, dev, name):
             assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
         R.adam_tf_step(params, grads, state)
         for k in params:
-            assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], step, ill, k, rel=2e-5 if step == 0 else 1e-4)
+            assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], step, ill, k, rel=2e-5 if step == 0 else 1e-4, quantile=1.0 if step == 0 else 0.999)
 
 
 def test_second_stream_for_bwd_w_is_bit_identical(ops, dev):
