@@ -311,12 +311,11 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
     int planes = 0;
     if ((size_t)kLdsBytes <= (size_t)prop.maxSharedMemoryPerMultiProcessor) {
         // 2 planes per workgroup keep every vertex on chip; 4 planes (only the active vertices on
-        // chip, 16 bytes each) halve the operator stream per plane.  Measured on MI355X: up to 2048
-        // rows (the sizes of real brain atlases, 246..1000 nodes) the generic kernel with 4 planes is
-        // 1.1-2x faster and is the automatic choice; beyond, the four-plane kernel of recurrence4.hip
-        // gathers 1.35x faster per plane but loses that again to its 512-thread shape, the patching of
-        // isolated vertices and register pressure (0.69-0.76 ms against 0.58-0.63 ms at the north-star
-        // shape), so there 4 planes are opt-in (chebgcn_graph_create_planes).
+        // chip, 16 bytes each) halve the operator stream per plane.  Measured on MI355X (same box, A/B):
+        // up to 2048 rows (the sizes of real brain atlases, 246..1000 nodes) the generic kernel with 4
+        // planes is 1.1-2x faster; beyond, the kernel of recurrence4.hip is 1.07x (adjoint) to 1.19x
+        // (forward) faster at the north-star shape of the benchmark graph (10000 active vertices).
+        // Automatic choice: 4 planes wherever a four-plane kernel shape exists.
         planes = planes_for(M) >= 2 ? 2 : 0;
         const int rows = ((nactive + 63) / 64) * 64, entries = (nactive + 2 + 3) & ~3;
         const bool small4 = planes_for(nactive) == 4 && generic4_fits(rows, g->Mp / 4);
@@ -325,7 +324,7 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
             delete g;
             return fail(CHEBGCN_EUNSUPPORTED, "graph_create: no four-plane kernel for %d active of %d vertices", nactive, M);
         }
-        if (want_planes == 4 || (want_planes == 0 && small4)) planes = 4;
+        if (want_planes == 4 || (want_planes == 0 && (small4 || big4))) planes = 4;
     }
     g->lds_ok = planes != 0;
     int rc = build_ell(M, g->Mp, planes, active, rp, ci, va, &g->fwd);

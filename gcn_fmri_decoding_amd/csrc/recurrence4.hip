@@ -75,6 +75,9 @@ __device__ __forceinline__ void stp(rsrc_t r, unsigned voff, unsigned soff, floa
     // reads the data (so nothing overwrites the registers before it) and supplies the wait states.
     asm volatile("s_nop 1" : : "v"(t) : "memory");
 }
+__device__ __forceinline__ void stp1(rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 2);      // (the builtin's data operand is an integer)
+}
 // byte offset of the 16-byte LDS entry named by the low / high 16 bits of w: one VALU op
 __device__ __forceinline__ unsigned ofs_lo(unsigned w) {
     unsigned r;
@@ -204,9 +207,12 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             for (int p = 0; p < 4; ++p) gx[u][p] = zero4;
     };
 
-    // Forward: x (= T_0, read from src) of the pieces that hold isolated vertices, for the even slabs,
-    // where such a vertex is (-1)^(k/2) x.  Lanes whose piece has none address beyond the slab: zeros,
-    // no memory access.  All requests of a batch of pieces are issued together (one latency).
+    // Forward, isolated vertices (no LDS slot): T_k = 0 for odd k, (-1)^(k/2) x for even k.  The copy-outs
+    // below write what the zero slot gives (0) everywhere; the even slabs of a group are put right in ONE
+    // pass when the group is turned over: the pieces that hold an isolated vertex re-read their 16 bytes
+    // of x (other lanes address beyond the slab: zeros, no memory access; all requests of a batch
+    // together: one latency) and store +-x over the zeros, 4 bytes at a time, in every even slab.
+    // (Patching each slab as it goes out cost one exposed memory latency per even slab and batch.)
     auto load_patch = [&](float4 (*px)[4], int g, int u0, int u1) {
         const rsrc_t rs = slab_rsrc(src, slab_bytes);
 #pragma unroll
@@ -216,27 +222,25 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             for (int p = 0; p < 4; ++p) px[u - u0][p] = ldp(rs, vo, plane_off(g, p, u));
         }
     };
-    // Stores the four planes of one linear piece of a forward slab.  t[i] = LDS entry of vertex 4q+i
-    // (zero for a vertex without a slot: pads, and isolated vertices in odd slabs); x = the patch.
-    auto store_piece = [&](rsrc_t out, int g, int u, const float4 (&t)[4], float iso_sign, const float4 (&x)[4]) {
-        const unsigned iso = (isomask >> (4 * u)) & 15u;
-        float4 o[4];
+    auto fix_isolated = [&](float4 (*px)[4], int g, int u0, int u1) {
+        float sgn = -1.f;
+        for (int k = 2; k < K; k += 2, sgn = -sgn) {
+            const rsrc_t rs = slab_rsrc(dst + (size_t)k * slab, slab_bytes);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) o[p] = plane_of_entries(t, p);
-        if (iso_sign != 0.f) {
+            for (int u = u0; u < u1; ++u) {
+                const unsigned iso = (isomask >> (4 * u)) & 15u;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (iso & 1u) o[p].x = iso_sign * x[p].x;
-                if (iso & 2u) o[p].y = iso_sign * x[p].y;
-                if (iso & 4u) o[p].z = iso_sign * x[p].z;
-                if (iso & 8u) o[p].w = iso_sign * x[p].w;
+                for (int i = 0; i < 4; ++i)
+                    if (iso & (1u << i)) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) stp1(rs, vb + 4u * i, plane_off(g, p, u), sgn * comp(px[u - u0][p], i));
+                    }
             }
         }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) stp(out, vb, plane_off(g, p, u), o[p]);
     };
-    // One slab of the forward stack from the LDS image, pieces [u0, u1), patch values in px
-    auto copy_out = [&](rsrc_t out, int g, float iso_sign, float4 (*px)[4], int u0, int u1) {
+    // One slab of the forward stack from the LDS image, pieces [u0, u1): t[i] = LDS entry of vertex 4q+i
+    // (zero for a vertex without a slot: pads and isolated vertices)
+    auto copy_out = [&](rsrc_t out, int g, int u0, int u1) {
 #pragma unroll
         for (int u = u0; u < u1; ++u) {
             const int q = tid + u * NT4;
@@ -246,7 +250,8 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 float4 t[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
-                store_piece(out, g, u, t, iso_sign, px[u - u0]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) stp(out, vb, plane_off(g, p, u), plane_of_entries(t, p));
             }
         }
     };
@@ -257,52 +262,92 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     auto turn_over = [&](bool have_prev, int pg, bool have_next, int ng) {
         const rsrc_t rs_out = slab_rsrc(ADJ ? dst : dst + (size_t)(K - 1) * slab, slab_bytes);   // dx / slab K-1
         if (have_prev && !ADJ) {
-            const int ko = K - 1;
-            const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);
+            // gx holds the next group's input (requested behind the last rotate); the x of the isolated
+            // vertices goes through registers of its own, which overlay the row state that died with that
+            // rotate: first batch requested before the copy-out of the last slab, second behind it
             constexpr int NB = (NQ + 1) / 2;
-#pragma unroll
-            for (int u0 = 0; u0 < NQ; u0 += NB) {
-                const int u1 = u0 + NB < NQ ? u0 + NB : NQ;
-                if (iso_sign != 0.f) load_patch(gx, pg, u0, u1);
-                copy_out(rs_out, pg, iso_sign, gx, u0, u1);
+            float4 px[NB][4];
+            const bool fix = K > 2;                  // an even slab beyond T_0 exists
+            if (fix) load_patch(px, pg, 0, NB);
+            copy_out(rs_out, pg, 0, NQ);
+            if (fix) {
+                fix_isolated(px, pg, 0, NB);
+                load_patch(px, pg, NB, NQ);
+                fix_isolated(px, pg, NB, NQ);
             }
         }
         if (have_prev && ADJ) {
+            // dx = the final image; an isolated vertex (no slot) has dx = G_0 - G_2 + G_4 - ...: the pieces
+            // that hold one re-read their 16 bytes of those gradient slabs (other lanes address out of
+            // range: no memory access).  Two pieces at a time, up to three slabs per round trip, all
+            // requests of a round issued together into the idle staging registers.
+            constexpr int NB = 2, NS = NQ / NB >= 3 ? 3 : NQ / NB;
+            static_assert(NB * NS <= NQ, "the staging registers hold a round of patch requests");
 #pragma unroll
-            for (int u = 0; u < NQ; ++u) {
-                const int q = tid + u * NT4;
-                if (q < Mq) {
-                    unsigned id[4];
-                    ids_of_piece(u, id);
-                    float4 t[4];
+            for (int u0 = 0; u0 < NQ; u0 += NB) {
+                float4 acc[NB][4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
-                    float4 o[4];
+                for (int uu = 0; uu < NB; ++uu)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) o[p] = plane_of_entries(t, p);
-                    const unsigned iso = (isomask >> (4 * u)) & 15u;
-                    if (iso != 0) {                  // an isolated vertex has dx = G_0 - G_2 + G_4 - ...
-                        float sgn = 1.f;
-                        for (int m = 0; m < K; m += 2, sgn = -sgn) {
-                            const rsrc_t rs_g = slab_rsrc(src + (size_t)m * slab, slab_bytes);
+                    for (int p = 0; p < 4; ++p) acc[uu][p] = zero4;
+                float sgn = 1.f;
+                for (int m0 = 0; m0 < K; m0 += 2 * NS) {
 #pragma unroll
-                            for (int p = 0; p < 4; ++p) {
-                                const float4 xg = ldp(rs_g, vb, plane_off(pg, p, u));
+                    for (int sidx = 0; sidx < NS; ++sidx) {
+                        const int m = m0 + 2 * sidx;
+                        const rsrc_t rs_g = slab_rsrc(src + (size_t)(m < K ? m : 0) * slab, slab_bytes);
 #pragma unroll
-                                for (int i = 0; i < 4; ++i)
-                                    if (iso & (1u << i)) add_comp(o[p], i, sgn * comp(xg, i));
-                            }
+                        for (int uu = 0; uu < NB; ++uu) {
+                            const int u = u0 + uu;
+                            const bool want = u < NQ && m < K && ((isomask >> (4 * (u < NQ ? u : 0))) & 15u) != 0;
+                            const unsigned vo = want ? vb : 0x80000000u;
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) gx[sidx * NB + uu][p] = ldp(rs_g, vo, plane_off(pg, p, u < NQ ? u : 0));
                         }
                     }
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) stp(rs_out, vb, plane_off(pg, p, u), o[p]);
+                    for (int sidx = 0; sidx < NS; ++sidx) {
+                        const float sg = (sidx & 1) ? -sgn : sgn;          // out-of-range requests returned zeros
+#pragma unroll
+                        for (int uu = 0; uu < NB; ++uu)
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) {
+                                acc[uu][p].x = fmaf(sg, gx[sidx * NB + uu][p].x, acc[uu][p].x);
+                                acc[uu][p].y = fmaf(sg, gx[sidx * NB + uu][p].y, acc[uu][p].y);
+                                acc[uu][p].z = fmaf(sg, gx[sidx * NB + uu][p].z, acc[uu][p].z);
+                                acc[uu][p].w = fmaf(sg, gx[sidx * NB + uu][p].w, acc[uu][p].w);
+                            }
+                    }
+                    if (NS & 1) sgn = -sgn;
+                }
+#pragma unroll
+                for (int uu = 0; uu < NB; ++uu) {
+                    const int u = u0 + uu;
+                    const int q = tid + u * NT4;
+                    if (u < NQ && q < Mq) {
+                        unsigned id[4];
+                        ids_of_piece(u, id);
+                        float4 t[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
+                        const unsigned iso = (isomask >> (4 * u)) & 15u;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            float4 o = plane_of_entries(t, p);
+                            if (iso & 1u) o.x = acc[uu][p].x;
+                            if (iso & 2u) o.y = acc[uu][p].y;
+                            if (iso & 4u) o.z = acc[uu][p].z;
+                            if (iso & 8u) o.w = acc[uu][p].w;
+                            stp(rs_out, vb, plane_off(pg, p, u), o);
+                        }
+                    }
                 }
             }
         }
         if (have_next) {
-            // (requested only now: the staging registers were the patch buffer of the copy-out above;
-            // one exposed HBM latency per group of four planes, ~2 % of its time)
-            load_planes(src + in_base, ng);
+            // adjoint (and the very first group): requested only now -- the staging registers were the
+            // patch buffer of the dx copy-out above; forward: requested behind the last rotate
+            if (ADJ || !have_prev) load_planes(src + in_base, ng);
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
                 const int q = tid + u * NT4;
@@ -372,6 +417,10 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 }
             }
             if (ADJ) load_planes(gj, grp, NH, NQ);
+            else if (last) {                         // the row state is dead: the next group's input may come
+                const int nxt = grp + (int)gridDim.x;
+                if (nxt < ngrp) load_planes(src, nxt); else clear_planes();
+            }
             CG_STAMP(4 * sdone + 2);
             __syncthreads();
             CG_STAMP(4 * sdone + 3);
@@ -405,8 +454,6 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             // forward: slab step-1 is written out while this step gathers
             const bool do_out = !ADJ && step > 1;
             const rsrc_t out_slab = slab_rsrc(dst + (size_t)(step - 1) * slab, slab_bytes);
-            const int ko = step - 1;
-            const float iso_sign = (ko & 1) ? 0.f : ((ko & 2) ? -1.f : 1.f);     // isolated vertex: T_k = 0 (odd k), (-1)^(k/2) x
 
             // ---- gather: st <- f * (A T_{k-1})[own rows] - st -----------------------------------
             // Operator entries travel through a ring of RING quads (4 entries of each of the 64 rows):
@@ -503,15 +550,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             // forward: slab step-1 (the image the gather just read) goes out now, before the barrier --
             // waves that finish their rows early stream while the others still gather; kept out of the
             // gather loop: its 40-odd temporaries do not fit next to the row state and the operator ring
-            if (do_out) {
-                constexpr int NB = (NQ + 1) / 2;     // two batches: the patch of all pieces does not fit next to the row state
-#pragma unroll
-                for (int u0 = 0; u0 < NQ; u0 += NB) {
-                    const int u1 = u0 + NB < NQ ? u0 + NB : NQ;
-                    if (iso_sign != 0.f) load_patch(gx, grp, u0, u1);      // gx is idle during the steps of the forward pass
-                    copy_out(out_slab, grp, iso_sign, gx, u0, u1);
-                }
-            }
+            if (do_out) copy_out(out_slab, grp, 0, NQ);
         }
         finish_step(K - 1, true);
         // ---- the final image goes out, the next group's input comes in -------------------------

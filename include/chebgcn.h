@@ -69,9 +69,9 @@ int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr /*host [M+1]*
                          const int32_t* colidx /*host [nnz]*/, const float* vals /*host [nnz]*/,
                          chebgcn_graph** out);
 /* The same, with the number of planes (window x feature columns) a recurrence workgroup carries
- * on chip chosen by the caller: 0 = automatic (what chebgcn_graph_create does: 4 for graphs of up
- * to 2048 active vertices, else 2), 2, or 4 (CHEBGCN_EUNSUPPORTED if 16 bytes per active vertex do
- * not fit the LDS: beyond ~10200 active vertices).  The
+ * on chip chosen by the caller: 0 = automatic (what chebgcn_graph_create does: 4 wherever 16 bytes
+ * per active vertex fit the 160 KB of LDS, i.e. up to ~10200 active vertices, else 2), 2, or 4
+ * (CHEBGCN_EUNSUPPORTED where 4 do not fit).  The
  * choice affects speed and the order of the terms inside a row sum (results agree to fp32
  * round-off). */
 int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,

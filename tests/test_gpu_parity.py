@@ -549,7 +549,7 @@ def test_four_plane_large_graph_kernel(ops, dev, nodes, B, Fin, K):
     assert g2.query(6) == 2
     g4 = ops.Graph(L, dev, planes=4)
     assert g4.query(6) == 4 and 2048 < g4.query(7) < M        # some vertices are isolated
-    assert ops.Graph(L, dev).query(6) == 2                    # beyond 2048 rows four planes are opt-in
+    assert ops.Graph(L, dev).query(6) == 4                    # and four planes are the automatic choice
     torch.manual_seed(nodes + K)
     x = torch.randn(B, Fin, g2.Mp, device=dev)
     G = torch.randn(K, B, Fin, g2.Mp, device=dev)
@@ -574,7 +574,7 @@ def test_four_plane_large_graph_kernel(ops, dev, nodes, B, Fin, K):
     assert torch.equal(s4b[:, :, :, :M], s4[:, :, :, :M])
 
 
-@pytest.mark.parametrize('planes', [0, 4])
+@pytest.mark.parametrize('planes', [0, 2])
 @pytest.mark.parametrize('nodes', [1500, 2600, 6000, 13000])
 def test_recurrence_other_kernel_shapes(ops, dev, nodes, planes):
     """Graph sizes that select the other workgroup shapes of the on-chip kernels -- two planes
@@ -585,13 +585,12 @@ def test_recurrence_other_kernel_shapes(ops, dev, nodes, planes):
     Ls, perm, _ = graph.synthetic_graph(nodes, k=8, levels=1)
     L = Ls[0]
     M = L.shape[0]
-    if planes == 4 and nodes > 10000:                       # 16 bytes per active vertex do not fit the LDS
+    if nodes > 10000:                                       # 16 bytes per active vertex do not fit the LDS
         with pytest.raises(_lib.ChebgcnError):
             ops.Graph(L, dev, planes=4)
-        return
     g = ops.Graph(L, dev, planes=planes)
-    # automatic: four planes up to 2048 rows, two beyond
-    assert g.query(3) == 1 and g.query(6) == (4 if planes == 4 or nodes <= 1500 else 2)
+    # automatic: four planes wherever 16 bytes per active vertex fit the LDS (up to ~10.2k active vertices)
+    assert g.query(3) == 1 and g.query(6) == (2 if planes == 2 or nodes > 10000 else 4)
     B, Fin, K = 2, 3, 5
     torch.manual_seed(nodes)
     x = torch.randn(B, Fin, g.Mp, device=dev)
