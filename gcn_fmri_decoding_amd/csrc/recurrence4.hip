@@ -494,7 +494,11 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 acc = fma4(v1, t1, acc);
             };
             auto quad = [&](const uint2 c, const float4 v, float4& acc) {
-                const unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
+                unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
+                if (CG_X & 512) {                    // experiment: conflict-free, still data-dependent addresses (wrong results)
+                    a0 = (a0 & 4096u) + lane * 16u; a1 = (a1 & 4096u) + lane * 16u + 1024u;
+                    a2 = (a2 & 4096u) + lane * 16u + 2048u; a3 = (a3 & 4096u) + lane * 16u + 3072u;
+                }
                 const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3);
                 acc = fma4(v.x, t0, acc);
                 acc = fma4(v.y, t1, acc);
