@@ -82,7 +82,7 @@ inline bool generic4_fits(int rows, int Mq) { return rows <= 2048 && Mq <= 768; 
 // recurrence4.hip: four-plane kernel beyond
 bool onchip4_fits(int lds_entries, int rows, int Mq);
 template <bool ADJ>
-int dispatch_onchip4(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K, int copy_t0,
+int dispatch_onchip4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
                      hipStream_t stream);
 }  // namespace chebgcn
 
@@ -95,4 +95,18 @@ struct chebgcn_graph {
     int lds_ok = 0;              // on-chip recurrence usable (LDS image fits)
     chebgcn::Ell fwd;            // L~
     chebgcn::Ell adj;            // L~^T
+    // Automatic plane choice on a big graph (four planes, recurrence4.hip): the two-plane images as well.
+    // Four planes win once a workgroup has several plane groups to work through (batch 256 at Fin = 32:
+    // 8 per CU); with one or two (batch 64) the two-plane kernel's lighter group turn-over wins.
+    int has_alt2 = 0;
+    chebgcn::Ell fwd2, adj2;
 };
+
+namespace chebgcn {
+// the operator image a launch over `nplanes` planes uses
+inline const Ell& pick_ell(const chebgcn_graph* g, bool adjoint, int nplanes) {
+    const Ell& e = adjoint ? g->adj : g->fwd;
+    if (g->has_alt2 && e.planes == 4 && (nplanes + 3) / 4 < 4 * g->num_cus) return adjoint ? g->adj2 : g->fwd2;
+    return e;
+}
+}  // namespace chebgcn

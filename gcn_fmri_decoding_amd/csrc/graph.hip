@@ -329,6 +329,13 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
     g->lds_ok = planes != 0;
     int rc = build_ell(M, g->Mp, planes, active, rp, ci, va, &g->fwd);
     if (rc == CHEBGCN_OK) rc = build_ell(M, g->Mp, planes, active, trp, tci, tva, &g->adj);
+    if (rc == CHEBGCN_OK && want_planes == 0 && planes == 4 && !generic4_fits(((nactive + 63) / 64) * 64, g->Mp / 4) &&
+        planes_for(M) >= 2) {
+        // big graph, automatic choice: small launches take the two-plane kernel (pick_ell, common.h)
+        rc = build_ell(M, g->Mp, 2, active, rp, ci, va, &g->fwd2);
+        if (rc == CHEBGCN_OK) rc = build_ell(M, g->Mp, 2, active, trp, tci, tva, &g->adj2);
+        g->has_alt2 = rc == CHEBGCN_OK;
+    }
     if (rc != CHEBGCN_OK) {
         chebgcn_graph_destroy(g);
         return rc;
@@ -341,6 +348,8 @@ extern "C" void chebgcn_graph_destroy(chebgcn_graph* g) {
     if (!g) return;
     free_ell(g->fwd);
     free_ell(g->adj);
+    free_ell(g->fwd2);
+    free_ell(g->adj2);
     delete g;
 }
 

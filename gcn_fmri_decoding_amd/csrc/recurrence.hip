@@ -628,9 +628,8 @@ static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* sr
 // P VGPRs per row slice (NJ) and 4P per linear piece (NQ = ceil(NJ/4)) next to ~70 for the
 // operator entries and temporaries; 1024 / 768 / 512 threads may use 128 / 168 / 256 VGPRs.
 template <int P, bool ADJ>
-static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K,
+static int dispatch_onchip(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K,
                            int copy_t0, hipStream_t stream) {
-    const Ell& ell = ADJ ? g->adj : g->fwd;
     const int rows = ell.ngroups * 64;
     const int Mq = g->Mp / 4;
     auto fits = [&](int nj, int nq, int nthr) {
@@ -640,7 +639,7 @@ static int dispatch_onchip(const chebgcn_graph* g, const float* src, float* dst,
     CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
     if constexpr (P == 4) {
         // beyond 2048 rows: the dedicated kernel of recurrence4.hip
-        return dispatch_onchip4<ADJ>(g, src, dst, nplanes, K, copy_t0, stream);
+        return dispatch_onchip4<ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
     } else {
         CG_TRY(8, 3, 512); CG_TRY(8, 3, 768); CG_TRY(11, 4, 768);
         if (g_wide) { CG_TRY(11, 3, 1024); }                                                  // experiment: 16 waves
@@ -697,8 +696,9 @@ extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, fl
                              stack + k * slab, nplanes, 2.f, stream);
         return rc;
     }
-    if (g->fwd.planes == 4) return dispatch_onchip<4, false>(g, x, stack, nplanes, K, copy_t0, stream);
-    return dispatch_onchip<2, false>(g, x, stack, nplanes, K, copy_t0, stream);
+    const Ell& ell = pick_ell(g, false, nplanes);
+    if (ell.planes == 4) return dispatch_onchip<4, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
+    return dispatch_onchip<2, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
 }
 
 extern "C" int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstack, float* dx, int B,
@@ -714,8 +714,9 @@ extern "C" int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstac
         return CHEBGCN_OK;
     }
     if (g->lds_ok) {
-        if (g->adj.planes == 4) return dispatch_onchip<4, true>(g, gstack, dx, nplanes, K, 0, stream);
-        return dispatch_onchip<2, true>(g, gstack, dx, nplanes, K, 0, stream);
+        const Ell& ell = pick_ell(g, true, nplanes);
+        if (ell.planes == 4) return dispatch_onchip<4, true>(g, ell, gstack, dx, nplanes, K, 0, stream);
+        return dispatch_onchip<2, true>(g, ell, gstack, dx, nplanes, K, 0, stream);
     }
     // fallback: Clenshaw with two scratch slabs; c_{j} = G_j + f L^T c_{j+1} - c_{j+2}
     float* scratch = nullptr;

@@ -48,8 +48,6 @@ __device__ long long g_dbg4[16 * 64];
 namespace {
 
 constexpr int QMAX = kQuadMin;       // quads stored for every group and requested two groups ahead
-constexpr int NT4 = 512;             // threads per workgroup
-constexpr int NW4 = NT4 / 64;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -109,11 +107,12 @@ __device__ __forceinline__ float4 plane_of_entries(const float4 (&t)[4], int p) 
 
 // ENT = LDS entries (16 B each), NJ = row slices per thread (ceil(groups / 8)), NQ = linear
 // 16-byte pieces per thread and plane (ceil(Mp/4 / 512)).
-template <int ENT, int NJ, int NQ, bool ADJ>
+template <int ENT, int NJ, int NQ, int NT4, bool ADJ>
 __global__ void __launch_bounds__(NT4)
 cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, int M, int Mp, int nplanes, int K,
              size_t slab, int flags) {
     __shared__ float4 T[ENT];                        // slot-indexed: the four planes of one vertex
+    constexpr int NW4 = NT4 / 64;
     static_assert(NJ <= 64 && NQ <= NJ && (NJ % 2) == 0, "shape");
     const int copy_t0 = flags & 1;
     const int tid = threadIdx.x;
@@ -262,15 +261,15 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     auto turn_over = [&](bool have_prev, int pg, bool have_next, int ng) {
         const rsrc_t rs_out = slab_rsrc(ADJ ? dst : dst + (size_t)(K - 1) * slab, slab_bytes);   // dx / slab K-1
         if (have_prev && !ADJ) {
-            // gx holds the next group's input (requested behind the last rotate); the x of the isolated
-            // vertices goes through registers of its own, which overlay the row state that died with that
-            // rotate: first batch requested before the copy-out of the last slab, second behind it
+            // Requests, in the order their data is needed (the vector memory pipeline returns in order): x
+            // of the isolated vertices of the first half of the pieces, then the next group's input.  The
+            // patch registers overlay the row state, which died with the last rotate.
             constexpr int NB = (NQ + 1) / 2;
             float4 px[NB][4];
-            const bool fix = K > 2;                  // an even slab beyond T_0 exists
-            if (fix) load_patch(px, pg, 0, NB);
+            if (K > 2) load_patch(px, pg, 0, NB);
+            if (have_next) load_planes(src, ng); else clear_planes();
             copy_out(rs_out, pg, 0, NQ);
-            if (fix) {
+            if (K > 2) {
                 fix_isolated(px, pg, 0, NB);
                 load_patch(px, pg, NB, NQ);
                 fix_isolated(px, pg, NB, NQ);
@@ -417,10 +416,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 }
             }
             if (ADJ) load_planes(gj, grp, NH, NQ);
-            else if (last) {                         // the row state is dead: the next group's input may come
-                const int nxt = grp + (int)gridDim.x;
-                if (nxt < ngrp) load_planes(src, nxt); else clear_planes();
-            }
+
             CG_STAMP(4 * sdone + 2);
             __syncthreads();
             CG_STAMP(4 * sdone + 3);
@@ -564,25 +560,27 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     }
 }
 
-template <int ENT, int NJ, int NQ, bool ADJ>
+template <int ENT, int NJ, int NQ, int NT4, bool ADJ>
 int launch4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
             hipStream_t stream) {
     const int ngrp = (nplanes + 3) / 4;
     int grid = g->num_cus * ((160 * 1024) / (ENT * 16) < 1 ? 1 : (160 * 1024) / (ENT * 16));
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
-    hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, ADJ>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M, g->Mp,
+    hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, NT4, ADJ>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M, g->Mp,
                        nplanes, K, slab, copy_t0 | (g_stagger << 20));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
 
-// shape 0 = none; shapes: {entries, rows per thread, linear pieces per thread}
+// shape 0 = none; shapes: {entries, threads, rows per thread, linear pieces per thread}.  512 threads (two
+// waves per SIMD, up to 256 registers each).  A 768-thread shape (three waves per SIMD, 168 registers,
+// 14 rows per thread) was measured on the same box: forward 0.64-0.66 ms against 0.61 ms, adjoint
+// 0.69 ms against 0.61 ms at the north-star shape -- its row state spills inside the gather.
 int shape4(int lds_entries, int rows, int Mq) {
     if (generic4_fits(rows, Mq)) return 0;           // small graphs: the generic kernel of recurrence.hip
-    const int nq = (Mq + NT4 - 1) / NT4;
-    if (lds_entries <= 5120 && rows <= 10 * NT4 && nq <= 4) return nq <= 3 ? 1 : 2;
-    if (lds_entries <= 10240 && rows <= 20 * NT4 && nq <= 7) return nq <= 6 ? 3 : 4;
+    if (lds_entries <= 5120 && rows <= 10 * 512 && (Mq + 511) / 512 <= 4) return (Mq + 511) / 512 <= 3 ? 1 : 2;
+    if (lds_entries <= 10240 && rows <= 20 * 512 && (Mq + 511) / 512 <= 7) return (Mq + 511) / 512 <= 6 ? 3 : 4;
     return 0;
 }
 
@@ -591,24 +589,23 @@ int shape4(int lds_entries, int rows, int Mq) {
 bool onchip4_fits(int lds_entries, int rows, int Mq) { return shape4(lds_entries, rows, Mq) != 0; }
 
 template <bool ADJ>
-int dispatch_onchip4(const chebgcn_graph* g, const float* src, float* dst, int nplanes, int K, int copy_t0,
+int dispatch_onchip4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
                      hipStream_t stream) {
-    const Ell& ell = ADJ ? g->adj : g->fwd;
     // one slab is addressed through one buffer descriptor (32-bit offsets): larger batches go in chunks of planes
     const int max_planes = (int)((0xFFFF0000ull / ((size_t)g->Mp * sizeof(float))) & ~3ull);
     if (nplanes > max_planes) return fail(CHEBGCN_EUNSUPPORTED, "recurrence: %d planes of %d vertices exceed 4 GB per slab", nplanes, g->Mp);
     switch (shape4(ell.lds_entries, ell.ngroups * 64, g->Mp / 4)) {
-        case 1: return launch4<5120, 10, 3, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
-        case 2: return launch4<5120, 10, 4, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
-        case 3: return launch4<10240, 20, 6, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
-        case 4: return launch4<10240, 20, 7, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 1: return launch4<5120, 10, 3, 512, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 2: return launch4<5120, 10, 4, 512, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 3: return launch4<10240, 20, 6, 512, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+        case 4: return launch4<10240, 20, 7, 512, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
         default: break;
     }
     return fail(CHEBGCN_EUNSUPPORTED, "recurrence: no four-plane kernel shape for %d rows", ell.ngroups * 64);
 }
 
-template int dispatch_onchip4<false>(const chebgcn_graph*, const float*, float*, int, int, int, hipStream_t);
-template int dispatch_onchip4<true>(const chebgcn_graph*, const float*, float*, int, int, int, hipStream_t);
+template int dispatch_onchip4<false>(const chebgcn_graph*, const Ell&, const float*, float*, int, int, int, hipStream_t);
+template int dispatch_onchip4<true>(const chebgcn_graph*, const Ell&, const float*, float*, int, int, int, hipStream_t);
 
 }  // namespace chebgcn
 
