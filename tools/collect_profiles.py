@@ -12,12 +12,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'refresh')
 DST = os.path.join(ROOT, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 
 for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats.csv', '%s_bench_kernel_stats.csv'),
                  ('kbench.txt', '%s_kbench.txt'), ('kbench.json', '%s_kbench.json'),
                  ('kbench_config4.txt', '%s_kbench_config4_K25_F64.txt'), ('kbench_config5.txt', '%s_kbench_config5_bf16.txt'),
-                 ('traffic_raw.json', '%s_traffic_raw.json')]:
+                 ('traffic_raw.json', '%s_traffic_raw.json'), ('kbench_two_planes.txt', '%s_kbench_two_plane_recurrence.txt'),
+                 ('mfma.txt', '%s_contraction_mfma_counters.txt'), ('stamps4.txt', '%s_recurrence4_phase_stamps.txt'), ('mfma_counters_available.txt', '%s_mfma_counters_available.txt'),
+                 ('config4_kernel_stats.csv', '%s_config4_kernel_stats.csv'), ('config5_kernel_stats.csv', '%s_config5_kernel_stats.csv')]:
     p = os.path.join(SRC, src)
     if os.path.exists(p):
         if src.endswith('.txt') or src == 'bench_line.json':
@@ -28,8 +30,9 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
 
 raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
 names = {'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd',
+         'cheb4_kernel<10240, 20, 6, 512, false>': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true>': 'recurrence_bwd_4planes',
          'contract_fwd_kernel<1>': 'contract_fwd', 'contract_bwd_w_kernel<5>': 'contract_bwd_w',
-         'contract_bwd_x_kernel<true>': 'contract_bwd_x', 'brelu_pool_bwd_kernel<2>': 'brelu_pool_bwd'}
+         'contract_bwd_x_kernel<true>': 'contract_bwd_x', 'brelu_pool_bwd_kernel<2, 1>': 'brelu_pool_bwd'}
 out = {'_note': 'HBM bytes per launch at the bench shape (B=64, Fin=Fout=32, K=5, M=10466), rocprofv3 --pmc FETCH_SIZE and '
                 'WRITE_SIZE in separate passes with --kernel-trace only (tools/pmc_traffic.sh); bytes = (2*FETCH_SIZE + '
                 'WRITE_SIZE) KiB -- FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; '

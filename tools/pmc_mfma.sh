@@ -30,8 +30,9 @@ for k, d in sorted(acc.items()):
     m = res[k]
     line = k + ' ' + ' '.join('%s=%.4g' % (c, x) for c, x in sorted(m.items()))
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in m and 'GRBM_GUI_ACTIVE' in m and m['GRBM_GUI_ACTIVE'] > 0:
-        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD with the matrix pipe busy, summed over the chip: 256 CUs x 4 SIMDs
-        line += '  -> MfmaUtil = %.3f' % (m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] * 256 * 4))
+        # SQ_VALU_MFMA_BUSY_CYCLES: matrix-pipe busy cycles summed over the chip's 1024 SIMDs (= 64 x the number of
+        # v_mfma_f32_32x32x2_f32, 32 x the number of v_mfma_f32_32x32x16_bf16); GRBM_GUI_ACTIVE: kernel cycles summed over the 8 XCDs
+        line += '  -> MfmaUtil = %.3f' % (m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8.0 * 1024))
     print(line)
 json.dump(res, open(out + '/mfma_raw.json', 'w'), indent=1)
 PY
