@@ -151,6 +151,70 @@ def kernel_leg(lib_graph, B, Fin, K, launches, what):
     return out
 
 
+def config5_leg(lib_graph, B, Fin, K, Fout, steps):
+    """BASELINE configs[4]: one wide layer (block_dura = Fin = 60 -> Fout = 256, K = 5, per-vertex
+    bias + ReLU) trained forward + backward -- recurrence, contraction, bias/ReLU gradient,
+    contraction gradients (dW, d stack), adjoint recurrence -- with the contraction and its two
+    gradients in fp32 MFMA, bf16 and split-bf16 (``ops.cheb_conv(precision=...)``).  Reports the
+    layer step time, the per-kernel HIP-event times and the fp32 parity of the mixed-precision results
+    (max error relative to max|fp32 result| of y, dx and dW on the same layer without the ReLU)."""
+    import torch
+    from gcn_fmri_decoding_amd import ops
+    g = lib_graph
+    dev = g.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    x = torch.randn((B, Fin, g.Mp), generator=gen, device=dev)
+    x[:, :, g.M:] = 0
+    W = (torch.randn((Fin * K, Fout), generator=gen, device=dev) * (2.0 / (Fin * K)) ** 0.5).requires_grad_(True)
+    bias = (torch.randn((Fout, g.Mp), generator=gen, device=dev) * 0.1).requires_grad_(True)
+    gout = torch.randn((B, Fout, g.Mp), generator=gen, device=dev)
+    gout[:, :, g.M:] = 0
+    out = {'shape': {'B': B, 'Fin': Fin, 'K': K, 'Fout': Fout, 'M': g.M}, 'steps': steps,
+           'what': 'BASELINE configs[4]: single wide layer forward + backward, HIP kernels only (no head, no optimizer)',
+           'timing': 'wall clock over the steps between synchronisations; per-kernel HIP events on a separate instrumented pass'}
+    ref = None
+    for precision in ('f32', 'bf16', 'bf16x3'):
+        def layer_step():
+            xs = x.detach().requires_grad_(True)
+            W.grad = bias.grad = None
+            y = ops.cheb_conv(xs, W, bias, g, K, relu=True, bias_kind=ops.BIAS_VERTEX, precision=precision)
+            y.backward(gout)
+            return y, xs.grad
+        for _ in range(2):
+            layer_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y, dx = layer_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ops.timers = ops.KernelTimers()
+        for _ in range(3):
+            layer_step()
+        kern = ops.timers.summary()
+        ops.timers = None
+        # parity pass WITHOUT the ReLU: with it, pre-activations within rounding of zero flip their mask and a
+        # flipped element changes dx / dW by a whole gout -- that would measure the flips, not the arithmetic
+        xs = x.detach().requires_grad_(True)
+        W.grad = bias.grad = None
+        y = ops.cheb_conv(xs, W, bias, g, K, relu=False, bias_kind=ops.BIAS_VERTEX, precision=precision)
+        y.backward(gout)
+        res = {'y': y[:, :, :g.M].detach(), 'dx': xs.grad[:, :, :g.M], 'dW': W.grad.clone()}
+        leg = {'ms_per_step': 1e3 * dt, 'windows_per_s': B / dt,
+               'kernels': {k: {'avg_ms': v['avg_ms'], 'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
+                               'TFLOPs': v['flops'] / (v['total_ms'] * 1e-3) / 1e12} for k, v in kern.items()}}
+        if ref is None:
+            ref = res
+        else:
+            leg['rel_err_vs_f32'] = {k: float((res[k] - ref[k]).abs().max() / ref[k].abs().max()) for k in res}
+        out[precision] = leg
+        del y, dx, res
+    del x, gout
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -163,7 +227,8 @@ def main():
     ap.add_argument('--cpu-windows', type=int, default=16, help='0 disables the CPU baseline leg')
     ap.add_argument('--kernel-legs', type=int, default=1,
                     help='1: also time the recurrence kernels alone at the north-star shape (K=5, Fin=32, batch 256) and at '
-                         'configs[3] (K=25, Fin=64, batch 64); N=1 only')
+                         'configs[3] (K=25, Fin=64, batch 64), and the wide layer of configs[4] (Fin=60, Fout=256) forward + '
+                         'backward in fp32 / bf16 / split bf16; N=1 only')
     ap.add_argument('--no-timers', action='store_true')
     ap.add_argument('--overlap-bwd-w', type=int, default=0, help='experiment: contract_bwd_w on a second stream')
     ap.add_argument('--timer-every', type=int, default=4,
@@ -280,6 +345,7 @@ def main():
             line['northstar'] = kernel_leg(g0, 256, 32, 5, 50, 'north-star shape of BASELINE.json: K=5 recurrence, Fin=32, batch 256, '
                                                                'M=10466; target frac >= 0.40')
             line['config4'] = kernel_leg(g0, 64, 64, 25, 20, 'BASELINE configs[3]: K=25, Fin=Fout=64, batch 64 (SpMM-bound regime)')
+            line['config5'] = config5_leg(g0, 64, 60, 5, 256, 10)
         if world == 1 and args.cpu_windows > 0:
             line['cpu_baseline'] = cpu_baseline(Ls[:1], cfg, args.cpu_windows)
         print(json.dumps(line))

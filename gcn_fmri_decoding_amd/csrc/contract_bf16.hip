@@ -34,14 +34,15 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 // W [FinK][Fout] fp32 -> Wp[part][ks][fo][16] bf16 (part 0 = hi, 1 = lo), zero beyond FinK / Fout
 __global__ void __launch_bounds__(256)
 pack_w_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ Wp, int FinK, int Fout, int nks, int FoutP,
-                   int parts) {
+                   int parts, int ldT) {
+    // ldT > 0: the operand is the TRANSPOSE of the row-major matrix W[Fout][ldT] (bwd_x: W^T)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (ks, fo)
     if (idx >= nks * FoutP) return;
     const int ks = idx / FoutP, fo = idx - ks * FoutP;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = ks * 16 + i;
-        const float w = (r < FinK && fo < Fout) ? W[(size_t)r * Fout + fo] : 0.f;
+        const float w = (r < FinK && fo < Fout) ? (ldT > 0 ? W[(size_t)fo * ldT + r] : W[(size_t)r * Fout + fo]) : 0.f;
         const __bf16 hi = (__bf16)w;
         Wp[(size_t)idx * 16 + i] = hi;
         if (parts > 1) Wp[((size_t)nks * FoutP + idx) * 16 + i] = (__bf16)(w - (float)hi);
@@ -252,9 +253,210 @@ static bool check_pool_bf16(int pool, int M) {
     return pool >= 1 && pool <= 128 && (pool & (pool - 1)) == 0 && M % pool == 0;
 }
 
+
+// --------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores:  dW[kk][o] = sum_{b,m} stack[kk][b,m] * dy[b][o][m]
+// (the MatMul gradient of models_gcn.py:616 for wide layers -- config 5 has Fin*K = 300, Fout = 256,
+// where the fp32-input MFMA of contract.hip costs 1.7 ms).  Same scheme as contract_bwd_w_kernel: a
+// chunk = 64 consecutive vertices of one window; its (RT + CT)*32 operand rows (256 B each) come by
+// LDS-DMA with the 16-byte-piece swizzle applied on the source side; a wave owns 16 of the 64
+// vertices for all RT x CT tiles: lane (row, h) reads the pieces 2q + h (q = 0, 1) of its row, eight
+// consecutive-in-pairs vertices = exactly the K = 16 operand of v_mfma_f32_32x32x16_bf16 after the
+// in-register fp32 -> bf16 conversion (A and B use the same pieces, and the order of the vertices
+// inside a reduction is free).  CT = 2 column tiles per workgroup halve the re-reads of the stack.
+// The four waves are reduced through LDS in a fixed order, every workgroup leaves one partial and two
+// small kernels sum the partials in a fixed order: deterministic.
+struct BwdWBf16Args {
+    const float* stack; const float* dy; float* partial;
+    int B, M, Mp, Fin, K, Fout, FinK;
+    int nchunks_m;               // ceil(M / 64)
+    size_t slab;                 // B*Fin*Mp
+};
+constexpr int BWB_ROW = 64;      // floats per LDS row (one chunk)
+constexpr int BWB_SPLIT = 8;
+
+// MFMA operand of one LDS row: the float4 pieces p0 and p0 + 2 (swizzled) -> eight bf16 (hi, and lo of the split)
+template <int PASSES>
+__device__ __forceinline__ void bwb_operand(const float* lds, int row, int p0, bool tail, int m0, int M, bf16x8& hi, bf16x8& lo) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int piece = p0 + 2 * q;
+        const float4 f = *reinterpret_cast<const float4*>(lds + row * BWB_ROW + 4 * (piece ^ (row & 15)));
+        v[4 * q + 0] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+        if (tail) {
+            const int n = m0 + 4 * piece;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * q + r] = (n + r < M) ? v[4 * q + r] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = (__bf16)v[i];
+        if (PASSES == 3) lo[i] = (__bf16)(v[i] - (float)hi[i]);
+    }
+}
+
+template <int RT, int CT, int PASSES>
+__global__ void __launch_bounds__(256, 2)      // two waves per SIMD = two workgroups per CU: one fetches while the other multiplies
+contract_bwd_w_bf16_kernel(BwdWBf16Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [(RT+CT)*32][64]
+    constexpr int NROWS = (RT + CT) * 32;
+    constexpr int NDMA = NROWS / 4;                     // wave instructions per chunk (4 rows each)
+    constexpr int PER_WAVE = NDMA / 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int tile0 = blockIdx.y * RT;                  // first row tile of this group
+    const int fo0 = blockIdx.z * 32 * CT;               // first column
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int u = 0; u < CT; ++u)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][u][j] = 0.f;
+
+    // DMA instruction n = wave + 4u covers rows 4n..4n+3: lane l -> row 4n + l/16, LDS piece l%16,
+    // source piece (l%16) ^ (row%16) -- the same for every u because 16 divides the row step
+    const int rsw = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+    const float* rsrc[PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+        const int n = wave + 4 * u;
+        const int row = 4 * n + (lane >> 4);
+        if (n < RT * 8) {
+            int kk = tile0 * 32 + row;
+            if (kk >= a.FinK) kk = 0;                   // rows beyond Fin*K: dropped by the final scatter
+            const int fin = kk / a.K, k = kk - fin * a.K;
+            rsrc[u] = a.stack + (size_t)k * a.slab + (size_t)fin * a.Mp + 4 * rsw;
+        } else {
+            int fo = fo0 + (row - RT * 32);
+            if (fo >= a.Fout) fo = 0;
+            rsrc[u] = a.dy + (size_t)fo * a.Mp + 4 * rsw;
+        }
+    }
+
+    const int total = a.B * a.nchunks_m;
+    for (int ch = blockIdx.x; ch < total; ch += gridDim.x) {
+        const int b = ch / a.nchunks_m;
+        const int m0 = (ch - b * a.nchunks_m) * 64;
+        const ptrdiff_t mo = (m0 + 4 * rsw < a.Mp) ? m0 : -4 * rsw;   // beyond the plane: any valid address, masked below
+        const ptrdiff_t so = (ptrdiff_t)b * a.Fin * a.Mp + mo, dof = (ptrdiff_t)b * a.Fout * a.Mp + mo;
+        __syncthreads();                                // previous chunk's operand reads are done
+#pragma unroll
+        for (int u = 0; u < PER_WAVE; ++u) {
+            const int n = wave + 4 * u;
+            const float* src = rsrc[u] + (n < RT * 8 ? so : dof);
+            __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BWB_ROW, 16, 0, 2);   // aux 2 = nt
+        }
+        __syncthreads();                                // DMA landed (the barrier's release waits vmcnt(0))
+
+        const bool tail = m0 + 64 > a.M;                // only the last chunk of a plane has vertices to mask
+        bf16x8 bh[CT], bl[CT];
+#pragma unroll
+        for (int u = 0; u < CT; ++u) bwb_operand<PASSES>(lds, RT * 32 + u * 32 + c, 4 * wave + h, tail, m0, a.M, bh[u], bl[u]);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            bf16x8 ah, al;
+            bwb_operand<PASSES>(lds, t * 32 + c, 4 * wave + h, tail, m0, a.M, ah, al);
+#pragma unroll
+            for (int u = 0; u < CT; ++u) {
+                acc[t][u] = mfma_bf16(ah, bh[u], acc[t][u]);
+                if (PASSES == 3) {
+                    acc[t][u] = mfma_bf16(ah, bl[u], acc[t][u]);
+                    acc[t][u] = mfma_bf16(al, bh[u], acc[t][u]);
+                }
+            }
+        }
+    }
+
+    // ---- workgroup reduction in LDS (fixed order: wave 0, then +1, +2, +3) ----------------
+    constexpr int per = RT * CT * 16 * 64;
+    static_assert(per <= NROWS * BWB_ROW, "the reduction image must fit the operand buffer");
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int u = 0; u < CT; ++u)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        float* p = lds + ((t * CT + u) * 16 + j) * 64 + lane;
+                        *p = (w == 0) ? acc[t][u][j] : *p + acc[t][u][j];
+                    }
+        }
+    }
+    __syncthreads();
+    float* dst = a.partial + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * per;
+    for (int o = threadIdx.x; o < per; o += 256) dst[o] = lds[o];
+}
+
+// partial: [Z][Y][X][rows*64] raw accumulator images (rows = RT*CT*16).  Stage 1: block
+// (row, y*S + s, z) sums the partials x = s, s+S, ... of one 64-lane accumulator row.
+__global__ void __launch_bounds__(256)
+bwb_reduce_stage1(const float* __restrict__ partial, float* __restrict__ stage, int nx, int ny, int rows) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const size_t per = (size_t)rows * 64;
+    const int row = blockIdx.x;
+    const int y = blockIdx.y / BWB_SPLIT, sp = blockIdx.y % BWB_SPLIT, z = blockIdx.z;
+    const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
+    float s = 0.f;
+    for (int x = sp + BWB_SPLIT * part; x < nx; x += 4 * BWB_SPLIT) s += base[(size_t)x * per];
+    red[part][lane] = s;
+    __syncthreads();
+    if (part == 0)
+        stage[((((size_t)z * ny + y) * BWB_SPLIT + sp) * rows + row) * 64 + lane] =
+            ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// Stage 2: sum the BWB_SPLIT stage rows and scatter from the accumulator layout to dW[kk][o].
+__global__ void __launch_bounds__(64)
+bwb_reduce_stage2(const float* __restrict__ stage, float* __restrict__ dW, int ny, int rt, int ct, int FinK, int Fout) {
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+    const int rows = rt * ct * 16;
+    float s = 0.f;
+    for (int sp = 0; sp < BWB_SPLIT; ++sp)
+        s += stage[((((size_t)z * ny + y) * BWB_SPLIT + sp) * rows + row) * 64 + lane];
+    const int tu = row >> 4, j = row & 15, h = lane >> 5;
+    const int t = tu / ct, u = tu - t * ct;
+    const int kk = (y * rt + t) * 32 + acc_row(j, h);
+    const int fo = (z * ct + u) * 32 + (lane & 31);
+    if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = s;
+}
+
+struct BwbPlan { int rt, ct, gx, gy, gz; size_t per; };
+static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
+    static int cus = 0;                       // cached: the attribute query is slow
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    BwbPlan p;
+    const int ntiles = (Fin * K + 31) / 32;
+    p.rt = ntiles < 5 ? ntiles : 5;
+    p.ct = Fout > 32 ? 2 : 1;
+    p.gy = (ntiles + p.rt - 1) / p.rt;
+    p.gz = (Fout + 32 * p.ct - 1) / (32 * p.ct);
+    const long long total = (long long)B * ((M + 63) / 64);
+    long long gx = 2ll * cus;                 // <= 56 KB of LDS and <= 256 registers: two workgroups per CU
+    if (gx > total) gx = total;
+    p.gx = gx < 1 ? 1 : (int)gx;
+    p.per = (size_t)p.rt * p.ct * 16 * 64;
+    return p;
+}
+
 }  // namespace chebgcn
 
 using namespace chebgcn;
+
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream);
 
 extern "C" size_t chebgcn_contract_fwd_bf16_workspace(int Fin, int K, int Fout) {
     if (Fin <= 0 || K <= 0 || Fout <= 0) return 0;
@@ -287,8 +489,15 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
     a.slab = (size_t)B * Fin * a.Mp;
     const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + 255) / 256 * 256;
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
-                       a.FinK, Fout, nks, FoutP, passes == 3 ? 2 : 1);
+                       a.FinK, Fout, nks, FoutP, passes == 3 ? 2 : 1, 0);
     CG_HIP(hipGetLastError());
+    return launch_contract_bf16(a, passes, workspace, stream);
+}
+
+// the packed operand is in `workspace`; `a` describes the rows, the planes and the epilogue
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream) {
+    const int B = a.B, M = a.M, Fout = a.Fout;
+    const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + 255) / 256 * 256;
     const int ntm = (M + 127) / 128;
     const int64_t nitems64 = (int64_t)ntm * B * ((Fout + 255) / 256);
     CG_REQUIRE(nitems64 < (1ll << 31), "contract_fwd_bf16: too many tiles");
@@ -307,6 +516,86 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
         CG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, (const __bf16*)workspace, nks, FoutP, ntm, nitems);
     }
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+// ---- gradient of the contraction wrt the stack on the bf16 matrix cores -------------------------
+// gstack[k][b][fin][m] = sum_o W[fin*K+k][o] * dy[b][o][m] (the MatMul gradient of
+// models_gcn.py:616): the SAME kernel with the roles swapped -- the reduction rows are the Fout planes
+// of dy (a "stack" of one slab), the operand is W^T packed in fragment order, and the Fin*K output
+// rows are scattered into the slab layout of the gradient stack by the epilogue (FwdArgs::out_K).
+extern "C" size_t chebgcn_contract_bwd_x_bf16_workspace(int Fin, int K, int Fout) {
+    if (Fin <= 0 || K <= 0 || Fout <= 0) return 0;
+    const size_t nks = bf16_ksteps(Fout), RowsP = ((size_t)Fin * K + 255) / 256 * 256;
+    return 2 * nks * RowsP * 16 * sizeof(uint16_t);
+}
+
+extern "C" int chebgcn_contract_bwd_x_bf16(const float* dy, const float* W, float* gstack, int B, int M, int Fin, int K,
+                                           int Fout, int passes, void* workspace, size_t workspace_bytes,
+                                           chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(dy && W && gstack && workspace, "contract_bwd_x_bf16: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0 && B <= 65535, "contract_bwd_x_bf16: bad shape");
+    CG_REQUIRE(passes == 1 || passes == 3, "contract_bwd_x_bf16: passes must be 1 (bf16) or 3 (split bf16), got %d", passes);
+    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout),
+               "contract_bwd_x_bf16: workspace of %zu bytes is too small", workspace_bytes);
+    FwdArgs a;
+    a.stack = dy; a.W = W; a.bias = nullptr; a.out = gstack; a.argmax = nullptr;
+    a.B = B; a.M = M; a.Mp = plane_stride(M);
+    a.Fin = Fout; a.K = 1; a.FinK = Fout;               // reduction rows: the Fout planes of one window of dy
+    a.Fout = Fin * K;                                   // output rows
+    a.pool = 1; a.pool_kind = 0; a.relu = 0; a.bias_kind = CHEBGCN_BIAS_NONE;
+    a.Mo = M; a.Mpo = a.Mp;
+    a.slab = (size_t)B * Fout * a.Mp;
+    a.out_K = K;
+    const int nks = bf16_ksteps(a.FinK), FoutP = (a.Fout + 255) / 256 * 256;
+    hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
+                       a.FinK, a.Fout, nks, FoutP, passes == 3 ? 2 : 1, Fout);
+    CG_HIP(hipGetLastError());
+    return launch_contract_bf16(a, passes, workspace, stream);
+}
+
+extern "C" size_t chebgcn_contract_bwd_w_bf16_workspace(int B, int M, int Fin, int K, int Fout) {
+    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
+    const BwbPlan p = bwb_plan(B, M, Fin, K, Fout);
+    return ((size_t)p.gx + BWB_SPLIT) * p.gy * p.gz * p.per * sizeof(float);   // partials + stage
+}
+
+extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, float* dW, void* workspace,
+                                           size_t workspace_bytes, int B, int M, int Fin, int K, int Fout, int passes,
+                                           chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(stack && dy && dW && workspace, "contract_bwd_w_bf16: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w_bf16: bad shape");
+    CG_REQUIRE(passes == 1 || passes == 3, "contract_bwd_w_bf16: passes must be 1 (bf16) or 3 (split bf16), got %d", passes);
+    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_bf16_workspace(B, M, Fin, K, Fout),
+               "contract_bwd_w_bf16: workspace too small");
+    const BwbPlan p = bwb_plan(B, M, Fin, K, Fout);
+    BwdWBf16Args a;
+    a.stack = stack; a.dy = dy; a.partial = (float*)workspace;
+    a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
+    a.nchunks_m = (M + 63) / 64;
+    a.slab = (size_t)B * Fin * a.Mp;
+    const dim3 grid(p.gx, p.gy, p.gz);
+    const size_t lds = (size_t)(p.rt + p.ct) * 32 * BWB_ROW * sizeof(float);
+#define CG_BWB(R, C, P)                                                                                   \
+    if (p.rt == R && p.ct == C && passes == P) {                                                          \
+        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_kernel<R, C, P>),    \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+        hipLaunchKernelGGL((contract_bwd_w_bf16_kernel<R, C, P>), grid, dim3(256), lds, stream, a);       \
+    }
+#define CG_BWB4(R) CG_BWB(R, 1, 1) CG_BWB(R, 1, 3) CG_BWB(R, 2, 1) CG_BWB(R, 2, 3)
+    CG_BWB4(1) CG_BWB4(2) CG_BWB4(3) CG_BWB4(4) CG_BWB4(5)
+#undef CG_BWB4
+#undef CG_BWB
+    CG_HIP(hipGetLastError());
+    const int rows = p.rt * p.ct * 16;
+    float* stage = (float*)workspace + (size_t)p.gx * p.gy * p.gz * p.per;
+    hipLaunchKernelGGL(bwb_reduce_stage1, dim3(rows, p.gy * BWB_SPLIT, p.gz), dim3(256), 0, stream,
+                       (const float*)workspace, stage, p.gx, p.gy, rows);
+    hipLaunchKernelGGL(bwb_reduce_stage2, dim3(rows, p.gy, p.gz), dim3(64), 0, stream, (const float*)stage, dW, p.gy,
+                       p.rt, p.ct, a.FinK, Fout);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -22,6 +22,9 @@ struct FwdArgs {
     int pool, pool_kind, relu, bias_kind;
     int Mo, Mpo;
     size_t slab;                 // B*Fin*Mp
+    // out_K > 0: the output rows are the rows fin*out_K + k of a Chebyshev (gradient) stack and go to
+    // out[k][b][fin][m] instead of out[b][row][m] (chebgcn_contract_bwd_x_bf16: the kernel computes W^T dy)
+    int out_K = 0;
 };
 
 // Epilogue of one filter row for the four vertices n0..n0+3 held by lane c of a half-wave:
@@ -50,7 +53,9 @@ __device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
     }
-    float* orow = a.out + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo;
+    const int foc = fo_ok ? fo : 0;
+    float* orow = a.out + (a.out_K > 0 ? ((size_t)(foc % a.out_K) * a.B * (a.Fout / a.out_K) + (size_t)b * (a.Fout / a.out_K) + foc / a.out_K)
+                                       : ((size_t)b * a.Fout + foc)) * a.Mpo;
     uint8_t* arow = a.argmax ? a.argmax + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo : nullptr;
     if (p == 1) {
         if (fo_ok && valid) *reinterpret_cast<float4*>(orow + n0) = make_float4(v[0], v[1], v[2], v[3]);

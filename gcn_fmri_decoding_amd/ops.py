@@ -329,6 +329,7 @@ class ChebConv(torch.autograd.Function):
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
         ctx.done = bufs.done if bufs is not None else None
+        ctx.precision = precision
         return out
 
     @staticmethod
@@ -354,33 +355,53 @@ class ChebConv(torch.autograd.Function):
             pool, pool_kind, relu, _stream())), 'brelu_pool_bwd')
         dW = None
         if ctx.needs_input_grad[1]:
-            nbytes = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
+            passes = PRECISIONS[ctx.precision]
+            if passes:
+                nbytes = lib.chebgcn_contract_bwd_w_bf16_workspace(B, M, Fin, K, Fout)
+            else:
+                nbytes = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
             ws = _workspace(nbytes, dev)
             if dW_buf is not None:
                 _check_grad_buffer(dW_buf, (Fin * K, Fout), 'dW')
                 dW = dW_buf                       # written, not accumulated: one use per step
             else:
                 dW = torch.empty((Fin * K, Fout), dtype=torch.float32, device=dev)
+
+            def launch_bwd_w():
+                if passes:
+                    call = lambda: lib.chebgcn_contract_bwd_w_bf16(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
+                                                                   K, Fout, passes, _stream())
+                else:
+                    call = lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin, K,
+                                                              Fout, _stream())
+                what = 'contract_bwd_w' + ('_' + ctx.precision if passes else '')
+                _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout, call), what)
+
             side = _side_stream(dev) if (overlap_bwd_w and ctx.needs_input_grad[0]) else None
             if side is not None:
                 # dW does not feed dx: it runs beside contract_bwd_x / recurrence_bwd on a second stream
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
-                    _lib.check(_launch('contract_bwd_w', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
-                                       lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M,
-                                                                          Fin, K, Fout, _stream())), 'contract_bwd_w')
+                    launch_bwd_w()
             else:
-                _lib.check(_launch('contract_bwd_w', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
-                                   lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
-                                                                      K, Fout, _stream())), 'contract_bwd_w')
+                launch_bwd_w()
         else:
             side = None
         dx = None
         if ctx.needs_input_grad[0]:
             gstack = torch.empty((K, B, Fin, g.Mp), dtype=torch.float32, device=dev)
-            _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
-                               lambda: lib.chebgcn_contract_bwd_x(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
-                                                                  _stream())), 'contract_bwd_x')
+            passes = PRECISIONS[ctx.precision]
+            if passes:
+                nws = lib.chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout)
+                wsx = torch.empty(nws, dtype=torch.uint8, device=dev)     # its own: bwd_w may be running beside it
+                what = 'contract_bwd_x_' + ctx.precision
+                _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
+                                   lambda: lib.chebgcn_contract_bwd_x_bf16(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
+                                                                           passes, _p(wsx), nws, _stream())), what)
+            else:
+                _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
+                                   lambda: lib.chebgcn_contract_bwd_x(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
+                                                                      _stream())), 'contract_bwd_x')
             dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
             _lib.check(_launch('recurrence_bwd', 4.0 * B * M * Fin * (K + 1), 0.0, lambda: lib.chebgcn_recurrence_bwd(
                 g.handle, _p(gstack), _p(dx), B, Fin, K, _stream())), 'recurrence_bwd')
@@ -410,8 +431,9 @@ class Buffers:
 
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
               dW=None, dbias=None, precision='f32', done=None):
-    """``precision``: arithmetic of the forward contraction ('f32', 'bf16', 'bf16x3'); the
-    recurrence and every gradient stay fp32."""
+    """``precision``: arithmetic of the contraction and of its two gradients ('f32', 'bf16', 'bf16x3':
+    chebgcn_contract_fwd_bf16 / _bwd_x_bf16 / _bwd_w_bf16 with 1 or 3 passes); storage, the recurrence, its adjoint
+    and the bias / ReLU / pooling gradients stay fp32."""
     bufs = None
     if stack is not None or out is not None or dW is not None or dbias is not None or precision != 'f32' or done is not None:
         bufs = Buffers(stack, out, dW, dbias, precision, done)

@@ -123,6 +123,21 @@ int chebgcn_contract_fwd_bf16(const float* stack, const float* W, const float* b
                               int pool, int pool_kind, int relu, int passes, void* workspace,
                               size_t workspace_bytes, chebgcn_stream stream);
 
+/* ---- the two gradients of the contraction on the bf16 matrix cores (wide layers; replace the
+ * MatMul gradient TensorFlow derives for models_gcn.py:616 when the layer computes in bf16).
+ * Same operands, layouts and `passes` as above; fp32 in HBM, fp32 accumulate, deterministic.
+ *   bwd_x: gstack[k][b][fin][m] = sum_o  W[fin*K+k][o] * dy[b][o][m]     (overwrites gstack)
+ *   bwd_w: dW[fin*K+k][o]       = sum_{b,m} stack[k][b][fin][m] * dy[b][o][m]   (overwrites dW)
+ * Workspaces: device scratch of at least the size the *_workspace function reports. */
+size_t chebgcn_contract_bwd_x_bf16_workspace(int Fin, int K, int Fout);
+int chebgcn_contract_bwd_x_bf16(const float* dy, const float* W, float* gstack, int B, int M, int Fin,
+                                int K, int Fout, int passes, void* workspace, size_t workspace_bytes,
+                                chebgcn_stream stream);
+size_t chebgcn_contract_bwd_w_bf16_workspace(int B, int M, int Fin, int K, int Fout);
+int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, float* dW, void* workspace,
+                                size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
+                                int passes, chebgcn_stream stream);
+
 /* ---- bias + ReLU + pooling on their own (b1relu / b2relu / mpool1 / apool1 called
  * separately, models_gcn.py:619-648); same conventions as the epilogue of contract_fwd.
  * x: [B][F][Mp(M)] -> out: [B][F][Mp(M/pool)]. */

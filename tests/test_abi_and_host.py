@@ -59,6 +59,14 @@ def test_argument_validation_without_gpu():
     assert lib.chebgcn_contract_fwd_bf16_workspace(60, 5, 256) == 2 * 19 * 256 * 16 * 2      # hi + lo, 19 k-steps
     assert lib.chebgcn_contract_fwd_bf16(None, None, None, 0, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 1, None, 0, None) == -1
     assert b'contract_fwd_bf16' in lib.chebgcn_last_error()
+    # bf16 gradients of the contraction
+    assert lib.chebgcn_contract_bwd_x_bf16_workspace(60, 5, 0) == 0
+    assert lib.chebgcn_contract_bwd_x_bf16_workspace(60, 5, 256) == 2 * 16 * 512 * 16 * 2     # W^T: 16 k-steps x 300 -> 512 rows
+    assert lib.chebgcn_contract_bwd_x_bf16(None, None, None, 1, 1, 1, 1, 1, 1, None, 0, None) == -1
+    assert b'contract_bwd_x_bf16' in lib.chebgcn_last_error()
+    assert lib.chebgcn_contract_bwd_w_bf16_workspace(0, 1, 1, 1, 1) == 0
+    assert lib.chebgcn_contract_bwd_w_bf16(None, None, None, None, 0, 1, 1, 1, 1, 1, 1, None) == -1
+    assert b'contract_bwd_w_bf16' in lib.chebgcn_last_error()
     with pytest.raises(_lib.ChebgcnError):
         _lib.check(-1, 'x')
 

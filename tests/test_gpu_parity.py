@@ -4,6 +4,8 @@ golden vectors produced by the reference.  Needs an MI355X: run with ``-m gpu``.
 Tolerance: BASELINE.json's north star asks for <= 1e-5 relative fp32; we assert
 max|hip - ref| <= 1e-5 * max|ref| per tensor (REL below), bit-exactness for index maps.
 """
+import ctypes
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -315,6 +317,88 @@ def test_bf16_contraction_config5_shape(ops, dev):
         got = ops.cheb_conv(x, W, bias, g, K, relu=True, bias_kind=ops.BIAS_VERTEX, precision=precision)[:, :, :M].double()
         err = float((got - ref).abs().max() / pre.abs().max())
         assert err <= rel, '%s: rel err %.3e' % (precision, err)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('B,M,Fin,K,Fout', [
+    (2, 10466, 60, 5, 256),      # BASELINE config 5 on the benchmark graph: RT = 5, CT = 2, two row groups
+    (3, 200, 3, 3, 40),          # one ragged row tile, two ragged column tiles
+    (2, 1000, 7, 5, 300),        # Fout beyond one 256-filter group of bwd_x; RT = 2
+    (1, 64, 16, 1, 16),          # K = 1, a single chunk, CT = 1
+    (5, 333, 13, 4, 33),         # RT = 2 (52 rows), ragged everything
+    (2, 96, 40, 5, 64)])         # RT = 5 with two row groups (200 rows), CT = 2
+def test_bf16_contraction_gradients(ops, dev, precision, B, M, Fin, K, Fout):
+    """chebgcn_contract_bwd_x_bf16 / chebgcn_contract_bwd_w_bf16 (the MatMul gradients of
+    models_gcn.py:616 on the bf16 matrix cores) against float64 sums of the same operands.  The
+    padding of the planes is filled with huge values: no gradient may see it."""
+    from gcn_fmri_decoding_amd import _lib
+    lib = _lib.lib()
+    Mp = (M + 31) // 32 * 32
+    passes = ops.PRECISIONS[precision]
+    gen = torch.Generator(device='cpu').manual_seed(B * 1000 + M + Fout)
+    stack = torch.randn(K, B, Fin, Mp, generator=gen)
+    dy = torch.randn(B, Fout, Mp, generator=gen)
+    W = torch.randn(Fin * K, Fout, generator=gen) * 0.2
+    stack[..., M:] = 1e30
+    dy[..., M:] = -1e30
+    sd, dd, Wd = stack.to(dev), dy.to(dev), W.to(dev)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- bwd_w
+    n = lib.chebgcn_contract_bwd_w_bf16_workspace(B, M, Fin, K, Fout)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    dW = torch.full((Fin * K, Fout), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_w_bf16(ptr(sd), ptr(dd), ptr(dW), ptr(ws), n, B, M, Fin, K, Fout, passes, stream), 'bwd_w_bf16')
+    s64 = stack[..., :M].double().permute(2, 0, 1, 3).reshape(Fin * K, B * M)            # rows fin*K + k
+    d64 = dy[..., :M].double().permute(1, 0, 2).reshape(Fout, B * M)
+    ref = s64 @ d64.T
+    err = float((dW.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err <= BF16_REL[precision], 'bwd_w %s: rel err %.3e' % (precision, err)
+    if precision == 'bf16':
+        assert err > 1e-6, 'suspiciously exact: is the fp32 kernel running?'
+    dW2 = torch.empty_like(dW)
+    _lib.check(lib.chebgcn_contract_bwd_w_bf16(ptr(sd), ptr(dd), ptr(dW2), ptr(ws), n, B, M, Fin, K, Fout, passes, stream), 'bwd_w_bf16')
+    assert torch.equal(dW, dW2), 'bwd_w_bf16 is not deterministic'
+
+    # ---- bwd_x
+    n = lib.chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    gs = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_x_bf16(ptr(dd), ptr(Wd), ptr(gs), B, M, Fin, K, Fout, passes, ptr(ws), n, stream), 'bwd_x_bf16')
+    refx = torch.einsum('ro,bom->rbm', W.double(), dy[..., :M].double())                  # [Fin*K, B, M]
+    refx = refx.reshape(Fin, K, B, M).permute(1, 2, 0, 3)                                # [K, B, Fin, M]
+    got = gs[..., :M].cpu().double()
+    err = float((got - refx).abs().max() / refx.abs().max())
+    assert err <= BF16_REL[precision], 'bwd_x %s: rel err %.3e' % (precision, err)
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+def test_bf16_layer_gradients_vs_fp32_layer(ops, dev, precision):
+    """A whole layer (recurrence + bf16 contraction, no ReLU / pooling so that no pick can flip):
+    dx, dW and dbias of the mixed-precision layer against the fp32 layer on the same inputs."""
+    L = levels()[0]
+    M = L.shape[0]
+    g = ops.Graph(L, dev)
+    B, Fin, K, Fout = 3, 12, 5, 72
+    rs = np.random.RandomState(11)
+    x = rs.randn(B, M, Fin).astype(np.float32)
+    W = torch.as_tensor((rs.randn(Fin * K, Fout) * 0.3).astype(np.float32)).to(dev)
+    b = torch.as_tensor((rs.randn(Fout) * 0.5).astype(np.float32)).to(dev)
+    gout = None
+    grads = {}
+    for prec in ('f32', precision):
+        xs = to_storage(ops, x, dev).requires_grad_(True)
+        Wp, bp = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = ops.cheb_conv(xs, Wp, bp, g, K, bias_kind=ops.BIAS_FILTER, precision=prec)
+        if gout is None:
+            gout = torch.zeros_like(out)
+            gout[:, :, :M] = torch.randn(B, Fout, M, device=dev)
+        out.backward(gout)
+        grads[prec] = (xs.grad[:, :, :M].double(), Wp.grad.double(), bp.grad.double())
+    for name, ref, got in zip(('dx', 'dW', 'dbias'), grads['f32'], grads[precision]):
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err <= BF16_REL[precision], '%s %s: rel err %.3e' % (name, precision, err)
 
 
 # ---------------------------------------------------------------------------------------
