@@ -45,6 +45,8 @@ SIGNATURES = {
     'chebgcn_contract_bwd_w_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'chebgcn_contract_bwd_w': (_i, [_p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_x': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'chebgcn_contract_bwd_x_relu': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'chebgcn_contract_bwd_w_relu': (_i, [_p, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_perm_data': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'chebgcn_to_plane': (_i, [_p, _p, _i, _i, _i, _p]),
     'chebgcn_from_plane': (_i, [_p, _p, _i, _i, _i, _p]),

@@ -105,12 +105,13 @@ contract_fwd_kernel(FwdArgs a) {
 // --------------------------------------------------------------------------------------
 struct BwdXArgs {
     const float* dy; const float* W; float* gstack;
+    const uint8_t* mask;         // MASK: dy = the gradient of the layer OUTPUT, gated by the ReLU mask of the forward
     int B, M, Mp, Fin, K, Fout, FinK;
     size_t slab;
 };
 
 // HOLD: dy tile (Fout <= 32 -> 16 float4 per lane) stays in registers across the row tiles.
-template <bool HOLD>
+template <bool HOLD, bool MASK>
 __global__ void __launch_bounds__(256)
 contract_bwd_x_kernel(BwdXArgs a) {
     const int lane = threadIdx.x & 63;
@@ -121,18 +122,28 @@ contract_bwd_x_kernel(BwdXArgs a) {
     if (m0 >= a.M) return;
     const int n0 = m0 + 4 * c;
     const bool valid = n0 < a.Mp;
+    // every load below is unconditional on a clamped address and masked afterwards: a conditional load is a
+    // branch with a full s_waitcnt behind it, i.e. one exposed memory round trip per row
     const float* dyb = a.dy + (size_t)b * a.Fout * a.Mp + (valid ? n0 : 0);
+    const uint8_t* mkb = MASK ? a.mask + (size_t)b * a.Fout * (a.Mp >> 2) + (valid ? (n0 >> 2) : 0) : nullptr;
+    const int Mq = a.Mp >> 2;
+    auto gated = [&](float4 v, int bits) {       // ReluGrad: zero where the forward result was not positive
+        return make_float4((bits & 1) ? v.x : 0.f, (bits & 2) ? v.y : 0.f, (bits & 4) ? v.z : 0.f, (bits & 8) ? v.w : 0.f);
+    };
     const int nfo2 = (a.Fout + 1) >> 1;
     const int ntiles = (a.FinK + 31) >> 5;
 
     float4 hold[HOLD ? 16 : 1];
     if (HOLD) {
+        int bits[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int fo = 2 * j + h;
-            hold[j] = (valid && fo < a.Fout) ? ld_stream(dyb + (size_t)fo * a.Mp)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int fo = 2 * j + h, foc = fo < a.Fout ? fo : 0;
+            hold[j] = ld_stream(dyb + (size_t)foc * a.Mp);
+            bits[j] = MASK ? (int)mkb[(size_t)foc * Mq] : 15;
         }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) hold[j] = gated(hold[j], (valid && 2 * j + h < a.Fout) ? bits[j] : 0);
     }
     for (int t = 0; t < ntiles; ++t) {
         f32x16 acc[4];
@@ -143,26 +154,42 @@ contract_bwd_x_kernel(BwdXArgs a) {
         const int kkA = t * 32 + c;                       // A row handled by this lane
         const float* wrow = a.W + (size_t)(kkA < a.FinK ? kkA : 0) * a.Fout;
         if (HOLD) {
+            float av[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int fo = 2 * j + h;
-                const float av = (kkA < a.FinK && fo < a.Fout) ? wrow[fo] : 0.f;
-                acc[0] = mfma(av, hold[j].x, acc[0]);
-                acc[1] = mfma(av, hold[j].y, acc[1]);
-                acc[2] = mfma(av, hold[j].z, acc[2]);
-                acc[3] = mfma(av, hold[j].w, acc[3]);
+                av[j] = wrow[fo < a.Fout ? fo : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float w = (kkA < a.FinK && 2 * j + h < a.Fout) ? av[j] : 0.f;
+                acc[0] = mfma(w, hold[j].x, acc[0]);
+                acc[1] = mfma(w, hold[j].y, acc[1]);
+                acc[2] = mfma(w, hold[j].z, acc[2]);
+                acc[3] = mfma(w, hold[j].w, acc[3]);
             }
         } else {
-            for (int j = 0; j < nfo2; ++j) {
-                const int fo = 2 * j + h;
-                const bool live = fo < a.Fout;
-                const float av = (kkA < a.FinK && live) ? wrow[fo] : 0.f;
-                const float4 bv = valid ? *reinterpret_cast<const float4*>(dyb + (size_t)(live ? fo : 0) * a.Mp)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-                acc[0] = mfma(av, bv.x, acc[0]);
-                acc[1] = mfma(av, bv.y, acc[1]);
-                acc[2] = mfma(av, bv.z, acc[2]);
-                acc[3] = mfma(av, bv.w, acc[3]);
+            for (int j0 = 0; j0 < nfo2; j0 += 4) {
+                float av[4];
+                float4 bv[4];
+                int bits[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int fo = 2 * (j0 + u) + h, foc = fo < a.Fout ? fo : 0;
+                    av[u] = wrow[foc];
+                    bv[u] = *reinterpret_cast<const float4*>(dyb + (size_t)foc * a.Mp);
+                    bits[u] = MASK ? (int)mkb[(size_t)foc * Mq] : 15;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool live = 2 * (j0 + u) + h < a.Fout;
+                    const float w = (kkA < a.FinK && live) ? av[u] : 0.f;
+                    const float4 g = gated(bv[u], (valid && live) ? bits[u] : 0);
+                    acc[0] = mfma(w, g.x, acc[0]);
+                    acc[1] = mfma(w, g.y, acc[1]);
+                    acc[2] = mfma(w, g.z, acc[2]);
+                    acc[3] = mfma(w, g.w, acc[3]);
+                }
             }
         }
 #pragma unroll
@@ -188,6 +215,7 @@ contract_bwd_x_kernel(BwdXArgs a) {
 // --------------------------------------------------------------------------------------
 struct BwdWArgs {
     const float* stack; const float* dy; float* partial;
+    const uint8_t* mask;         // MASK: see BwdXArgs
     int B, M, Mp, Fin, K, Fout, FinK;
     int nchunks_m;               // ceil(M / 64)
     int ntiles;                  // ceil(FinK / 32)
@@ -206,7 +234,7 @@ struct BwdWArgs {
 // every workgroup leaves one partial; reduce_partials sums them deterministically.
 constexpr int BW_ROW = 64;       // floats per LDS row (one chunk)
 
-template <int RT>
+template <int RT, bool MASK>
 __global__ void __launch_bounds__(256)
 contract_bwd_w_kernel(BwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [(RT+1)*32][64]
@@ -257,6 +285,14 @@ contract_bwd_w_kernel(BwdWArgs a) {
         const int b = ch / a.nchunks_m;
         const int m0 = (ch - b * a.nchunks_m) * 64;
         __syncthreads();                                // previous chunk's operand reads are done
+        int gate[2] = {15, 15};
+        if (MASK) {                                     // the two mask bytes of this lane's pieces, in flight beside the DMA
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int quad = (m0 >> 2) + 4 * wave + 2 * q + h;
+                gate[q] = (b_ok && quad < (a.Mp >> 2)) ? a.mask[((size_t)b * a.Fout + fo0 + c) * (a.Mp >> 2) + quad] : 0;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < PER_WAVE; ++u) {
             const int n = wave + 4 * u;
@@ -278,10 +314,10 @@ contract_bwd_w_kernel(BwdWArgs a) {
             const int row = RT * 32 + c;
             float4 v = *reinterpret_cast<const float4*>(lds + row * BW_ROW + 4 * (piece ^ (row & 15)));
             const int n = m0 + 4 * piece;
-            v.x = (b_ok && n + 0 < a.M) ? v.x : 0.f;
-            v.y = (b_ok && n + 1 < a.M) ? v.y : 0.f;
-            v.z = (b_ok && n + 2 < a.M) ? v.z : 0.f;
-            v.w = (b_ok && n + 3 < a.M) ? v.w : 0.f;
+            v.x = (b_ok && n + 0 < a.M && (gate[q] & 1)) ? v.x : 0.f;
+            v.y = (b_ok && n + 1 < a.M && (gate[q] & 2)) ? v.y : 0.f;
+            v.z = (b_ok && n + 2 < a.M && (gate[q] & 4)) ? v.z : 0.f;
+            v.w = (b_ok && n + 3 < a.M && (gate[q] & 8)) ? v.w : 0.f;
             bv[q] = v;
         }
 #pragma unroll
@@ -396,6 +432,7 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
     CG_REQUIRE(!(pool_kind == CHEBGCN_POOL_AVG && relu && argmax && pool > 8),
                "contract_fwd: average pooling keeps a ReLU mask only for pool <= 8");
     a.argmax = pool > 1 ? argmax : nullptr;
+    a.relu_mask = (pool == 1 && relu) ? argmax : nullptr;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
     a.pool = pool; a.pool_kind = pool_kind; a.relu = relu; a.bias_kind = bias_kind;
     a.Mo = M / pool; a.Mpo = plane_stride(a.Mo);
@@ -412,20 +449,36 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
     return CHEBGCN_OK;
 }
 
-extern "C" int chebgcn_contract_bwd_x(const float* dy, const float* W, float* gstack, int B, int M,
-                                      int Fin, int K, int Fout, chebgcn_stream stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    CG_REQUIRE(dy && W && gstack, "contract_bwd_x: NULL argument");
-    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0 && B <= 65535, "contract_bwd_x: bad shape");
+static int launch_bwd_x(const float* dy, const uint8_t* mask, const float* W, float* gstack, int B, int M, int Fin, int K,
+                        int Fout, hipStream_t stream) {
     BwdXArgs a;
-    a.dy = dy; a.W = W; a.gstack = gstack;
+    a.dy = dy; a.W = W; a.gstack = gstack; a.mask = mask;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
     a.slab = (size_t)B * Fin * a.Mp;
     dim3 grid((M + 511) / 512, B, 1);
-    if (Fout <= 32) hipLaunchKernelGGL(contract_bwd_x_kernel<true>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(contract_bwd_x_kernel<false>, grid, dim3(256), 0, stream, a);
+    if (mask) {
+        if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((contract_bwd_x_kernel<false, true>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, false>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((contract_bwd_x_kernel<false, false>), grid, dim3(256), 0, stream, a);
+    }
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_contract_bwd_x(const float* dy, const float* W, float* gstack, int B, int M,
+                                      int Fin, int K, int Fout, chebgcn_stream stream_) {
+    CG_REQUIRE(dy && W && gstack, "contract_bwd_x: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0 && B <= 65535, "contract_bwd_x: bad shape");
+    return launch_bwd_x(dy, nullptr, W, gstack, B, M, Fin, K, Fout, (hipStream_t)stream_);
+}
+
+extern "C" int chebgcn_contract_bwd_x_relu(const float* dout, const uint8_t* relu_mask, const float* W, float* gstack, int B,
+                                           int M, int Fin, int K, int Fout, chebgcn_stream stream_) {
+    CG_REQUIRE(dout && relu_mask && W && gstack, "contract_bwd_x_relu: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0 && B <= 65535, "contract_bwd_x_relu: bad shape");
+    return launch_bwd_x(dout, relu_mask, W, gstack, B, M, Fin, K, Fout, (hipStream_t)stream_);
 }
 
 extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K, int Fout) {
@@ -435,16 +488,10 @@ extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K,
     return ((size_t)gx + BW_SPLIT) * gy * gz * rt * 16 * 64 * sizeof(float);   // partials + stage
 }
 
-extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void* workspace,
-                                      size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
-                                      chebgcn_stream stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    CG_REQUIRE(stack && dy && dW && workspace, "contract_bwd_w: NULL argument");
-    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w: bad shape");
-    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout),
-               "contract_bwd_w: workspace too small");
+static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask, float* dW, void* workspace, int B, int M,
+                        int Fin, int K, int Fout, hipStream_t stream) {
     BwdWArgs a;
-    a.stack = stack; a.dy = dy; a.partial = (float*)workspace;
+    a.stack = stack; a.dy = dy; a.partial = (float*)workspace; a.mask = mask;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
     a.nchunks_m = (M + 63) / 64;
     a.ntiles = (a.FinK + 31) / 32;
@@ -455,9 +502,15 @@ extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float
     const size_t lds = (size_t)(rt + 1) * 32 * BW_ROW * sizeof(float);
 #define CG_BW(N)                                                                                        \
     case N:                                                                                             \
-        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_kernel<N>),             \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL(contract_bwd_w_kernel<N>, grid, dim3(256), lds, stream, a);                  \
+        if (mask) {                                                                                     \
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_kernel<N, true>),   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+            hipLaunchKernelGGL((contract_bwd_w_kernel<N, true>), grid, dim3(256), lds, stream, a);      \
+        } else {                                                                                        \
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_kernel<N, false>),  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+            hipLaunchKernelGGL((contract_bwd_w_kernel<N, false>), grid, dim3(256), lds, stream, a);     \
+        }                                                                                               \
         break
     switch (rt) {
         CG_BW(1); CG_BW(2); CG_BW(3); CG_BW(4); CG_BW(5);
@@ -472,4 +525,24 @@ extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float
                        gy, rt, a.FinK, Fout);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void* workspace,
+                                      size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
+                                      chebgcn_stream stream_) {
+    CG_REQUIRE(stack && dy && dW && workspace, "contract_bwd_w: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w: bad shape");
+    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout),
+               "contract_bwd_w: workspace too small");
+    return launch_bwd_w(stack, dy, nullptr, dW, workspace, B, M, Fin, K, Fout, (hipStream_t)stream_);
+}
+
+extern "C" int chebgcn_contract_bwd_w_relu(const float* stack, const float* dout, const uint8_t* relu_mask, float* dW,
+                                           void* workspace, size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
+                                           chebgcn_stream stream_) {
+    CG_REQUIRE(stack && dout && relu_mask && dW && workspace, "contract_bwd_w_relu: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w_relu: bad shape");
+    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout),
+               "contract_bwd_w_relu: workspace too small");
+    return launch_bwd_w(stack, dout, relu_mask, dW, workspace, B, M, Fin, K, Fout, (hipStream_t)stream_);
 }

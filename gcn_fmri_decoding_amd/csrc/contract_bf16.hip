@@ -483,6 +483,7 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
     FwdArgs a;
     a.stack = stack; a.W = W; a.bias = bias; a.out = out;
     a.argmax = pool > 1 ? argmax : nullptr;
+    a.relu_mask = (pool == 1 && relu) ? argmax : nullptr;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
     a.pool = pool; a.pool_kind = pool_kind; a.relu = relu; a.bias_kind = bias_kind;
     a.Mo = M / pool; a.Mpo = plane_stride(a.Mo);

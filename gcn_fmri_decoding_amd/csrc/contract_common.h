@@ -25,6 +25,10 @@ struct FwdArgs {
     // out_K > 0: the output rows are the rows fin*out_K + k of a Chebyshev (gradient) stack and go to
     // out[k][b][fin][m] instead of out[b][row][m] (chebgcn_contract_bwd_x_bf16: the kernel computes W^T dy)
     int out_K = 0;
+    // pool == 1 with ReLU: one byte per four vertices, bit r = (result of vertex 4i+r > 0), planes
+    // [B][Fout][Mp/4] -- all the gradient kernels need of the forward result (the ReluGrad of the
+    // reference's autodiff folded into chebgcn_contract_bwd_*_relu)
+    uint8_t* relu_mask = nullptr;
 };
 
 // Epilogue of one filter row for the four vertices n0..n0+3 held by lane c of a half-wave:
@@ -58,7 +62,12 @@ __device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo
                                        : ((size_t)b * a.Fout + foc)) * a.Mpo;
     uint8_t* arow = a.argmax ? a.argmax + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo : nullptr;
     if (p == 1) {
-        if (fo_ok && valid) *reinterpret_cast<float4*>(orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+        if (fo_ok && valid) {
+            *reinterpret_cast<float4*>(orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.relu_mask)
+                a.relu_mask[((size_t)b * a.Fout + fo) * (a.Mpo >> 2) + (n0 >> 2)] =
+                    (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
+        }
     } else if (a.pool_kind == CHEBGCN_POOL_MAX) {
         if (p == 2) {
             const int no = n0 >> 1;

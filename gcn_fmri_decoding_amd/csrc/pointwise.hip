@@ -34,7 +34,12 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
             // read once: streaming loads leave the L2 to dy, which the next two kernels read
             float g = __builtin_nontemporal_load(dout + oi);
             if (pool == 1) {
-                if (relu && !(__builtin_nontemporal_load(out + oi) > 0.f)) g = 0.f;
+                if (relu) {
+                    // argmax given: the ReLU mask contract_fwd leaves at pool == 1 (a bit per vertex)
+                    const bool pos_out = argmax ? ((argmax[((size_t)b * F + f) * (Mp >> 2) + (m >> 2)] >> (m & 3)) & 1) != 0
+                                                : __builtin_nontemporal_load(out + oi) > 0.f;
+                    if (!pos_out) g = 0.f;
+                }
             } else if (pool_kind == CHEBGCN_POOL_MAX) {
                 const bool sel = argmax[oi] == pos;
                 if (!sel || (relu && !(out[oi] > 0.f))) g = 0.f;
@@ -42,7 +47,7 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
                 g *= inv;
                 if (relu && !((argmax[oi] >> pos) & 1)) g = 0.f;
             }
-            dy[((size_t)b * F + f) * Mp + m] = g;
+            if (dy) dy[((size_t)b * F + f) * Mp + m] = g;     // NULL: bias gradient only (the contraction gradients gate dout themselves)
             sum += g;
         }
     }
@@ -64,6 +69,59 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(dbias + f, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
+// ---- bias gradient of a pool == 1 ReLU layer from (dout, ReLU bit mask) alone: the contraction
+// gradients gate dout themselves (contract_bwd_*_relu), so nothing but dbias is written here.
+// thread = four consecutive vertices (one mask byte, one 16-byte load per window) of filter f and
+// one of four interleaved subsets of the batch; fixed-order LDS sum of the four subsets.
+template <int BIAS>
+__global__ void __launch_bounds__(256)
+bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dbias,
+                      int B, int M, int Mp, int F) {
+    __shared__ float4 psum[256];
+    const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int Mq = Mp >> 2;
+    const int q = blockIdx.x * 64 + ql;
+    const int f = blockIdx.y;
+    const bool live = q < Mq;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        const float* gp = dout + (size_t)f * Mp + 4 * q;
+        const uint8_t* mp = mask + (size_t)f * Mq + q;
+#pragma unroll 4
+        for (int b = part; b < B; b += 4) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * F * Mp));
+            const int bits = mp[(size_t)b * F * Mq];
+            sum.x += (bits & 1) ? g.x : 0.f;
+            sum.y += (bits & 2) ? g.y : 0.f;
+            sum.z += (bits & 4) ? g.z : 0.f;
+            sum.w += (bits & 8) ? g.w : 0.f;
+        }
+        const int m = 4 * q;                            // the padding of the plane takes no gradient
+        sum.x = m + 0 < M ? sum.x : 0.f;
+        sum.y = m + 1 < M ? sum.y : 0.f;
+        sum.z = m + 2 < M ? sum.z : 0.f;
+        sum.w = m + 3 < M ? sum.w : 0.f;
+    }
+    psum[threadIdx.x] = sum;
+    __syncthreads();
+    if (part == 0) {
+        float4 t = psum[ql];
+#pragma unroll
+        for (int p = 1; p < 4; ++p) {
+            const float4 o = psum[p * 64 + ql];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        if (BIAS == CHEBGCN_BIAS_VERTEX) {
+            if (live) *reinterpret_cast<float4*>(dbias + (size_t)f * Mp + 4 * q) = t;
+        } else {
+            float s = (t.x + t.y) + (t.z + t.w);
+            for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+            if (ql == 0) atomicAdd(dbias + f, s);
+        }
     }
 }
 
@@ -209,13 +267,25 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
                                       float* dbias, int bias_kind, int B, int M, int F, int pool,
                                       int pool_kind, int relu, chebgcn_stream stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    CG_REQUIRE(dout && dy, "brelu_pool_bwd: NULL argument");
+    CG_REQUIRE(dout && (dy || (dbias && bias_kind != CHEBGCN_BIAS_NONE)), "brelu_pool_bwd: NULL argument");
     CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "brelu_pool_bwd: bad shape");
     CG_REQUIRE(pool >= 1 && (pool & (pool - 1)) == 0 && pool <= 128 && M % pool == 0, "brelu_pool_bwd: bad pool %d", pool);
-    CG_REQUIRE(!relu || out, "brelu_pool_bwd: relu needs the forward output");
+    CG_REQUIRE(!relu || out || (pool == 1 && argmax), "brelu_pool_bwd: relu needs the forward output (or its mask at pool 1)");
     CG_REQUIRE(pool == 1 || argmax || (pool_kind == CHEBGCN_POOL_AVG && !relu), "brelu_pool_bwd: pooling needs argmax/mask");
     CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || dbias, "brelu_pool_bwd: dbias is NULL");
     const int Mp = plane_stride(M), Mpo = plane_stride(M / pool);
+    if (!dy && pool == 1 && relu && argmax) {           // bias gradient alone, from the ReLU mask
+        if (bias_kind == CHEBGCN_BIAS_FILTER) {
+            CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, dim3((Mp / 4 + 63) / 64, F), dim3(256), 0, stream,
+                               dout, argmax, dbias, B, M, Mp, F);
+        } else {
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, dim3((Mp / 4 + 63) / 64, F), dim3(256), 0, stream,
+                               dout, argmax, dbias, B, M, Mp, F);
+        }
+        CG_HIP(hipGetLastError());
+        return CHEBGCN_OK;
+    }
     // enough workgroups for the chip: small graphs split the batch over 4 or 8 thread groups
     const int parts = ((M + 255) / 256) * F >= 1024 ? 1 : ((M + 63) / 64) * F >= 1024 ? 4 : 8;
     if (bias_kind == CHEBGCN_BIAS_FILTER) CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));

@@ -71,6 +71,7 @@ class KernelTimers:
 
 
 timers = None
+fold_relu_grad = True        # pool == 1 layers: ReluGrad inside chebgcn_contract_bwd_*_relu (False: separate brelu_pool_bwd pass)
 overlap_bwd_w = False        # experiment: contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd
 _side_streams = {}
 
@@ -282,7 +283,9 @@ class ChebConv(torch.autograd.Function):
     """y = pool(act(sum_k T_k(L~) x W_k + bias)) on plane storage tensors.
 
     forward : recurrence_fwd (models_gcn.py:598-610) + contract_fwd (:611-648)
-    backward: brelu_pool_bwd, contract_bwd_w, contract_bwd_x, recurrence_bwd
+    backward: brelu_pool_bwd, contract_bwd_w, contract_bwd_x, recurrence_bwd; for pool == 1 layers with
+              ReLU the ReluGrad runs inside contract_bwd_w_relu / contract_bwd_x_relu on the bit mask the
+              forward left, and brelu_pool_bwd only reduces the bias gradient
     ``bufs`` is a ``Buffers`` holder (kept out of autograd's sight): ``bufs.stack`` is an
     optional preallocated [K, B, Fin, Mp] buffer -- when ``x`` already is its slab 0 no copy
     of T_0 is made; ``bufs.out`` optionally receives the result, e.g. slab 0 of the next
@@ -316,15 +319,21 @@ class ChebConv(torch.autograd.Function):
             out = out.detach()                # fresh alias: an output, not an input, for autograd
             if tuple(out.shape) != (B, Fout, plane_stride(Mo)) or not out.is_contiguous():
                 raise ValueError('out buffer has the wrong shape')
+        precision = getattr(bufs, 'precision', 'f32') if bufs is not None else 'f32'
         argmax = None
         if pool > 1 and (pool_kind == POOL_MAX or relu):
             argmax = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
+        # pool == 1 with ReLU: contract_fwd leaves a bit per vertex (the ReLU mask) and the gradients of the
+        # contraction gate the incoming gradient themselves -- no dy tensor, no pass over `out` in backward
+        fold = bool(fold_relu_grad and pool == 1 and relu and precision == 'f32')
+        if fold:
+            argmax = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device)
         b = bias.detach() if bias is not None else None
         if b is not None and not b.is_contiguous():
             b = b.contiguous()
-        precision = getattr(bufs, 'precision', 'f32') if bufs is not None else 'f32'
         contract_fwd_into(stack, Wc, b, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision)
-        ctx.save_for_backward(stack, Wc, out, argmax)
+        ctx.save_for_backward(stack, Wc, None if fold else out, argmax)
+        ctx.fold = fold
         ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
@@ -341,7 +350,7 @@ class ChebConv(torch.autograd.Function):
         g = ctx.graph
         gout = gout.contiguous()
         dev = gout.device
-        dy = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev)
+        fold = ctx.fold
         dbias = None
         if bias_kind != BIAS_NONE and ctx.needs_input_grad[2]:
             if dbias_buf is not None:
@@ -350,9 +359,18 @@ class ChebConv(torch.autograd.Function):
             else:
                 dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
         Mo = M // pool
-        _lib.check(_launch('brelu_pool_bwd', 4.0 * B * Fout * (2 * Mo + M), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
-            _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bias_kind if dbias is not None else BIAS_NONE, B, M, Fout,
-            pool, pool_kind, relu, _stream())), 'brelu_pool_bwd')
+        if fold:
+            # ReluGrad folded into the two contraction gradients (chebgcn_contract_bwd_*_relu read gout and the
+            # mask); what is left of this pass is the bias reduction, which writes nothing but dbias
+            dy, mask = gout, argmax
+            if dbias is not None:
+                _lib.check(_launch('bias_grad', B * Fout * M * (4.0 + 0.25), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
+                    _p(gout), None, _p(mask), None, _p(dbias), bias_kind, B, M, Fout, 1, pool_kind, 1, _stream())), 'brelu_pool_bwd')
+        else:
+            dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev), None
+            _lib.check(_launch('brelu_pool_bwd', 4.0 * B * Fout * (2 * Mo + M), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
+                _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bias_kind if dbias is not None else BIAS_NONE, B, M, Fout,
+                pool, pool_kind, relu, _stream())), 'brelu_pool_bwd')
         dW = None
         if ctx.needs_input_grad[1]:
             passes = PRECISIONS[ctx.precision]
@@ -371,6 +389,9 @@ class ChebConv(torch.autograd.Function):
                 if passes:
                     call = lambda: lib.chebgcn_contract_bwd_w_bf16(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
                                                                    K, Fout, passes, _stream())
+                elif fold:
+                    call = lambda: lib.chebgcn_contract_bwd_w_relu(_p(stack), _p(dy), _p(mask), _p(dW), _p(ws), ws.numel(), B,
+                                                                   M, Fin, K, Fout, _stream())
                 else:
                     call = lambda: lib.chebgcn_contract_bwd_w(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin, K,
                                                               Fout, _stream())
@@ -398,6 +419,10 @@ class ChebConv(torch.autograd.Function):
                 _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
                                    lambda: lib.chebgcn_contract_bwd_x_bf16(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
                                                                            passes, _p(wsx), nws, _stream())), what)
+            elif fold:
+                _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
+                                   lambda: lib.chebgcn_contract_bwd_x_relu(_p(dy), _p(mask), _p(Wc), _p(gstack), B, M, Fin, K,
+                                                                           Fout, _stream())), 'contract_bwd_x_relu')
             else:
                 _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
                                    lambda: lib.chebgcn_contract_bwd_x(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,

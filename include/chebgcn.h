@@ -105,7 +105,10 @@ int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstack, float* d
  * [Fout][Mp(M)] or NULL;  out: [B][Fout][Mp(M/pool)];  argmax (may be NULL, only
  * written for max pooling with pool > 1): [B][Fout][Mp(M/pool)] bytes, position of
  * the first maximum inside each window.  relu != 0 applies max(.,0) before pooling.
- * pool must be a power of two <= 128 and divide M. */
+ * pool must be a power of two <= 128 and divide M.
+ * pool == 1 with relu != 0: a non-NULL argmax receives the ReLU MASK, [B][Fout][Mp(M)/4] bytes,
+ * bit r of byte i = (out[4i+r] > 0) -- all that the gradient entries *_relu below need of the
+ * forward result. */
 int chebgcn_contract_fwd(const float* stack, const float* W, const float* bias, int bias_kind,
                          float* out, uint8_t* argmax, int B, int M, int Fin, int K, int Fout,
                          int pool, int pool_kind, int relu, chebgcn_stream stream);
@@ -148,7 +151,8 @@ int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bias_kind, flo
 /* ---- backward of pooling + ReLU + bias (MaxPoolGrad, ReluGrad, bias reductions) ---
  * dout, out: [B][F][Mp(M/pool)] (out = forward result); argmax as written by the
  * forward; dy: [B][F][Mp(M)] receives d(loss)/d(pre-bias activation); dbias: [F] or
- * [F][Mp(M)] (overwritten) or NULL. */
+ * [F][Mp(M)] (overwritten) or NULL.  pool == 1 with relu: a non-NULL argmax is the ReLU mask of
+ * contract_fwd and replaces `out` (which may then be NULL).  dy == NULL: only dbias is computed. */
 int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const uint8_t* argmax,
                            float* dy, float* dbias, int bias_kind, int B, int M, int F,
                            int pool, int pool_kind, int relu, chebgcn_stream stream);
@@ -161,6 +165,16 @@ size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K, int Fout);
 int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void* workspace,
                            size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
                            chebgcn_stream stream);
+/* The same two gradients with the ReluGrad of the reference's autodiff folded in (pool == 1
+ * layers): dout = d(loss)/d(layer output) [B][Fout][Mp], relu_mask as written by contract_fwd;
+ * dy = dout where the mask bit is set, else 0, is formed in registers and never stored.  The bias
+ * gradient of such a layer: chebgcn_brelu_pool_bwd(dout, NULL, relu_mask, dy = NULL, dbias, ...). */
+int chebgcn_contract_bwd_w_relu(const float* stack, const float* dout, const uint8_t* relu_mask,
+                                float* dW, void* workspace, size_t workspace_bytes, int B, int M,
+                                int Fin, int K, int Fout, chebgcn_stream stream);
+int chebgcn_contract_bwd_x_relu(const float* dout, const uint8_t* relu_mask, const float* W,
+                                float* gstack, int B, int M, int Fin, int K, int Fout,
+                                chebgcn_stream stream);
 int chebgcn_contract_bwd_x(const float* dy, const float* W, float* gstack, int B, int M,
                            int Fin, int K, int Fout, chebgcn_stream stream);
 

@@ -242,6 +242,61 @@ def test_layer_gradients_vs_oracle(ops, dev, lvl, B, Fin, Fout, K, p, pool_kind,
         assert float(bd.grad[:, M:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('lvl,B,Fin,Fout,K,bias', [
+    (0, 3, 5, 32, 3, 2), (0, 2, 32, 32, 5, 2), (1, 2, 4, 40, 2, 1), (0, 1, 7, 70, 4, 0), (2, 5, 3, 9, 3, 2)])
+def test_relu_grad_fold_is_bit_identical(ops, dev, lvl, B, Fin, Fout, K, bias):
+    """pool == 1 layers with ReLU: the gradients computed by chebgcn_contract_bwd_w_relu /
+    _bwd_x_relu from (gout, ReLU bit mask) are the SAME numbers as the separate ReluGrad pass
+    (chebgcn_brelu_pool_bwd -> dy) followed by the plain gradients: gating a product's operand to
+    zero in registers or in memory feeds the matrix cores identical values."""
+    L = levels()[lvl]
+    M = L.shape[0]
+    g = ops.Graph(L, dev)
+    rs = np.random.RandomState(17 + Fout)
+    x = rs.randn(B, M, Fin).astype(np.float32)
+    W = torch.as_tensor((rs.randn(Fin * K, Fout) * 0.3).astype(np.float32)).to(dev)
+    if bias == 1:
+        b, kind = torch.as_tensor((rs.randn(Fout) * 0.5).astype(np.float32)).to(dev), ops.BIAS_FILTER
+    elif bias == 2:
+        b, kind = torch.zeros((Fout, g.Mp), device=dev), ops.BIAS_VERTEX
+        b[:, :M] = torch.as_tensor((rs.randn(Fout, M) * 0.5).astype(np.float32)).to(dev)
+    else:
+        b, kind = None, ops.BIAS_NONE
+    gout = torch.zeros((B, Fout, g.Mp), device=dev)
+    gout[:, :, :M] = torch.as_tensor(rs.randn(B, Fout, M).astype(np.float32)).to(dev)
+    res = {}
+    try:
+        for fold in (False, True):
+            ops.fold_relu_grad = fold
+            xs = to_storage(ops, x, dev).requires_grad_(True)
+            Wp = W.clone().requires_grad_(True)
+            bp = b.clone().requires_grad_(True) if b is not None else None
+            out = ops.cheb_conv(xs, Wp, bp, g, K, relu=True, bias_kind=kind)
+            out.backward(gout)
+            res[fold] = (out.detach()[:, :, :M], xs.grad[:, :, :M], Wp.grad, None if bp is None else
+                         (bp.grad[:, :M] if bias == 2 else bp.grad))
+    finally:
+        ops.fold_relu_grad = True
+    for name, a, c in zip(('out', 'dx', 'dW', 'dbias'), res[False], res[True]):
+        if a is None:
+            continue
+        if name == 'dbias' and bias == 1:
+            # the per-filter bias gradient is an atomic sum over workgroups: fp32 order varies run to run
+            close(c.cpu().numpy(), a.cpu().numpy(), what=name)
+        else:
+            assert torch.equal(a, c), '%s differs between the folded and the separate ReluGrad' % name
+    # and against the oracle (the fold is what every other layer test runs through as well)
+    y = R.chebyshev5_fwd(x, L, W.cpu().numpy(), K)
+    if bias == 2:
+        bb = b[:, :M].cpu().numpy().T[None]
+    elif bias == 1:
+        bb = b.cpu().numpy().reshape(1, 1, Fout)
+    else:
+        bb = np.zeros((1, 1, Fout), np.float32)
+    a_ref = R.brelu_fwd(y, bb)
+    close(from_storage(res[True][0], M), a_ref, what='out')
+
+
 # ---------------------------------------------------------------------------------------
 # bf16 matrix-core contraction (BASELINE config 5).  Tolerances (relative to max|ref|): one pass
 # rounds both operands to bf16 (2^-9 each) -> 1e-2; three passes keep hi*hi + hi*lo + lo*hi of
