@@ -72,7 +72,9 @@ class KernelTimers:
 
 timers = None
 fold_relu_grad = True        # pool == 1 layers: ReluGrad inside chebgcn_contract_bwd_*_relu (False: separate brelu_pool_bwd pass)
-overlap_bwd_w = False        # experiment: contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd
+# contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd (dW feeds neither): +1.5 % on the
+# configs[1] step.  Not on instrumented steps, whose per-kernel event times must not include a neighbour.
+overlap_bwd_w = True
 _side_streams = {}
 
 
@@ -398,7 +400,7 @@ class ChebConv(torch.autograd.Function):
                 what = 'contract_bwd_w' + ('_' + ctx.precision if passes else '')
                 _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout, call), what)
 
-            side = _side_stream(dev) if (overlap_bwd_w and ctx.needs_input_grad[0]) else None
+            side = _side_stream(dev) if (overlap_bwd_w and ctx.needs_input_grad[0] and (timers is None or not timers.active)) else None
             if side is not None:
                 # dW does not feed dx: it runs beside contract_bwd_x / recurrence_bwd on a second stream
                 side.wait_stream(torch.cuda.current_stream(dev))

@@ -280,8 +280,9 @@ def test_relu_grad_fold_is_bit_identical(ops, dev, lvl, B, Fin, Fout, K, bias):
     for name, a, c in zip(('out', 'dx', 'dW', 'dbias'), res[False], res[True]):
         if a is None:
             continue
-        if name == 'dbias' and bias == 1:
-            # the per-filter bias gradient is an atomic sum over workgroups: fp32 order varies run to run
+        if name == 'dbias':
+            # the two bias reductions split the batch differently (and the per-filter one is an atomic sum over
+            # workgroups): same terms, another fp32 summation order
             close(c.cpu().numpy(), a.cpu().numpy(), what=name)
         else:
             assert torch.equal(a, c), '%s differs between the folded and the separate ReluGrad' % name
