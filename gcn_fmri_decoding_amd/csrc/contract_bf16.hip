@@ -394,6 +394,170 @@ contract_bwd_w_bf16_kernel(BwdWBf16Args a) {
     for (int o = threadIdx.x; o < per; o += 256) dst[o] = lds[o];
 }
 
+// --------------------------------------------------------------------------------------------------
+// The same weight gradient for WIDE layers (Fin*K > 160 or Fout > 64) in ONE pass over the operands:
+// a workgroup of 8 waves owns a 320 x 256 tile of dW -- all of it at config 5 (300 x 256) -- so the
+// stack and dy are each read once (the 5x2-tile kernel above reads the stack 4 and dy 2 times there).
+// Wave (wy, wz) keeps the 5 x 2 tiles (rows 160 wy.., columns 64 wz..) in 160 accumulator registers;
+// no two waves share a tile, so there is no cross-wave reduction.
+// Operand ring: 4 buffers x [576 rows][16 vertices] fp32 (36 KB each) filled by LDS-DMA, three chunks
+// in flight while one is multiplied: one k-step of v_mfma_f32_32x32x16_bf16 per chunk.  A row is 64 B =
+// four 16-byte pieces, piece p of row r at position p ^ ((r >> 2) & 3) (applied on the source side of
+// the DMA), which makes the operand reads (16 lanes = 16 rows, same logical piece) conflict free.
+// A workgroup walks a CONTIGUOUS range of (window, 16-vertex) chunks, so the second half of every
+// 128-byte line it touches is an L2 hit a moment later.  One barrier per chunk; DMA waits are counted
+// by hand and the operands are read in asm blocks (compiler-visible LDS reads would wait for every DMA
+// in flight).
+constexpr int BWW_ROWS = 576;                    // 320 stack rows + 256 dy rows
+constexpr int BWW_BUF = BWW_ROWS * 64;           // bytes per ring buffer
+constexpr int BWW_NBUF = 4;
+
+template <int PASSES>
+__global__ void __launch_bounds__(512)
+contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];   // [BWW_NBUF][BWW_BUF]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wy = wave >> 2, wz = wave & 3;
+    const int c = lane & 31, g = lane >> 5;
+    const int row0 = blockIdx.y * 320, col0 = blockIdx.z * 256;
+
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[t][u][j] = 0.f;
+
+    // DMA instruction n = wave + 8u (n < 36) fills ring rows 16n..16n+15: lane l -> row 16n + l/4,
+    // position l%4, source piece (l%4) ^ ((row >> 2) & 3) = (l%4) ^ ((l >> 4) & 3) for every n
+    const int spiece = (lane & 3) ^ ((lane >> 4) & 3);
+    const int ndma = wave < 4 ? 5 : 4;
+    const float* rsrc[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int n = wave + 8 * u;
+        const int R = 16 * n + (lane >> 2);
+        if (n < 20) {
+            int kk = row0 + R;
+            if (kk >= a.FinK) kk = 0;                   // rows beyond Fin*K: dropped by the final scatter
+            const int fin = kk / a.K, k = kk - fin * a.K;
+            rsrc[u] = a.stack + (size_t)k * a.slab + (size_t)fin * a.Mp + 4 * spiece;
+        } else {
+            int fo = col0 + (R - 320);
+            if (fo >= a.Fout || n >= 36) fo = 0;
+            rsrc[u] = a.dy + (size_t)fo * a.Mp + 4 * spiece;
+        }
+    }
+    const int ch0 = (int)((long long)total_chunks * blockIdx.x / gridDim.x);
+    const int ch1 = (int)((long long)total_chunks * (blockIdx.x + 1) / gridDim.x);
+    auto issue = [&](int ch, int slot) {
+        const int b = ch / a.nchunks_m;
+        const int m0 = (ch - b * a.nchunks_m) * 16;
+        const size_t so = (size_t)b * a.Fin * a.Mp + m0, dof = (size_t)b * a.Fout * a.Mp + m0;
+        const unsigned base = (unsigned)(size_t)ring + slot * BWW_BUF;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int n = wave + 8 * u;
+            if (n < 36) {
+                const float* src = rsrc[u] + (n < 20 ? so : dof);
+                __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(base + n * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    if (ch0 >= ch1) goto flush;                          // (more workgroups than chunks)
+    {
+    // prologue: three chunks in flight (past the end of the range: harmless re-reads of the last chunk)
+#pragma unroll 1
+    for (int d = 0; d < BWW_NBUF - 1; ++d) issue(ch0 + d < ch1 ? ch0 + d : ch1 - 1, d);
+    // operand addresses of this lane inside a buffer: row tile * 2048 + c * 64 + 16 * (piece ^ swizzle)
+    const int sw = (c >> 2) & 3;
+    const unsigned offA0 = (wy * 5) * 2048 + c * 64 + 16 * ((2 * g) ^ sw);
+    const unsigned offA1 = (wy * 5) * 2048 + c * 64 + 16 * ((2 * g + 1) ^ sw);
+    const unsigned offB0 = 320 * 64 + (wz * 2) * 2048 + c * 64 + 16 * ((2 * g) ^ sw);
+    const unsigned offB1 = 320 * 64 + (wz * 2) * 2048 + c * 64 + 16 * ((2 * g + 1) ^ sw);
+
+    int slot = 0;
+#pragma unroll 1
+    for (int ch = ch0; ch < ch1; ++ch) {
+        // this wave's part of chunk `ch` is (BWW_NBUF-2) chunks of DMAs old
+        if (wave < 4) wait_vmcnt<2 * 5>(); else wait_vmcnt<2 * 4>();
+        __builtin_amdgcn_s_barrier();                    // everybody's part landed; everybody is done with the buffer refilled next
+        {
+            const int nx = ch + BWW_NBUF - 1;
+            issue(nx < ch1 ? nx : ch1 - 1, (slot + BWW_NBUF - 1) & (BWW_NBUF - 1));
+        }
+        const unsigned buf = (unsigned)(size_t)ring + slot * BWW_BUF;
+        slot = (slot + 1) & (BWW_NBUF - 1);
+        const int m0 = (ch % a.nchunks_m) * 16;
+        const bool tail = m0 + 16 > a.M;
+        const int nlive = a.M - m0 - 8 * g;             // vertices of this lane's eight that exist (tail chunks)
+
+        f32x4 rb[4];
+        {
+            const unsigned b0 = buf + offB0, b1 = buf + offB1;
+            asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %4 offset:2048\n"
+                         "ds_read_b128 %3, %5 offset:2048\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(rb[0]), "=&v"(rb[1]), "=&v"(rb[2]), "=&v"(rb[3]) : "v"(b0), "v"(b1) : "memory");
+        }
+        auto split = [&](f32x4 lo4, f32x4 hi4, bf16x8& hi, bf16x8& lo) {
+            float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            if (tail) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = i < nlive ? v[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                hi[i] = (__bf16)v[i];
+                if (PASSES == 3) lo[i] = (__bf16)(v[i] - (float)hi[i]);
+            }
+        };
+        bf16x8 bh[2], bl[2];
+        split(rb[0], rb[1], bh[0], bl[0]);
+        split(rb[2], rb[3], bh[1], bl[1]);
+
+        f32x4 ra[10];
+        {
+            const unsigned a0 = buf + offA0, a1 = buf + offA1;
+            asm volatile("ds_read_b128 %0, %10\n ds_read_b128 %1, %11\n ds_read_b128 %2, %10 offset:2048\n ds_read_b128 %3, %11 offset:2048\n"
+                         "ds_read_b128 %4, %10 offset:4096\n ds_read_b128 %5, %11 offset:4096\n ds_read_b128 %6, %10 offset:6144\n"
+                         "ds_read_b128 %7, %11 offset:6144\n ds_read_b128 %8, %10 offset:8192\n ds_read_b128 %9, %11 offset:8192\n"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(ra[0]), "=&v"(ra[1]), "=&v"(ra[2]), "=&v"(ra[3]), "=&v"(ra[4]), "=&v"(ra[5]), "=&v"(ra[6]),
+                           "=&v"(ra[7]), "=&v"(ra[8]), "=&v"(ra[9])
+                         : "v"(a0), "v"(a1) : "memory");
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            bf16x8 ah, al;
+            split(ra[2 * t], ra[2 * t + 1], ah, al);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (PASSES == 3) {
+                    acc[t][u] = mfma_bf16(al, bh[u], acc[t][u]);        // small terms first
+                    acc[t][u] = mfma_bf16(ah, bl[u], acc[t][u]);
+                }
+                acc[t][u] = mfma_bf16(ah, bh[u], acc[t][u]);
+            }
+        }
+    }
+    wait_vmcnt<0>();                                     // the run-ahead DMAs
+    }
+flush:
+    // every wave owns its tiles: the partial goes straight to the workspace in accumulator layout,
+    // rows ordered (row tile, column tile, register) as bwb_reduce_stage2 expects for rt = 10, ct = 8
+    float* dst = a.partial + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(10 * 8 * 16 * 64);
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                dst[(((wy * 5 + t) * 8 + (wz * 2 + u)) * 16 + j) * 64 + lane] = acc[t][u][j];
+}
+
 // partial: [Z][Y][X][rows*64] raw accumulator images (rows = RT*CT*16).  Stage 1: block
 // (row, y*S + s, z) sums the partials x = s, s+S, ... of one 64-lane accumulator row.
 __global__ void __launch_bounds__(256)
@@ -429,7 +593,7 @@ bwb_reduce_stage2(const float* __restrict__ stage, float* __restrict__ dW, int n
     if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = s;
 }
 
-struct BwbPlan { int rt, ct, gx, gy, gz; size_t per; };
+struct BwbPlan { int rt, ct, gx, gy, gz; size_t per; bool wide; };
 static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
     static int cus = 0;                       // cached: the attribute query is slow
     if (cus == 0) {
@@ -439,6 +603,18 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
             cus = 256;
     }
     BwbPlan p;
+    p.wide = Fin * K > 160 && Fout > 64;      // one pass over the operands: 320 x 256 tile per workgroup
+    if (p.wide) {
+        p.rt = 10; p.ct = 8;
+        p.gy = (Fin * K + 319) / 320;
+        p.gz = (Fout + 255) / 256;
+        const long long total = (long long)B * ((M + 15) / 16);
+        long long gx = cus / (p.gy * p.gz);   // 144 KB of LDS: one workgroup per CU
+        if (gx > total) gx = total;
+        p.gx = gx < 1 ? 1 : (int)gx;
+        p.per = (size_t)10 * 8 * 16 * 64;
+        return p;
+    }
     const int ntiles = (Fin * K + 31) / 32;
     p.rt = ntiles < 5 ? ntiles : 5;
     p.ct = Fout > 32 ? 2 : 1;
@@ -579,6 +755,21 @@ extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, 
     a.nchunks_m = (M + 63) / 64;
     a.slab = (size_t)B * Fin * a.Mp;
     const dim3 grid(p.gx, p.gy, p.gz);
+    if (p.wide) {
+        a.nchunks_m = (M + 15) / 16;
+        const size_t ldsw = (size_t)BWW_NBUF * BWW_BUF;
+        const long long total = (long long)B * a.nchunks_m;
+        CG_REQUIRE(total < (1ll << 31), "contract_bwd_w_bf16: too many chunks");
+        if (passes == 3) {
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_wide_kernel<3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+            hipLaunchKernelGGL(contract_bwd_w_bf16_wide_kernel<3>, grid, dim3(512), ldsw, stream, a, (int)total);
+        } else {
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_wide_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+            hipLaunchKernelGGL(contract_bwd_w_bf16_wide_kernel<1>, grid, dim3(512), ldsw, stream, a, (int)total);
+        }
+    }
     const size_t lds = (size_t)(p.rt + p.ct) * 32 * BWB_ROW * sizeof(float);
 #define CG_BWB(R, C, P)                                                                                   \
     if (p.rt == R && p.ct == C && passes == P) {                                                          \

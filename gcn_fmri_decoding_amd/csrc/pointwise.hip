@@ -72,14 +72,14 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
     }
 }
 
-// ---- bias gradient of a pool == 1 ReLU layer from (dout, ReLU bit mask) alone: the contraction
-// gradients gate dout themselves (contract_bwd_*_relu), so nothing but dbias is written here.
+// ---- ReluGrad + bias gradient of a pool == 1 layer from (dout, ReLU bit mask).  dy == NULL: the
+// contraction gradients gate dout themselves (contract_bwd_*_relu) and nothing but dbias is written.
 // thread = four consecutive vertices (one mask byte, one 16-byte load per window) of filter f and
 // one of four interleaved subsets of the batch; fixed-order LDS sum of the four subsets.
 template <int BIAS>
 __global__ void __launch_bounds__(256)
-bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dbias,
-                      int B, int M, int Mp, int F) {
+bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dy,
+                      float* __restrict__ dbias, int B, int M, int Mp, int F) {
     __shared__ float4 psum[256];
     const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int Mq = Mp >> 2;
@@ -95,10 +95,10 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * F * Mp));
             const int bits = mp[(size_t)b * F * Mq];
-            sum.x += (bits & 1) ? g.x : 0.f;
-            sum.y += (bits & 2) ? g.y : 0.f;
-            sum.z += (bits & 4) ? g.z : 0.f;
-            sum.w += (bits & 8) ? g.w : 0.f;
+            const float4 d = make_float4((bits & 1) ? g.x : 0.f, (bits & 2) ? g.y : 0.f, (bits & 4) ? g.z : 0.f,
+                                         (bits & 8) ? g.w : 0.f);
+            if (dy) *reinterpret_cast<float4*>(dy + ((size_t)b * F + f) * Mp + 4 * q) = d;
+            sum.x += d.x; sum.y += d.y; sum.z += d.z; sum.w += d.w;
         }
         const int m = 4 * q;                            // the padding of the plane takes no gradient
         sum.x = m + 0 < M ? sum.x : 0.f;
@@ -106,6 +106,7 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
         sum.z = m + 2 < M ? sum.z : 0.f;
         sum.w = m + 3 < M ? sum.w : 0.f;
     }
+    if (BIAS == CHEBGCN_BIAS_NONE) return;
     psum[threadIdx.x] = sum;
     __syncthreads();
     if (part == 0) {
@@ -274,14 +275,18 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
     CG_REQUIRE(pool == 1 || argmax || (pool_kind == CHEBGCN_POOL_AVG && !relu), "brelu_pool_bwd: pooling needs argmax/mask");
     CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || dbias, "brelu_pool_bwd: dbias is NULL");
     const int Mp = plane_stride(M), Mpo = plane_stride(M / pool);
-    if (!dy && pool == 1 && relu && argmax) {           // bias gradient alone, from the ReLU mask
+    if (pool == 1 && relu && argmax) {                  // ReLU mask of contract_fwd: vertices in fours, dy optional
+        const dim3 grid((Mp / 4 + 63) / 64, F);
         if (bias_kind == CHEBGCN_BIAS_FILTER) {
             CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, dim3((Mp / 4 + 63) / 64, F), dim3(256), 0, stream,
-                               dout, argmax, dbias, B, M, Mp, F);
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, B, M,
+                               Mp, F);
+        } else if (bias_kind == CHEBGCN_BIAS_VERTEX) {
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, B, M,
+                               Mp, F);
         } else {
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, dim3((Mp / 4 + 63) / 64, F), dim3(256), 0, stream,
-                               dout, argmax, dbias, B, M, Mp, F);
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_NONE>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, B, M,
+                               Mp, F);
         }
         CG_HIP(hipGetLastError());
         return CHEBGCN_OK;

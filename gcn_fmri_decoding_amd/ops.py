@@ -328,13 +328,14 @@ class ChebConv(torch.autograd.Function):
         # pool == 1 with ReLU: contract_fwd leaves a bit per vertex (the ReLU mask) and the gradients of the
         # contraction gate the incoming gradient themselves -- no dy tensor, no pass over `out` in backward
         fold = bool(fold_relu_grad and pool == 1 and relu and precision == 'f32')
-        if fold:
+        if pool == 1 and relu:
+            # the mask also serves the separate ReluGrad pass (bf16 gradients): a byte per four vertices instead of `out`
             argmax = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device)
         b = bias.detach() if bias is not None else None
         if b is not None and not b.is_contiguous():
             b = b.contiguous()
         contract_fwd_into(stack, Wc, b, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision)
-        ctx.save_for_backward(stack, Wc, None if fold else out, argmax)
+        ctx.save_for_backward(stack, Wc, None if (pool == 1 and relu) else out, argmax)
         ctx.fold = fold
         ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
@@ -370,7 +371,9 @@ class ChebConv(torch.autograd.Function):
                     _p(gout), None, _p(mask), None, _p(dbias), bias_kind, B, M, Fout, 1, pool_kind, 1, _stream())), 'brelu_pool_bwd')
         else:
             dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev), None
-            _lib.check(_launch('brelu_pool_bwd', 4.0 * B * Fout * (2 * Mo + M), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
+            # with the ReLU mask of a pool == 1 layer `out` is not read (a byte per four vertices instead)
+            nbytes = B * Fout * M * (8.0 + 0.25) if out is None else 4.0 * B * Fout * (2 * Mo + M)
+            _lib.check(_launch('brelu_pool_bwd', nbytes, 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
                 _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bias_kind if dbias is not None else BIAS_NONE, B, M, Fout,
                 pool, pool_kind, relu, _stream())), 'brelu_pool_bwd')
         dW = None
