@@ -28,7 +28,8 @@ def main():
     ap.add_argument('--K', type=int, default=5)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_fwd_inplace', 'recurrence_bwd', 'contract_fwd',
-                                                     'contract_bwd_w', 'contract_bwd_x', 'brelu_pool_bwd'])
+                                                     'contract_bwd_w_relu', 'contract_bwd_x_relu', 'bias_grad_relu', 'contract_bwd_w', 'contract_bwd_x',
+                                                     'brelu_pool_bwd'])
     ap.add_argument('--ablate', type=int, nargs='+', default=[0])
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (0 = automatic, 2, 4)')
@@ -85,6 +86,9 @@ def main():
         dW = torch.empty(Fin * K, Fout, device=dev)
         ws = torch.empty(lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout), dtype=torch.uint8, device=dev)
         ws16 = torch.empty(lib.chebgcn_contract_fwd_bf16_workspace(Fin, K, Fout), dtype=torch.uint8, device=dev)
+        wsx16 = torch.empty(lib.chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout), dtype=torch.uint8, device=dev)
+        wsw16 = torch.empty(lib.chebgcn_contract_bwd_w_bf16_workspace(B, M, Fin, K, Fout), dtype=torch.uint8, device=dev)
+        mask = torch.randint(0, 16, (B, Fout, Mp // 4), dtype=torch.uint8, device=dev)     # ReLU bit mask, half the bits set
         st = ops._stream()
         P = ops._p
         calls = {
@@ -109,6 +113,26 @@ def main():
                                4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
             'contract_bwd_x': (lambda: lib.chebgcn_contract_bwd_x(P(dy), P(W), P(gstack), B, M, Fin, K, Fout, st),
                                4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            # the gradients of a pool == 1 ReLU layer as the model runs them: ReluGrad folded in (bit mask)
+            'contract_bwd_w_relu': (lambda: lib.chebgcn_contract_bwd_w_relu(P(stack), P(dy), P(mask), P(dW), P(ws), ws.numel(), B, M,
+                                                                            Fin, K, Fout, st),
+                                    B * M * (4.0 * (Fin * K + Fout) + Fout / 4.0), 2.0 * B * M * Fin * K * Fout),
+            'contract_bwd_x_relu': (lambda: lib.chebgcn_contract_bwd_x_relu(P(dy), P(mask), P(W), P(gstack), B, M, Fin, K, Fout, st),
+                                    B * M * (4.0 * (Fin * K + Fout) + Fout / 4.0), 2.0 * B * M * Fin * K * Fout),
+            'bias_grad_relu': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), None, P(mask), None, P(dbias), 2, B, M, Fout, 1, 0, 1, st),
+                               B * Fout * M * 4.25, 0.0),
+            'contract_bwd_w_bf16': (lambda: lib.chebgcn_contract_bwd_w_bf16(P(stack), P(dy), P(dW), P(wsw16), wsw16.numel(), B, M, Fin,
+                                                                            K, Fout, 1, st),
+                                    4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_bwd_w_bf16x3': (lambda: lib.chebgcn_contract_bwd_w_bf16(P(stack), P(dy), P(dW), P(wsw16), wsw16.numel(), B, M,
+                                                                              Fin, K, Fout, 3, st),
+                                      4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_bwd_x_bf16': (lambda: lib.chebgcn_contract_bwd_x_bf16(P(dy), P(W), P(gstack), B, M, Fin, K, Fout, 1, P(wsx16),
+                                                                            wsx16.numel(), st),
+                                    4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_bwd_x_bf16x3': (lambda: lib.chebgcn_contract_bwd_x_bf16(P(dy), P(W), P(gstack), B, M, Fin, K, Fout, 3, P(wsx16),
+                                                                              wsx16.numel(), st),
+                                      4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
             'brelu_pool_bwd': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), P(out), None, P(dx) if Fin == Fout else P(out),
                                                                   P(dbias), 2, B, M, Fout, 1, 0, 1, st),
                                4.0 * B * Fout * 3 * M, 0.0),

@@ -11,8 +11,8 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
            "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_MFMA" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o a$i -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --iters 3 --kernels contract_fwd contract_bwd_w contract_bwd_x > $out/a$i.log 2>&1
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o b$i -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 3 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 > $out/b$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o a$i -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --iters 3 --kernels contract_fwd contract_bwd_w_relu contract_bwd_x_relu > $out/a$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out -o b$i -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 3 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x_bf16 contract_bwd_x_bf16x3 > $out/b$i.log 2>&1
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections, json
@@ -22,7 +22,7 @@ for f in sorted(glob.glob(out + '/**/*counter_collection.csv', recursive=True)):
     shape = 'config5' if '/b' in f.replace(out, '') else 'bench'
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'contract' not in k and 'reduce_partials' not in k: continue
+        if 'contract' not in k and 'reduce' not in k: continue
         acc[shape + ' ' + k[:70]][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {}
 for k, d in sorted(acc.items()):

@@ -10,7 +10,7 @@ python3 bench.py > $out/bench_line.json 2> $out/bench.err
 python3 tools/kbench.py --json $out/kbench.json > $out/kbench.txt 2>&1
 python3 tools/kbench.py --planes 2 --B 64 256 --kernels recurrence_fwd recurrence_fwd_inplace recurrence_bwd > $out/kbench_two_planes.txt 2>&1
 python3 tools/kbench.py --B 64 256 --fin 64 --K 25 --kernels recurrence_fwd_inplace recurrence_bwd --iters 5 > $out/kbench_config4.txt 2>&1
-python3 tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_x --iters 10 > $out/kbench_config5.txt 2>&1
+python3 tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 --iters 10 > $out/kbench_config5.txt 2>&1
 bash tools/pmc_traffic.sh refresh > $out/traffic.log 2>&1
 cp gpurun_out/traffic_refresh/traffic_raw.json $out/ 2>/dev/null
 bash tools/pmc_mfma.sh refresh > $out/mfma.txt 2>&1
@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- py
 find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4 -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 5 --kernels recurrence_fwd_inplace recurrence_bwd contract_fwd contract_bwd_w contract_bwd_x > $out/prof4.log 2>&1
 find $out/prof4 -name "*kernel_stats.csv" -exec cp {} $out/config4_kernel_stats.csv \;
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -o c5 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 5 --kernels recurrence_fwd_inplace contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_x > $out/prof5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -o c5 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 5 --kernels recurrence_fwd_inplace contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 > $out/prof5.log 2>&1
 find $out/prof5 -name "*kernel_stats.csv" -exec cp {} $out/config5_kernel_stats.csv \;
 rm -rf $out/prof $out/prof4 $out/prof5
 ls -la $out
