@@ -19,6 +19,20 @@
 // (a 32 x 2 sliver of W) is 8 B per lane from L1/L2.
 #include "contract_common.h"
 
+// Waves per SIMD the register allocation is held to (second __launch_bounds__ argument).  Left alone the
+// compiler parks the accumulators in AGPRs and spends VGPRs freely: 171 registers for contract_bwd_w_kernel<5>,
+// one more than three workgroups per CU allow.  (Holding contract_fwd to four waves or contract_bwd_x to three
+// makes them spill: measured slower or equal, left at the compiler's choice.)
+#ifndef CG_LB_FWD
+#define CG_LB_FWD 1
+#endif
+#ifndef CG_LB_BWX
+#define CG_LB_BWX 1
+#endif
+#ifndef CG_LB_BWW
+#define CG_LB_BWW 3          // 48 KB of LDS per workgroup allow three: 0.138 -> 0.120 ms at the bench shape
+#endif
+
 namespace chebgcn {
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
@@ -31,7 +45,7 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 constexpr int FWD_UNROLL = 8;
 
 template <int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NT == 1 ? CG_LB_FWD : 1)
 contract_fwd_kernel(FwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,7 +126,7 @@ struct BwdXArgs {
 
 // HOLD: dy tile (Fout <= 32 -> 16 float4 per lane) stays in registers across the row tiles.
 template <bool HOLD, bool MASK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, CG_LB_BWX)
 contract_bwd_x_kernel(BwdXArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -235,12 +249,12 @@ struct BwdWArgs {
 constexpr int BW_ROW = 64;       // floats per LDS row (one chunk)
 
 template <int RT, bool MASK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, CG_LB_BWW)
 contract_bwd_w_kernel(BwdWArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [(RT+1)*32][64]
     constexpr int NROWS = (RT + 1) * 32;
     constexpr int NDMA = NROWS / 4;                     // wave instructions per chunk (4 rows each)
-    constexpr int PER_WAVE = (NDMA + 3) / 4;
+    constexpr int PER_WAVE = NDMA / 4;                  // 2 (RT + 1), exact
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -253,26 +267,25 @@ contract_bwd_w_kernel(BwdWArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
-    // rows this lane fetches: instruction n covers rows 4n..4n+3, lane l -> row 4n + l/16, piece l%16
-    size_t roff[PER_WAVE];                              // plane offset (without the window part)
-    int rwin[PER_WAVE];                                 // per-window stride of that row's tensor
-    int rpiece[PER_WAVE];                               // source piece after the swizzle
+    // rows this lane fetches: DMA instruction n = wave + 4u covers rows 4n..4n+3, lane l -> row 4n + l/16,
+    // LDS piece l%16, source piece (l%16) ^ (row%16) -- the same for every u because 16 divides the row step.
+    // One pointer per instruction (row base + source piece) is all the bookkeeping: the register budget of this
+    // kernel decides between two and three workgroups per CU.
+    const int rsw = (lane & 15) ^ ((4 * wave + (lane >> 4)) & 15);
+    const float* rsrc[PER_WAVE];
 #pragma unroll
     for (int u = 0; u < PER_WAVE; ++u) {
         const int n = wave + 4 * u;
         const int row = 4 * n + (lane >> 4);
-        rpiece[u] = (lane & 15) ^ (row & 15);
-        if (row < RT * 32) {
-            int kk = (tile0 + row / 32) * 32 + (row & 31);
+        if (n < RT * 8) {
+            int kk = tile0 * 32 + row;
             if (kk >= a.FinK) kk = 0;                   // masked later (A rows beyond Fin*K)
             const int fin = kk / a.K, k = kk - fin * a.K;
-            roff[u] = (size_t)k * a.slab + (size_t)fin * a.Mp;
-            rwin[u] = a.Fin;
+            rsrc[u] = a.stack + (size_t)k * a.slab + (size_t)fin * a.Mp + 4 * rsw;
         } else {
             int fo = fo0 + (row - RT * 32);
             if (fo >= a.Fout) fo = 0;
-            roff[u] = (size_t)fo * a.Mp;
-            rwin[u] = -a.Fout;                          // negative: the row comes from dy
+            rsrc[u] = a.dy + (size_t)fo * a.Mp + 4 * rsw;
         }
     }
     bool a_ok[RT];
@@ -293,16 +306,13 @@ contract_bwd_w_kernel(BwdWArgs a) {
                 gate[q] = (b_ok && quad < (a.Mp >> 2)) ? a.mask[((size_t)b * a.Fout + fo0 + c) * (a.Mp >> 2) + quad] : 0;
             }
         }
+        const ptrdiff_t mo = (m0 + 4 * rsw < a.Mp) ? m0 : -4 * rsw;   // beyond the plane: any valid address, masked below
+        const ptrdiff_t so = (ptrdiff_t)b * a.Fin * a.Mp + mo, dof = (ptrdiff_t)b * a.Fout * a.Mp + mo;
 #pragma unroll
         for (int u = 0; u < PER_WAVE; ++u) {
             const int n = wave + 4 * u;
-            if (n < NDMA) {
-                int m = m0 + 4 * rpiece[u];
-                if (m >= a.Mp) m = 0;                   // beyond the plane: any valid address, masked below
-                const float* src = (rwin[u] > 0 ? a.stack + (size_t)b * a.Fin * a.Mp : a.dy + (size_t)b * a.Fout * a.Mp)
-                                   + roff[u] + m;
-                __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 2);   // aux 2 = nt: every chunk is read once
-            }
+            const float* src = rsrc[u] + (n < RT * 8 ? so : dof);
+            __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 2);   // aux 2 = nt: every chunk is read once
         }
         __syncthreads();                                // DMA landed (the barrier's release waits vmcnt(0))
 
