@@ -36,15 +36,11 @@
 
 namespace chebgcn {
 
-int g_ablate = 0;   // set through chebgcn_tune(0, bits) by tools/kbench.py; 0 in production
 int g_stagger = 0;          // chebgcn_tune(4, x): 0 = automatic
 int g_wide = 0;            // chebgcn_tune(3, 1): prefer the 1024-thread shape (experiment)
 
 #ifndef CG_X
-#define CG_X 0               // timing experiments only (tools/xbuild.sh); results are wrong when non-zero
-#endif
-#ifndef CG_ABL
-#define CG_ABL 0             // 1: honour the ablation bits of chebgcn_tune(0, bits) (tools/xbuild.sh); 0 in production
+#define CG_X 0               // 64: in-kernel phase stamps (tools/xbuild.sh, tools/kbench.py --stamps); 0 in production
 #endif
 constexpr int QMAX = 3;      // quads (4 operator entries each) requested per group, always, one group ahead
 static_assert(QMAX <= kQuadPad && QMAX == kQuadMin, "the operator arrays are padded for the unconditional requests");
@@ -164,9 +160,6 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     constexpr int nthr = NTHR;
     constexpr int nwaves = NTHR >> 6;
     const int copy_t0 = flags & 1;
-    // ablation bits for tools/kbench.py (always 0 in production):
-    // 1 = no global stores, 2 = no gather, 16 = no global loads, 32 = no start stagger
-    const int abl = CG_ABL ? flags >> 8 : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -220,7 +213,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     // One-off stagger of the workgroups of an XCD (blockIdx % 8 selects the XCD): started in
     // lock-step, all CUs would stream from L2, gather from LDS and write to HBM at the same
     // times; spread over roughly one step they overlap each other's phases instead.
-    if (!(abl & 32)) {
+    {
         // ... scaled with the number of groups a workgroup works through
         const int gpw = (ngrp + (int)gridDim.x - 1) / (int)gridDim.x;
         const int sx = (flags >> 20) & 0xFF;             // chebgcn_tune(4, x): stagger in 1/8 units of 640 cycles per rank (experiment)
@@ -241,7 +234,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             const int q = tid + u * nthr;
 #pragma unroll
             for (int p = 0; p < P; ++p) pre[u][p] = zero4;
-            if (q < Mq && !(abl & 16)) {
+            if (q < Mq) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) pre[u][p] = ldg4(base + (size_t)plane_of(grp, p) * Mp + 4 * q);
             }
@@ -250,7 +243,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
     // LDS -> P planes of slab `out`; isolated vertices get sign * xiso (forward) ------------
     auto copy_out_piece = [&](int u, float* out, int grp, float iso_sign, const float* xiso) {
         const int q = tid + u * nthr;
-        if (q < Mq && !(abl & 1)) {
+        if (q < Mq) {
             const uint2 nq = opaque(nsreg[u]);
             if constexpr (P == 4) {
                 // two plane pairs one after the other (8-byte LDS reads): half the live registers
@@ -325,7 +318,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                     for (int p = 0; p < P; ++p) t.x[p] = comp(pre[u][p], i);
                     lds_put<P>(T, wr_slot(slot_of(nq, i)), t);
                 }
-                if (!ADJ && copy_t0 && !(abl & 1)) {            // T_0 = x goes straight to slab 0
+                if (!ADJ && copy_t0) {            // T_0 = x goes straight to slab 0
 #pragma unroll
                     for (int p = 0; p < P; ++p)
                         if (grp * P + p < nplanes) stg4(dst + (size_t)(grp * P + p) * Mp + 4 * q, pre[u][p]);
@@ -356,17 +349,16 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             }
         };
         auto finish_step = [&](int sdone, bool last) {
-            if (ADJ && (CG_X & 2048)) fetch(src + (size_t)(K - 1 - sdone) * slab, grp);   // experiment: before the barrier
             CG_STAMP(4 * sdone + 0);
-            if (!(CG_X & 32)) __syncthreads();                  // every gather (and copy-out read) of this step is done
+            __syncthreads();                                    // every gather (and copy-out read) of this step is done
             CG_STAMP(4 * sdone + 1);
             // forward: only now, behind the barrier -- HBM loads queued while other waves still
             // gather would hold up their operator loads (the vector memory pipeline returns in order)
             if (!ADJ && last) fetch_next();
             // adjoint: G_j of the finished step, added after the rotate
-            if (ADJ && !(CG_X & 2048)) fetch(src + (size_t)(K - 1 - sdone) * slab, grp);
+            if (ADJ) fetch(src + (size_t)(K - 1 - sdone) * slab, grp);
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
-            if (!(CG_X & 16)) {
+            {
                 Ent<P> prev[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
@@ -381,7 +373,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 }
             }
             CG_STAMP(4 * sdone + 2);
-            if (!(CG_X & 32)) __syncthreads();
+            __syncthreads();
             CG_STAMP(4 * sdone + 3);
             if (ADJ) {
                 // ---- c_j += G_j, linear --------------------------------------------------------
@@ -429,8 +421,6 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 // {quad offset, length} of group j*nwaves + wave, from lane j of the wave's table
                 qoff = __builtin_amdgcn_readlane(gtab.x, j);
                 len = __builtin_amdgcn_readlane(gtab.y, j);
-                if (abl & 2) { qoff = 0; len = 0; }
-                if (CG_X & 1) qoff = 0;              // experiment: operator always from the same (L1-resident) quads
             };
             // buffer loads: descriptor + uniform offset in SGPRs, lane offset in one VGPR -- no 64-bit
             // address arithmetic on the vector ALU.  Ids come eight at a time (one record per two
@@ -438,9 +428,8 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             auto request_ids = [&](int j, int o) {   // id record o of group j -> its ring slot
                 int qoff, len;
                 group_info(j, qoff, len);
-                if ((CG_X & 4) && j > 1) return;               // experiment: no operator loads after the prologue
                 if (o >= 1 && len <= 10) return;               // the second record only beyond 10 entries (9..10: ids in the value record)
-                if (j < JL && o < 2 && !(CG_X & 32768)) {      // resident in LDS (j is a compile-time constant here)
+                if (j < JL && o < 2) {      // resident in LDS (j is a compile-time constant here)
                     ro[(QO * j + o) % ORING] = idrec[((j * nwaves + wave) * 2 + o) * 64 + lane];
                     return;
                 }
@@ -450,7 +439,6 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             auto request = [&](int j, int q) {       // values of quad q of group j -> their ring slot
                 int qoff, len;
                 group_info(j, qoff, len);
-                if ((CG_X & 4) && j > 1) return;
                 if (q >= 2 && len <= 8) return;                // the third quad only where a row needs it
                 const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(valq_rsrc, lane * 16, (qoff + q) * 1024, 0);
                 rv[(QMAX * j + q) % RING] = make_float4(v.x, v.y, v.z, v.w);
@@ -471,8 +459,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 unsigned at[4] = {entry_ofs<P, 0>(c.x), entry_ofs<P, 1>(c.x), entry_ofs<P, 0>(c.y), entry_ofs<P, 1>(c.y)};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    t[i] = lds_at<P>(T, (CG_X & 512) ? (at[i] & 4u) + (lane + 64 * i) * 4 * P       // conflict-free, still data-dependent
-                                        : (CG_X & 2) ? (lane + 64 * i) * 4 * P : at[i]);
+                    t[i] = lds_at<P>(T, at[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -494,7 +481,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 if (!ADJ && do_out && j >= NJ - NQ) copy_out_piece(j - (NJ - NQ), out_slab, grp, iso_sign, src);
                 // waves that are ahead yield to the ones behind, so that the waves of a SIMD reach
                 // the barrier together instead of the oldest finishing early (fewer waves = less overlap)
-                if (!(CG_X & 1024) && NJ >= 4 && (j == 0 || (4 * j) / NJ != (4 * (j - 1)) / NJ)) {
+                if (NJ >= 4 && (j == 0 || (4 * j) / NJ != (4 * (j - 1)) / NJ)) {
                     const int pr = 3 - (4 * j) / NJ;
                     if (pr == 3) __builtin_amdgcn_s_setprio(3);
                     else if (pr == 2) __builtin_amdgcn_s_setprio(2);
@@ -506,7 +493,6 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                 float acc[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) acc[p] = 0.f;
-                const bool gather = !(abl & 2);
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) {
                     // the first two quads always (zero-padded), the third for rows beyond 8 entries
@@ -514,17 +500,17 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
                     // copy that prepares .w as a v_pk_fma operand into the block of the CONDITIONAL third-quad
                     // request, where it needs `s_waitcnt vmcnt(0)` right behind the load -- the whole operator
                     // ring drained once per level)
-                    if (gather && q == 2 && len > 8 && len <= 10) {
+                    if (q == 2 && len > 8 && len <= 10) {
                         // a third quad of two entries: their ids are the .z word of the value record
                         const float4 v = opaque(rv[(QMAX * j + q) % RING]);
                         pair(__float_as_uint(v.z), v.x, v.y, acc);
-                    } else if (gather && (q < 2 || len > 10)) quad(ids_of(j, q), opaque(rv[(QMAX * j + q) % RING]), acc);
+                    } else if (q < 2 || len > 10) quad(ids_of(j, q), opaque(rv[(QMAX * j + q) % RING]), acc);
                     if (j + 2 < NJ) {
                         request(j + 2, q);                       // refill the slots just consumed
                         if ((q & 1) || q == QMAX - 1) request_ids(j + 2, q >> 1);
                     }
                 }
-                if (gather && len > 4 * QMAX) {
+                if (len > 4 * QMAX) {
                     for (int q = QMAX; 4 * q < len; ++q) {       // rows longer than 4*QMAX entries (rare)
                         const uint4 o = e.colo[(size_t)((qoff >> 1) + (q >> 1)) * 64 + lane];
                         const float4 v = e.valq[(size_t)(qoff + q) * 64 + lane];
@@ -549,7 +535,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
                 const int q = tid + u * nthr;
-                if (q < Mq && !(abl & 1)) {
+                if (q < Mq) {
                     float4 o[P];
                     unsigned iso = 0;
                     const uint2 nq = opaque(nsreg[u]);
@@ -619,7 +605,7 @@ static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* sr
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), 0, stream, view(ell), src, dst, g->M, g->Mp,
-                       nplanes, K, slab, copy_t0 | ((g_ablate & 0xFFF) << 8) | (g_stagger << 20));
+                       nplanes, K, slab, copy_t0 | (g_stagger << 20));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
@@ -671,7 +657,6 @@ extern "C" int chebgcn_debug_stamps(long long* out) {       // CG_X & 64 builds 
 }
 
 extern "C" int chebgcn_tune(int key, int value) {
-    if (key == 0) { g_ablate = value; return 0; }
     if (key == 3) { g_wide = value; return 0; }
     if (key == 4) { g_stagger = value & 0xFF; return 0; }
     return -1;

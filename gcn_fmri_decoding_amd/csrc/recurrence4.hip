@@ -34,7 +34,7 @@ extern int g_ablate;
 extern int g_stagger;
 
 #ifndef CG_X
-#define CG_X 0               // timing experiments only (tools/xbuild.sh)
+#define CG_X 0               // 64: in-kernel phase stamps (tools/xbuild.sh, tools/kbench.py --stamps); 0 in production
 #endif
 // In-kernel phase stamps (CG_X & 64, tools/xbuild.sh): lane 0 of every wave of workgroup 37 records the
 // cycle counter at the phase boundaries of its SECOND plane group (tools/kbench.py --stamps).
@@ -490,11 +490,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 acc = fma4(v1, t1, acc);
             };
             auto quad = [&](const uint2 c, const float4 v, float4& acc) {
-                unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
-                if (CG_X & 512) {                    // experiment: conflict-free, still data-dependent addresses (wrong results)
-                    a0 = (a0 & 4096u) + lane * 16u; a1 = (a1 & 4096u) + lane * 16u + 1024u;
-                    a2 = (a2 & 4096u) + lane * 16u + 2048u; a3 = (a3 & 4096u) + lane * 16u + 3072u;
-                }
+                const unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
                 const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3);
                 acc = fma4(v.x, t0, acc);
                 acc = fma4(v.y, t1, acc);

@@ -2,12 +2,10 @@
 """Per-kernel micro-benchmark of libchebgcn.so on the benchmark graph (M = 10466).
 
     python tools/kbench.py [--B 64 256] [--fin 32] [--fout 32] [--K 5] [--iters 20]
-                           [--kernels recurrence_fwd ...] [--ablate 0 1 2 ...]
+                           [--kernels recurrence_fwd ...]
 
 Times each C-ABI entry point with HIP events on the launch stream and prints achieved
 algorithmic GB/s (SURVEY.md 8d byte counts) and the fraction of the 8 TB/s HBM roofline.
-``--ablate`` sets the undeclared chebgcn_tune(0, bits) knob of the recurrence kernel
-(1 no stores, 2 no gather, 4 synthetic operator, 8 no LDS reads, 16 no loads).
 """
 import argparse
 import json
@@ -30,7 +28,6 @@ def main():
     ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_fwd_inplace', 'recurrence_bwd', 'contract_fwd',
                                                      'contract_bwd_w_relu', 'contract_bwd_x_relu', 'bias_grad_relu', 'contract_bwd_w', 'contract_bwd_x',
                                                      'brelu_pool_bwd'])
-    ap.add_argument('--ablate', type=int, nargs='+', default=[0])
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (0 = automatic, 2, 4)')
     ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
@@ -47,8 +44,8 @@ def main():
     import ctypes
     handle = ctypes.CDLL(_lib.LIB_PATH)
     tune = getattr(handle, 'chebgcn_tune', None)          # experiment builds only (tools/xbuild.sh, CHEBGCN_LIB=...)
-    if tune is None and (args.wide or args.stagger or args.ablate != [0] or args.stamps):
-        raise SystemExit('--wide / --stagger / --ablate / --stamps need an experiment build (tools/xbuild.sh)')
+    if tune is None and (args.wide or args.stagger or args.stamps):
+        raise SystemExit('--wide / --stagger / --stamps need an experiment build (tools/xbuild.sh)')
     if tune is not None:
         tune(3, args.wide)
         tune(4, args.stagger)
@@ -139,13 +136,8 @@ def main():
         }
         for name in args.kernels:
             fn, nbytes, flops = calls[name]
-            abls = args.ablate if name.startswith('recurrence') else [0]
-            for abl in abls:
-                if tune is not None:
-                    tune(0, abl)
+            for abl in [0]:
                 med, best = timeit(lambda: _lib.check(fn(), name), args.iters)
-                if tune is not None:
-                    tune(0, 0)
                 r = {'kernel': name, 'B': B, 'Fin': Fin, 'Fout': Fout, 'K': K, 'ablate': abl, 'median_ms': med,
                      'min_ms': best, 'GBps': nbytes / med / 1e6, 'frac_hbm': nbytes / med / 1e6 / 8000.0,
                      'TFLOPs': flops / med / 1e9}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds timing-experiment variants of the library (recurrence.hip compiled with -DCG_X=<bits>)
+# Builds experiment variants of the library (recurrence*.hip with -DCG_EXPERIMENT -DCG_X=<bits>; 64 = phase stamps)
 # into build_x/libchebgcn_x<bits>.so; select one with CHEBGCN_LIB=... python tools/kbench.py.
 set -e
 cd "$(dirname "$0")/../gcn_fmri_decoding_amd/csrc"
@@ -7,7 +7,7 @@ make -s
 mkdir -p ../../build_x
 for x in "$@"; do
   for f in recurrence recurrence4; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -DCG_EXPERIMENT=1 -DCG_X=$x -DCG_ABL=${CG_ABL:-0} -c $f.hip -o ../../build_x/${f}_x$x.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -DCG_EXPERIMENT=1 -DCG_X=$x -c $f.hip -o ../../build_x/${f}_x$x.o
   done
   /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 graph.o ../../build_x/recurrence_x$x.o ../../build_x/recurrence4_x$x.o contract.o contract_bf16.o pointwise.o coarsen_host.o -o ../../build_x/libchebgcn_x$x.so
 done
