@@ -63,21 +63,26 @@ pack_w_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ Wp, int Fin
 // block (compiler-visible LDS reads would be ordered behind every DMA in flight).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int PASSES>
+// NW = waves per workgroup = 64-filter slices per work item: 4 (256 filters), or 5 (320) where that pads the
+// filter count less -- the gradient wrt the stack at config 5 has 300 "filters" (rows Fin*K): one group of 320
+// instead of two of 256.  The fifth wave takes no part in the stack DMA (16 rows = 4 waves x 4).
+template <int PASSES, int NW>
 struct Bf16Cfg {
     static constexpr int PARTS = PASSES == 3 ? 2 : 1;
-    static constexpr int STAGE = 8192 + PARTS * 8192;             // bytes
-    static constexpr int NSTAGE = PASSES == 3 ? 6 : 9;            // 144 KB either way
+    static constexpr int WPART = NW * 64 * 32;                    // bytes of one bf16 image of W per stage
+    static constexpr int STAGE = 8192 + PARTS * WPART;            // bytes
+    static constexpr int NSTAGE = (147456 / STAGE);               // 9 / 6 stages (NW = 4), 8 / 5 (NW = 5): <= 144 KB
     static constexpr int DEPTH = NSTAGE - 2;
-    static constexpr int NDMA = 2 + 2 * PARTS;                    // wave instructions per wave and stage
+    static constexpr int NDMA = 2 + 2 * PARTS;                    // wave instructions per wave and stage (waves 0..3)
+    static constexpr int NDMA_W = 2 * PARTS;                      // ... of the fifth wave
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int PASSES>
-__global__ void __launch_bounds__(256)
+template <int PASSES, int NW>
+__global__ void __launch_bounds__(NW * 64)
 contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int FoutP, int ntm, int nitems) {
-    using C = Bf16Cfg<PASSES>;
+    using C = Bf16Cfg<PASSES, NW>;
     extern __shared__ __attribute__((aligned(16))) char ring[];         // [NSTAGE][STAGE]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -102,7 +107,7 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
         int m = item_mt(p_it) * 128 + 4 * c;
         if (m >= a.Mp) m = 0;                                      // beyond the plane: any readable address, never stored
         p_base = a.stack + (size_t)item_b(p_it) * a.Fin * a.Mp + m;
-        p_w = Wp + (size_t)item_z(p_it) * 256 * 16 + (size_t)wave * 1024 + lane * 8;
+        p_w = Wp + (size_t)item_z(p_it) * (NW * 64) * 16 + (size_t)wave * 1024 + lane * 8;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int row = 4 * wave + 2 * q + g;
@@ -116,6 +121,7 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
         const unsigned stage = (unsigned)(size_t)ring + slot * C::STAGE;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            if (NW > 4 && wave >= 4) break;                           // the stack rows belong to the first four waves
             // rows beyond Fin*K re-read the last plane (finite data) against zero weights
             const bool live = pf[q] < a.Fin;
             const int fin = live ? pf[q] : a.Fin - 1, k = live ? pk[q] : a.K - 1;
@@ -132,7 +138,7 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
             for (int q = 0; q < 2; ++q)
                 __builtin_amdgcn_global_load_lds(p_w + part * lo_part + q * 512,
                                                  reinterpret_cast<__attribute__((address_space(3))) void*>(
-                                                     stage + 8192 + part * 8192 + wave * 2048 + q * 1024),
+                                                     stage + 8192 + part * C::WPART + wave * 2048 + q * 1024),
                                                  16, 0, 0);
         p_w += w_step;
         if (++p_ks == nks) {
@@ -149,7 +155,7 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
     int cslot = 0;
 
     for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int fo0 = (item_z(it) * 4 + wave) * 64;
+        const int fo0 = (item_z(it) * NW + wave) * 64;
         const int b = item_b(it);
         const int n0 = item_mt(it) * 128 + 4 * c;
         const bool valid = n0 < a.Mp;
@@ -165,10 +171,12 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
         for (int ks = 0; ks < nks; ++ks) {
             produce(pslot);
             pslot = pslot + 1 == C::NSTAGE ? 0 : pslot + 1;
-            wait_vmcnt<C::DEPTH * C::NDMA>();                  // this wave's part of stage `cslot` has landed
+            // this wave's part of stage `cslot` has landed
+            if (NW > 4 && wave >= 4) wait_vmcnt<C::DEPTH * C::NDMA_W>(); else wait_vmcnt<C::DEPTH * C::NDMA>();
             __builtin_amdgcn_s_barrier();                      // ... and everybody else's
             const unsigned xb = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + g * 4096 + c * 16;
             const unsigned ab = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + 8192 + (64 * wave + c) * 32 + 16 * g;
+            const unsigned ab2 = ab + C::WPART;                // the lo image (PASSES == 3)
             f32x4 x[8];
             i32x4 ar[2 * C::PARTS];
             if (PASSES == 3) {
@@ -177,10 +185,10 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
                     "ds_read_b128 %3, %12 offset:1536\n ds_read_b128 %4, %12 offset:2048\n ds_read_b128 %5, %12 offset:2560\n"
                     "ds_read_b128 %6, %12 offset:3072\n ds_read_b128 %7, %12 offset:3584\n"
                     "ds_read_b128 %8, %13\n ds_read_b128 %9, %13 offset:1024\n"
-                    "ds_read_b128 %10, %13 offset:8192\n ds_read_b128 %11, %13 offset:9216\n s_waitcnt lgkmcnt(0)"
+                    "ds_read_b128 %10, %14\n ds_read_b128 %11, %14 offset:1024\n s_waitcnt lgkmcnt(0)"
                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
                       "=&v"(ar[0]), "=&v"(ar[1]), "=&v"(ar[2 % (2 * C::PARTS)]), "=&v"(ar[3 % (2 * C::PARTS)])
-                    : "v"(xb), "v"(ab)
+                    : "v"(xb), "v"(ab), "v"(ab2)
                     : "memory");
             } else {
                 asm volatile(
@@ -223,22 +231,27 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
         if (fo0 < a.Fout) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                // the 16 per-vertex bias rows of the tile are requested together (one round trip)
-                float4 bb[16];
+                // the per-vertex bias rows of the tile are requested together (one round trip): all 16 with the
+                // whole register file (NW = 4), 4 at a time where two waves share a SIMD (NW = 5)
+                constexpr int JB = NW > 4 ? 4 : 16;
                 const bool vb = a.bias_kind == CHEBGCN_BIAS_VERTEX;
-                if (vb) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int fo = fo0 + 32 * t + acc_row(j, g);
-                        const int foc = fo < a.Fout ? fo : a.Fout - 1;
-                        bb[j] = *reinterpret_cast<const float4*>(a.bias + (size_t)foc * a.Mp + (valid ? n0 : 0));
+                for (int j0 = 0; j0 < 16; j0 += JB) {
+                    float4 bb[JB];
+                    if (vb) {
+#pragma unroll
+                        for (int j = 0; j < JB; ++j) {
+                            const int fo = fo0 + 32 * t + acc_row(j0 + j, g);
+                            const int foc = fo < a.Fout ? fo : a.Fout - 1;
+                            bb[j] = *reinterpret_cast<const float4*>(a.bias + (size_t)foc * a.Mp + (valid ? n0 : 0));
+                        }
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int fo = fo0 + 32 * t + acc_row(j, g);
-                    float v[4] = {acc[t][0][j], acc[t][1][j], acc[t][2][j], acc[t][3][j]};
-                    fwd_epilogue_row(a, b, fo, v, n0, valid, c, vb, vb ? bb[j] : make_float4(0.f, 0.f, 0.f, 0.f));
+                    for (int j = 0; j < JB; ++j) {
+                        const int fo = fo0 + 32 * t + acc_row(j0 + j, g);
+                        float v[4] = {acc[t][0][j0 + j], acc[t][1][j0 + j], acc[t][2][j0 + j], acc[t][3][j0 + j]};
+                        fwd_epilogue_row(a, b, fo, v, n0, valid, c, vb, vb ? bb[j] : make_float4(0.f, 0.f, 0.f, 0.f));
+                    }
                 }
             }
         }
@@ -632,7 +645,7 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
 
 using namespace chebgcn;
 
-static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream);
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw);
 
 extern "C" size_t chebgcn_contract_fwd_bf16_workspace(int Fin, int K, int Fout) {
     if (Fin <= 0 || K <= 0 || Fout <= 0) return 0;
@@ -668,31 +681,35 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
                        a.FinK, Fout, nks, FoutP, passes == 3 ? 2 : 1, 0);
     CG_HIP(hipGetLastError());
-    return launch_contract_bf16(a, passes, workspace, stream);
+    return launch_contract_bf16(a, passes, workspace, stream, 4);
 }
 
 // the packed operand is in `workspace`; `a` describes the rows, the planes and the epilogue
-static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream) {
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw) {
     const int B = a.B, M = a.M, Fout = a.Fout;
-    const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + 255) / 256 * 256;
+    const int G = nw * 64;                               // filters per work item
+    const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + G - 1) / G * G;
     const int ntm = (M + 127) / 128;
-    const int64_t nitems64 = (int64_t)ntm * B * ((Fout + 255) / 256);
+    const int64_t nitems64 = (int64_t)ntm * B * (FoutP / G);
     CG_REQUIRE(nitems64 < (1ll << 31), "contract_fwd_bf16: too many tiles");
     const int nitems = (int)nitems64;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const dim3 grid(nitems < cus ? nitems : cus);       // one workgroup per CU (128 accumulator registers per lane)
-    if (passes == 3) {
-        auto kern = contract_fwd_bf16_kernel<3>;
-        constexpr int lds = Bf16Cfg<3>::NSTAGE * Bf16Cfg<3>::STAGE;
-        CG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, (const __bf16*)workspace, nks, FoutP, ntm, nitems);
+#define CG_BF16_LAUNCH(P, NW)                                                                                      \
+    do {                                                                                                           \
+        constexpr int lds = Bf16Cfg<P, NW>::NSTAGE * Bf16Cfg<P, NW>::STAGE;                                        \
+        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_fwd_bf16_kernel<P, NW>),                 \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));                              \
+        hipLaunchKernelGGL((contract_fwd_bf16_kernel<P, NW>), grid, dim3(NW * 64), lds, stream, a,                 \
+                           (const __bf16*)workspace, nks, FoutP, ntm, nitems);                                     \
+    } while (0)
+    if (nw == 5) {
+        if (passes == 3) CG_BF16_LAUNCH(3, 5); else CG_BF16_LAUNCH(1, 5);
     } else {
-        auto kern = contract_fwd_bf16_kernel<1>;
-        constexpr int lds = Bf16Cfg<1>::NSTAGE * Bf16Cfg<1>::STAGE;
-        CG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, (const __bf16*)workspace, nks, FoutP, ntm, nitems);
+        if (passes == 3) CG_BF16_LAUNCH(3, 4); else CG_BF16_LAUNCH(1, 4);
     }
+#undef CG_BF16_LAUNCH
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
@@ -702,9 +719,13 @@ static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, h
 // models_gcn.py:616): the SAME kernel with the roles swapped -- the reduction rows are the Fout planes
 // of dy (a "stack" of one slab), the operand is W^T packed in fragment order, and the Fin*K output
 // rows are scattered into the slab layout of the gradient stack by the epilogue (FwdArgs::out_K).
+// waves per workgroup for `rows` output rows: five (groups of 320) where that pads less than four (256)
+static int bwd_x_bf16_waves(int rows) { return (rows + 319) / 320 * 320 < (rows + 255) / 256 * 256 ? 5 : 4; }
+
 extern "C" size_t chebgcn_contract_bwd_x_bf16_workspace(int Fin, int K, int Fout) {
     if (Fin <= 0 || K <= 0 || Fout <= 0) return 0;
-    const size_t nks = bf16_ksteps(Fout), RowsP = ((size_t)Fin * K + 255) / 256 * 256;
+    const size_t G = 64 * (size_t)bwd_x_bf16_waves(Fin * K);
+    const size_t nks = bf16_ksteps(Fout), RowsP = ((size_t)Fin * K + G - 1) / G * G;
     return 2 * nks * RowsP * 16 * sizeof(uint16_t);
 }
 
@@ -726,11 +747,12 @@ extern "C" int chebgcn_contract_bwd_x_bf16(const float* dy, const float* W, floa
     a.Mo = M; a.Mpo = a.Mp;
     a.slab = (size_t)B * Fout * a.Mp;
     a.out_K = K;
-    const int nks = bf16_ksteps(a.FinK), FoutP = (a.Fout + 255) / 256 * 256;
+    const int nw = bwd_x_bf16_waves(a.Fout), G = 64 * nw;
+    const int nks = bf16_ksteps(a.FinK), FoutP = (a.Fout + G - 1) / G * G;
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
                        a.FinK, a.Fout, nks, FoutP, passes == 3 ? 2 : 1, Fout);
     CG_HIP(hipGetLastError());
-    return launch_contract_bf16(a, passes, workspace, stream);
+    return launch_contract_bf16(a, passes, workspace, stream, nw);
 }
 
 extern "C" size_t chebgcn_contract_bwd_w_bf16_workspace(int B, int M, int Fin, int K, int Fout) {

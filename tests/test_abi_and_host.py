@@ -61,7 +61,8 @@ def test_argument_validation_without_gpu():
     assert b'contract_fwd_bf16' in lib.chebgcn_last_error()
     # bf16 gradients of the contraction
     assert lib.chebgcn_contract_bwd_x_bf16_workspace(60, 5, 0) == 0
-    assert lib.chebgcn_contract_bwd_x_bf16_workspace(60, 5, 256) == 2 * 16 * 512 * 16 * 2     # W^T: 16 k-steps x 300 -> 512 rows
+    assert lib.chebgcn_contract_bwd_x_bf16_workspace(60, 5, 256) == 2 * 16 * 320 * 16 * 2     # W^T: 16 k-steps x 300 -> 320 rows (five waves)
+    assert lib.chebgcn_contract_bwd_x_bf16_workspace(32, 5, 64) == 2 * 4 * 256 * 16 * 2        # 160 rows: one group of 256
     assert lib.chebgcn_contract_bwd_x_bf16(None, None, None, 1, 1, 1, 1, 1, 1, None, 0, None) == -1
     assert b'contract_bwd_x_bf16' in lib.chebgcn_last_error()
     assert lib.chebgcn_contract_bwd_w_bf16_workspace(0, 1, 1, 1, 1) == 0
