@@ -29,6 +29,20 @@
 #ifndef CG_LB_BWX
 #define CG_LB_BWX 1
 #endif
+// s_setprio around a wave's block of MFMAs: without it the waves of a SIMD that are ready together share the
+// matrix pipe round-robin, finish together and then all wait for memory together (a convoy: matrix time and
+// memory time add up instead of overlapping)
+// Measured at the bench shape: contract_fwd 0.139 -> 0.132 ms, contract_bwd_x 0.147 -> 0.135 ms, step -1.9 %.
+#ifndef CG_PRIO
+#define CG_PRIO 1
+#endif
+#if CG_PRIO
+#define CG_PRIO_HI() __builtin_amdgcn_s_setprio(3)
+#define CG_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define CG_PRIO_HI() ((void)0)
+#define CG_PRIO_LO() ((void)0)
+#endif
 #ifndef CG_LB_BWW
 #define CG_LB_BWW 3          // 48 KB of LDS per workgroup allow three: 0.138 -> 0.120 ms at the bench shape
 #endif
@@ -91,6 +105,7 @@ contract_fwd_kernel(FwdArgs a) {
             if (k >= a.K) { k -= a.K; ++fin; }
             if (k >= a.K) { k -= a.K; ++fin; }
         }
+        CG_PRIO_HI();
 #pragma unroll
         for (int u = 0; u < FWD_UNROLL; ++u)
 #pragma unroll
@@ -100,6 +115,7 @@ contract_fwd_kernel(FwdArgs a) {
                 acc[t][2] = mfma(av[u][t], bv[u].z, acc[t][2]);
                 acc[t][3] = mfma(av[u][t], bv[u].w, acc[t][3]);
             }
+        CG_PRIO_LO();
     }
 
     // ---- epilogue: bias, relu, pool, store ----------------------------------------------
@@ -174,6 +190,7 @@ contract_bwd_x_kernel(BwdXArgs a) {
                 const int fo = 2 * j + h;
                 av[j] = wrow[fo < a.Fout ? fo : 0];
             }
+            CG_PRIO_HI();
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const float w = (kkA < a.FinK && 2 * j + h < a.Fout) ? av[j] : 0.f;
@@ -182,6 +199,7 @@ contract_bwd_x_kernel(BwdXArgs a) {
                 acc[2] = mfma(w, hold[j].z, acc[2]);
                 acc[3] = mfma(w, hold[j].w, acc[3]);
             }
+            CG_PRIO_LO();
         } else {
             for (int j0 = 0; j0 < nfo2; j0 += 4) {
                 float av[4];
@@ -330,6 +348,7 @@ contract_bwd_w_kernel(BwdWArgs a) {
             v.w = (b_ok && n + 3 < a.M && (gate[q] & 8)) ? v.w : 0.f;
             bv[q] = v;
         }
+        CG_PRIO_HI();
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
 #pragma unroll
@@ -348,6 +367,7 @@ contract_bwd_w_kernel(BwdWArgs a) {
                 acc[t] = mfma(v.w, bv[q].w, acc[t]);
             }
         }
+        CG_PRIO_LO();
     }
 
     // ---- workgroup reduction in LDS (fixed order: wave 0, then +1, +2, +3) ----------------
