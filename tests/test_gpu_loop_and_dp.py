@@ -158,8 +158,10 @@ from gcn_fmri_decoding_amd import models_gcn, ops, dist as gdist
 rank, world, out = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), os.environ['CHEBGCN_OUT']
 dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
-if world > 1:
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+force_dp = os.environ.get('CHEBGCN_FORCE_DP') == '1'      # world 1 on RCCL: the collective calls as the 8-GPU bench makes them
+if world > 1 or force_dp:
+    dist.init_process_group(os.environ.get('CHEBGCN_BACKEND', 'gloo'), rank=rank, world_size=world,
+                            **({'device_id': dev} if os.environ.get('CHEBGCN_BACKEND') == 'nccl' else {}))
 z = load_golden(os.environ['CHEBGCN_FIXTURE'])
 Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
 B = 4
@@ -167,10 +169,10 @@ torch.manual_seed(100 + rank)                      # ranks draw DIFFERENT initia
 net = models_gcn.cgcnn({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
                        channel=int(z['channel']), brelu=str(z['brelu']), batch_size=B // world, regularization=5e-4,
                        dropout=1, initial='he', verbose=False)
-if world > 1:
+if world > 1 or force_dp:
     dp = gdist.DataParallel(net)
 net._init_variables()                              # what fit() does after wrapping (the reference re-runs op_init) ...
-if world > 1:
+if world > 1 or force_dp:
     dp.broadcast_parameters()                      # ... followed by this (models_gcn.fit): rank 0's second draw wins
 rs = np.random.RandomState(3)
 x = rs.randn(B, Ls[0].shape[0], int(z['channel'])).astype(np.float32)
@@ -185,13 +187,15 @@ for step in range(3):
     grads.append(net._grad.detach().cpu().numpy().copy())
 torch.cuda.synchronize()
 np.savez(out % rank, flat0=flat0, flat=net._flat.detach().cpu().numpy(), g0=grads[0], g2=grads[2],
-         sent=np.array(sorted(net._dp._sent) if world > 1 else []), nb=len(net._dp._buckets) if world > 1 else 0)
-if world > 1:
+         sent=np.array(sorted(net._dp._sent) if net._dp is not None else []),
+         nb=len(net._dp._buckets) if net._dp is not None else 0)
+if world > 1 or force_dp:
+    dist.barrier()
     dist.destroy_process_group()
 '''
 
 
-def _run_ranks(world, fixture, tmp_path, tag):
+def _run_ranks(world, fixture, tmp_path, tag, extra_env=None):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
@@ -202,7 +206,8 @@ def _run_ranks(world, fixture, tmp_path, tag):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   CHEBGCN_ROOT=ROOT, CHEBGCN_OUT=out, CHEBGCN_FIXTURE=fixture, HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   CHEBGCN_ROOT=ROOT, CHEBGCN_OUT=out, CHEBGCN_FIXTURE=fixture, HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, log in zip(procs, logs):
@@ -230,3 +235,19 @@ def test_cgcnn_data_parallel_two_ranks_one_gpu(dev, fixture, tmp_path):
     assert np.abs(0.5 * a['g2'] - one['g2']).max() <= 1e-3 * np.abs(one['g2']).max()     # after two Adam steps (ill-conditioned elements)
     d = np.abs(a['flat'] - one['flat'])
     assert np.quantile(d, 0.99) <= 2e-5 * np.abs(one['flat']).max() and d.max() <= 3 * 1.1e-3
+
+
+def test_cgcnn_data_parallel_on_rccl_world_one(dev, tmp_path):
+    """The collective calls exactly as ``bench.py --gpus N`` makes them -- process group on backend
+    "nccl" (RCCL) bound to the device, broadcast of the three flat buffers, asynchronous all-reduces
+    of slices of the flat gradient issued from the autograd hook and from ``layer_done`` while
+    backward runs (contract_bwd_w on its second stream), ``wait`` -- with a world of one rank, where a
+    sum over ranks is the identity: same gradients and variables as the plain model."""
+    fixture = 'inference_pool_n212'
+    dp = _run_ranks(1, fixture, tmp_path, 'rccl', {'CHEBGCN_FORCE_DP': '1', 'CHEBGCN_BACKEND': 'nccl'})[0]
+    one = _run_ranks(1, fixture, tmp_path, 'plain')[0]
+    assert int(dp['nb']) == 2 and dp['sent'].tolist() == [0, 1]
+    assert np.array_equal(dp['flat0'], one['flat0'])
+    for k in ('g0', 'g2', 'flat'):
+        scale = np.abs(one[k]).max()
+        assert np.abs(dp[k] - one[k]).max() <= 1e-6 * scale, k      # per-filter bias sums are atomic: not bit-reproducible
