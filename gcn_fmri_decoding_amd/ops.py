@@ -328,7 +328,8 @@ class ChebConv(torch.autograd.Function):
         # pool == 1 with ReLU: contract_fwd leaves a bit per vertex (the ReLU mask) and the gradients of the
         # contraction gate the incoming gradient themselves -- no dy tensor, no pass over `out` in backward
         fold = bool(fold_relu_grad and pool == 1 and relu and precision == 'f32')
-        if pool == 1 and relu:
+        wants_grad = any(ctx.needs_input_grad[:3])       # inference: no mask is written
+        if pool == 1 and relu and wants_grad:
             # the mask also serves the separate ReluGrad pass (bf16 gradients): a byte per four vertices instead of `out`
             argmax = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device)
         b = bias.detach() if bias is not None else None
