@@ -31,12 +31,14 @@ class DataParallel:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self._head_names = [s.name for s in model._spec_list if s.group == 'head']
-        self._pending = 0
+        self._pending = set()       # head variables whose gradient is not enqueued yet
+        self._head_sent = True
         self._work = []
         self._hooks = []
+        self._stream_ordered = dist.get_backend(process_group) == 'nccl'
         for name in self._head_names:
             p = model._params[name]
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_head_grad))
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, name=name: self.head_grads_done((name,))))
         self._plan_conv_buckets(conv_groups)
         model._dp = self
         self.broadcast_parameters()
@@ -78,17 +80,28 @@ class DataParallel:
 
     # called by cgcnn.train_step -----------------------------------------------------
     def begin_step(self):
-        self._pending = len(self._head_names)
+        self._pending = set(self._head_names)
+        self._head_sent = False
         self._work = []
         self._sent = set()
 
     def _reduce(self, a, b):
         g = self.model._grad[a:b]
+        if g.is_cuda and not self._stream_ordered:
+            # RCCL orders the collective behind the kernels already enqueued on the current stream.  Other backends
+            # (gloo, used by the tests that put two ranks on one GPU) were seen reading the slice before the kernels
+            # that write it had run: wait for them.
+            torch.cuda.current_stream(g.device).synchronize()
         self._work.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _on_head_grad(self, _param):
-        self._pending -= 1
-        if self._pending == 0:
+    def head_grads_done(self, names):
+        """The head variables ``names`` have their gradients enqueued.  Reported by autograd's post-accumulate
+        hook and by the FC layers of the training step, which write dW / db into the flat buffer themselves
+        (both may report the same variable: the set makes that harmless).  The head goes out once, when the
+        last one is in."""
+        self._pending.difference_update(names)
+        if not self._pending and not self._head_sent:
+            self._head_sent = True
             self._reduce(0, self.model._n_head)
 
     def layer_done(self, layer):
@@ -102,9 +115,10 @@ class DataParallel:
     def finish_step(self):
         """Reduce what is left, wait, and return the scale that turns sums into means."""
         m = self.model
-        if self._pending != 0:          # head hook did not fire (e.g. frozen head): reduce it now
+        if not self._head_sent:         # some head variable never reported (e.g. frozen head): reduce it now
+            self._head_sent = True
             self._reduce(0, m._n_head)
-            self._pending = 0
+            self._pending = set()
         if self._buckets:
             for i, (_, ranges) in enumerate(self._buckets):
                 if i not in self._sent:

@@ -330,7 +330,8 @@ class base_model(object):
         forward, loss, backward, (gradient all-reduce), TF-form Adam.  Returns
         (reported learning rate, loss_average tensor)."""
         self.training_mode = True
-        self._grad.zero_()
+        if not self._fusable():
+            self._grad.zero_()          # autograd accumulates into .grad there; the fused path writes every gradient
         if self._dp is not None:
             self._dp.begin_step()
         logits = self._inference_storage(x_storage, self.dropout)
@@ -340,15 +341,17 @@ class base_model(object):
         if self._dp is not None:
             grad_scale = self._dp.finish_step()
         with torch.no_grad():       # the loss of this step is evaluated on the pre-update variables
-            loss = cross_entropy.detach() + self.regularization * self.regularization_term()
+            v = self._flat[:self._n_reg]
+            loss = torch.add(cross_entropy.detach(), torch.dot(v, v), alpha=0.5 * self.regularization)   # + reg * sum l2_loss
         self._apply_adam(grad_scale)
         reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
         self.global_step += 1
         with torch.no_grad():
             # tf.train.ExponentialMovingAverage(0.9) over a Tensor: zero-initialised shadow,
             # zero-debiased on read (:269-275)
-            self._loss_ema = 0.1 * loss if self._loss_ema is None else 0.9 * self._loss_ema + 0.1 * loss
-            loss_average = self._loss_ema / (1 - 0.9 ** self.global_step)
+            # shadow = 0.9 * shadow + 0.1 * loss, as one kernel
+            self._loss_ema = 0.1 * loss if self._loss_ema is None else torch.lerp(self._loss_ema, loss, 0.1)
+            loss_average = self._loss_ema * (1.0 / (1 - 0.9 ** self.global_step))
         self.training_mode = False
         return reported_lr, loss_average
 
@@ -681,7 +684,13 @@ class cgcnn(base_model):
         b = self._bias_variable([Mout], regularization=True)
         if x.is_meta:
             return torch.empty((N, Mout), device='meta')
-        x = torch.addmm(b, x, W)
+        if self.training_mode and torch.is_grad_enabled() and W.grad is not None and b.grad is not None:
+            # training step: the layer writes its gradients straight into the flat gradient buffer (like the
+            # conv layers do) -- no accumulate-into-.grad add per variable, no zeroing of the buffer
+            dp, names = self._dp, (self._var_name('weights'), self._var_name('bias'))
+            x = _LinearInto.apply(x, W, b, W.grad, b.grad, (lambda: dp.head_grads_done(names)) if dp is not None else None)
+        else:
+            x = torch.addmm(b, x, W)
         return torch.relu(x) if relu else x
 
     # ------------------------------------------------------------------ network
@@ -745,6 +754,30 @@ class cgcnn(base_model):
         with self.variable_scope('logits'):
             x = self.fc(x, self.M[-1], relu=False)
         return x
+
+
+class _LinearInto(torch.autograd.Function):
+    """``x @ W + b`` whose backward WRITES dW and db into the given buffers (views of the model's flat
+    gradient buffer: one use of a variable per step) instead of returning them to autograd, then reports
+    through ``done`` (dist.DataParallel.head_grads_done: the head's all-reduce starts from it)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gW, gb, done):
+        ctx.save_for_backward(x, W)
+        ctx.bufs = (gW, gb, done)
+        return torch.addmm(b.detach(), x, W.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        gW, gb, done = ctx.bufs
+        g = g.contiguous()
+        torch.mm(x.t(), g, out=gW)
+        torch.sum(g, 0, out=gb)
+        dx = g @ W.t() if ctx.needs_input_grad[0] else None
+        if done is not None:
+            done()
+        return dx, None, None, None, None, None
 
 
 def get_best_checkpoint(best_checkpoint_dir, select_maximum_value=True):

@@ -84,7 +84,7 @@ def _worker(rank, world, port, ret):
         model._grad.zero_()
         dp.begin_step()
         model.loss(xs, ys).backward()
-        fired = dp._pending == 0 and len(dp._work) == 1     # head bucket went out from the hook
+        fired = not dp._pending and len(dp._work) == 1     # head bucket went out from the hook
         dp.layer_done(3)                                    # what ops.ChebConv.backward reports, layer by layer
         fired = fired and len(dp._work) == 3 and dp._sent == {0}
         dp.layer_done(2)                                    # not the first layer of its run: nothing goes out yet
