@@ -385,7 +385,9 @@ def test_bf16_contraction_config5_shape(ops, dev):
     (2, 96, 40, 5, 64),          # RT = 5 with two row groups (200 rows), CT = 2
     (2, 500, 70, 5, 300),        # one-pass wide kernel with 2 x 2 workgroup tiles (350 rows, 300 columns)
     (3, 77, 33, 5, 65),          # wide kernel, ragged tiles, chunks of 16 vertices with a tail of 13
-    (70, 40, 60, 5, 256)])       # wide kernel with more windows than vertices chunks per window
+    (70, 40, 60, 5, 256),        # wide kernel with more windows than vertices chunks per window
+    (2, 300, 120, 5, 64),        # 600 rows: bwd_x on five waves with two groups of 320; bwd_w with four row groups
+    (1, 130, 20, 5, 96)])        # 100 rows (one group of 256 on four waves), 96 reduction rows = 6 k-steps
 def test_bf16_contraction_gradients(ops, dev, precision, B, M, Fin, K, Fout):
     """chebgcn_contract_bwd_x_bf16 / chebgcn_contract_bwd_w_bf16 (the MatMul gradients of
     models_gcn.py:616 on the bf16 matrix cores) against float64 sums of the same operands.  The
