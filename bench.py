@@ -231,7 +231,7 @@ def main():
                          'backward in fp32 / bf16 / split bf16; N=1 only')
     ap.add_argument('--no-timers', action='store_true')
     ap.add_argument('--overlap-bwd-w', type=int, default=1, help='contract_bwd_w on a second stream (ops.overlap_bwd_w)')
-    ap.add_argument('--timer-every', type=int, default=4,
+    ap.add_argument('--timer-every', type=int, default=10,
                     help='per-kernel HIP-event timing on every n-th timed step (event markers cost ~5 %% of a step when on every step)')
     args = ap.parse_args()
 
