@@ -310,3 +310,74 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
             gk = gk[:, :spec.ref_shape[1]].t().unsqueeze(0)
         ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
         close(gk.cpu().numpy(), ref, rel=5e-5, what='grad ' + k)
+
+
+# ---------------------------------------------------------------------------------------
+# the north-star launch itself: K = 5, Fin = 32, batch 256 (8192 planes: the four-plane kernels)
+# ---------------------------------------------------------------------------------------
+
+def test_northstar_launch_properties(ops, dev, bench_graph):
+    """The launches bench.py's ``northstar`` object times (BASELINE.json's north-star shape: K=5
+    recurrence, Fin=32, batch 256, M=10466 -- cheb4_kernel<10240,20,6,512,false/true>), checked at
+    full size through what does not need a 1.7 GB oracle run:
+    * planes drawn from all over the batch agree with the CPU oracle for every order k (1e-5);
+    * in place (T_0 already in slab 0, as the model runs it) and with the copy of x: the same bits;
+    * the adjoint identity  sum_k <T_k(L~) x, G_k> = <x, recurrence_bwd(G)>  over ALL 8192 planes
+      (float64 sums of fp32 results, 1e-5 of the magnitude sum);
+    * linearity of the forward launch (1e-5)."""
+    import ctypes
+    from gcn_fmri_decoding_amd import _lib
+    from oracle import graph_ref as GR
+    lib = _lib.lib()
+    L = bench_graph
+    M = L.shape[0]
+    g = ops.graph_for(L, dev)
+    assert g.query(6) == 4                                              # the automatic graph carries four planes ...
+    B, Fin, K = 256, 32, 5
+    Mp = g.Mp
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    x = torch.randn((B, Fin, Mp), generator=gen, device=dev)
+    x[:, :, M:] = float('nan')                                         # pads must never leak
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    stack = torch.empty((K, B, Fin, Mp), device=dev)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, st), 'fwd copy')
+    stack2 = torch.empty((K, B, Fin, Mp), device=dev)
+    stack2[0].copy_(x)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(stack2), P(stack2), B, Fin, K, st), 'fwd in place')
+    assert torch.equal(stack[:, :, :, :M], stack2[:, :, :, :M]), 'in place and copied T_0 differ'
+    assert torch.isfinite(stack[:, :, :, :M]).all()
+
+    # oracle on a handful of planes (first, last, around group boundaries)
+    Lr = GR.rescale_L(L, 2)
+    for (b, f) in [(0, 0), (0, 3), (0, 4), (17, 31), (128, 5), (255, 28), (255, 31)]:
+        xv = x[b, f, :M].cpu().numpy().astype(np.float32)
+        T = [xv, (Lr @ xv).astype(np.float32)]
+        for k in range(2, K):
+            T.append((2 * (Lr @ T[-1]) - T[-2]).astype(np.float32))
+        for k in range(K):
+            close(stack[k, b, f, :M].cpu().numpy(), T[k], what='plane (%d,%d) order %d' % (b, f, k))
+
+    # adjoint identity over the whole launch
+    G = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    G[:, :, :, M:] = float('nan')
+    dx = torch.empty((B, Fin, Mp), device=dev)
+    _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, st), 'bwd')
+    assert torch.isfinite(dx[:, :, :M]).all()
+    lhs = float((stack[:, :, :, :M].double() * G[:, :, :, :M].double()).sum())
+    rhs = float((x[:, :, :M].double() * dx[:, :, :M].double()).sum())
+    mag = float((stack[:, :, :, :M].double() * G[:, :, :, :M].double()).abs().sum())
+    assert abs(lhs - rhs) <= 1e-5 * mag, (lhs, rhs, mag)
+
+    # linearity: T(a x + y) = a T(x) + T(y)
+    y = torch.randn((B, Fin, Mp), generator=gen, device=dev)
+    sy = torch.empty_like(stack)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(y), P(sy), B, Fin, K, st), 'fwd y')
+    z = (0.5 * x + y)
+    sz = torch.empty_like(stack)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(z), P(sz), B, Fin, K, st), 'fwd z')
+    ref = 0.5 * stack[:, :, :, :M] + sy[:, :, :, :M]
+    err = float((sz[:, :, :, :M] - ref).abs().max() / ref.abs().max())
+    assert err <= REL, 'linearity: %.3e' % err
