@@ -316,7 +316,8 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
 # the north-star launch itself: K = 5, Fin = 32, batch 256 (8192 planes: the four-plane kernels)
 # ---------------------------------------------------------------------------------------
 
-def test_northstar_launch_properties(ops, dev, bench_graph):
+@pytest.mark.parametrize('B,Fin,K', [(256, 32, 5), (64, 64, 25)])      # north star; BASELINE configs[3] (bench.py `config4`)
+def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K):
     """The launches bench.py's ``northstar`` object times (BASELINE.json's north-star shape: K=5
     recurrence, Fin=32, batch 256, M=10466 -- cheb4_kernel<10240,20,6,512,false/true>), checked at
     full size through what does not need a 1.7 GB oracle run:
@@ -333,7 +334,6 @@ def test_northstar_launch_properties(ops, dev, bench_graph):
     M = L.shape[0]
     g = ops.graph_for(L, dev)
     assert g.query(6) == 4                                              # the automatic graph carries four planes ...
-    B, Fin, K = 256, 32, 5
     Mp = g.Mp
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
@@ -352,7 +352,7 @@ def test_northstar_launch_properties(ops, dev, bench_graph):
 
     # oracle on a handful of planes (first, last, around group boundaries)
     Lr = GR.rescale_L(L, 2)
-    for (b, f) in [(0, 0), (0, 3), (0, 4), (17, 31), (128, 5), (255, 28), (255, 31)]:
+    for (b, f) in [(0, 0), (0, 3), (0, 4), (17, Fin - 1), (B // 2, 5), (B - 1, Fin - 4), (B - 1, Fin - 1)]:
         xv = x[b, f, :M].cpu().numpy().astype(np.float32)
         T = [xv, (Lr @ xv).astype(np.float32)]
         for k in range(2, K):
