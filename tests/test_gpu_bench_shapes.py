@@ -381,3 +381,60 @@ def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K):
     ref = 0.5 * stack[:, :, :, :M] + sy[:, :, :, :M]
     err = float((sz[:, :, :, :M] - ref).abs().max() / ref.abs().max())
     assert err <= REL, 'linearity: %.3e' % err
+
+
+def test_contraction_bench_launch_b64(ops, dev):
+    """The contraction launches of the bench step at their real size (batch 64, M = 10466, Fin = Fout = 32,
+    K = 5: contract_fwd<1> with the ReLU bit mask, contract_bwd_w_kernel<5, true> on 768 workgroups + the
+    two reduce kernels, contract_bwd_x_kernel<true, true>, bias_grad_relu_kernel) against float64 matrix
+    products of the same operands computed on the device (1e-5 / 2e-5 of max, pads poisoned)."""
+    import ctypes
+    from gcn_fmri_decoding_amd import _lib
+    lib = _lib.lib()
+    B, M, Fin, K, Fout = 64, 10466, 32, 5, 32
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * 0.1
+    bias = torch.zeros((Fout, Mp), device=dev)
+    bias[:, :M] = torch.randn((Fout, M), generator=gen, device=dev) * 0.3
+    stack[..., M:] = float('nan')
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    out = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    mask = torch.zeros((B, Fout, Mp // 4), dtype=torch.uint8, device=dev)
+    _lib.check(lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), ops.BIAS_VERTEX, P(out), P(mask), B, M, Fin, K, Fout, 1, 0, 1, st), 'fwd')
+    S = stack[..., :M].permute(2, 0, 1, 3).reshape(Fin * K, B, M).double()          # rows fin*K + k
+    pre = torch.einsum('rbm,ro->bom', S, W.double()) + bias[:, :M].double()
+    ref = pre.clamp(min=0)
+    err = float((out[..., :M].double() - ref).abs().max() / pre.abs().max())
+    assert err <= REL, 'contract_fwd: %.3e' % err
+    bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, Fout, Mp)[..., :M].bool()
+    assert torch.equal(bits, out[..., :M] > 0), 'ReLU bit mask disagrees with the output'
+
+    gout = torch.randn((B, Fout, Mp), generator=gen, device=dev)
+    gout[..., M:] = float('nan')
+    dy = (gout[..., :M] * bits).double()                                                # ReluGrad
+    n = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    dW = torch.full((Fin * K, Fout), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_w_relu(P(stack), P(gout), P(mask), P(dW), P(ws), n, B, M, Fin, K, Fout, st), 'bwd_w')
+    dW_ref = torch.einsum('rbm,bom->ro', S, dy)
+    err = float((dW.double() - dW_ref).abs().max() / dW_ref.abs().max())
+    assert err <= GREL, 'contract_bwd_w_relu: %.3e' % err
+    del S
+
+    gstack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_x_relu(P(gout), P(mask), P(W), P(gstack), B, M, Fin, K, Fout, st), 'bwd_x')
+    gs_ref = torch.einsum('ro,bom->rbm', W.double(), dy).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    err = float((gstack[..., :M].double() - gs_ref).abs().max() / gs_ref.abs().max())
+    assert err <= GREL, 'contract_bwd_x_relu: %.3e' % err
+
+    dbias = torch.full((Fout, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_brelu_pool_bwd(P(gout), None, P(mask), None, P(dbias), ops.BIAS_VERTEX, B, M, Fout, 1, 0, 1, st), 'bias')
+    db_ref = dy.sum(0)
+    err = float((dbias[:, :M].double() - db_ref).abs().max() / db_ref.abs().max())
+    assert err <= GREL, 'bias gradient: %.3e' % err
+    assert float(dbias[:, M:].abs().sum()) == 0.0
