@@ -316,7 +316,9 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
 # the north-star launch itself: K = 5, Fin = 32, batch 256 (8192 planes: the four-plane kernels)
 # ---------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize('B,Fin,K', [(256, 32, 5), (64, 64, 25)])      # north star; BASELINE configs[3] (bench.py `config4`)
+# north star; BASELINE configs[3] (bench.py `config4`); the two recurrence launches of the bench step (batch 64: 2048 and
+# 960 planes, which pick_ell sends to the two-plane kernel cheb_onchip_kernel<2,14,4,768,*>)
+@pytest.mark.parametrize('B,Fin,K', [(256, 32, 5), (64, 64, 25), (64, 32, 5), (64, 15, 5)])
 def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K):
     """The launches bench.py's ``northstar`` object times (BASELINE.json's north-star shape: K=5
     recurrence, Fin=32, batch 256, M=10466 -- cheb4_kernel<10240,20,6,512,false/true>), checked at
