@@ -377,7 +377,8 @@ def test_bf16_contraction_config5_shape(ops, dev):
 
 @pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
 @pytest.mark.parametrize('B,M,Fin,K,Fout', [
-    (2, 10466, 60, 5, 256),      # BASELINE config 5 on the benchmark graph: RT = 5, CT = 2, two row groups
+    (2, 10466, 60, 5, 256),      # BASELINE config 5 on the benchmark graph: the one-pass wide bwd_w, bwd_x on five waves
+    (64, 10466, 60, 5, 256),     # ... and at the batch bench.py's config5 object times (41920 chunks over 256 workgroups)
     (3, 200, 3, 3, 40),          # one ragged row tile, two ragged column tiles
     (2, 1000, 7, 5, 300),        # Fout beyond one 256-filter group of bwd_x; RT = 2
     (1, 64, 16, 1, 16),          # K = 1, a single chunk, CT = 1
