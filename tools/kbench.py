@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_fwd_inplace', 'recurrence_bwd', 'contract_fwd',
                                                      'contract_bwd_w_relu', 'contract_bwd_x_relu', 'bias_grad_relu', 'contract_bwd_w', 'contract_bwd_x',
                                                      'brelu_pool_bwd'])
+    ap.add_argument('--nodes', type=int, default=10000, help='points of the synthetic kNN graph (10000 -> M = 10466)')
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (0 = automatic, 2, 4)')
     ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
@@ -39,7 +40,7 @@ def main():
     import bench
     from gcn_fmri_decoding_amd import _lib, ops
     dev = torch.device('cuda:0')
-    Ls, perm = bench.load_graph(10000, 1, 0, 1, None)
+    Ls, perm = bench.load_graph(args.nodes, 1, 0, 1, None)
     lib = _lib.lib()
     import ctypes
     handle = ctypes.CDLL(_lib.LIB_PATH)
