@@ -13,6 +13,14 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a fresh checkout has no libchebgcn.so (built artefacts are not in history): build it once, as
+    # __graft_entry__.build() does, so that the ABI / host tests do not depend on the order of the driver's steps
+    so = os.path.join(ROOT, 'gcn_fmri_decoding_amd', 'libchebgcn.so')
+    if not os.path.exists(so):
+        import shutil
+        import subprocess
+        if shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc'):
+            subprocess.run(['make', '-s', '-C', os.path.join(ROOT, 'gcn_fmri_decoding_amd', 'csrc')], check=False)
 
 
 def load_golden(name):
