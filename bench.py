@@ -214,6 +214,161 @@ def config5_leg(lib_graph, B, Fin, K, Fout, steps):
     torch.cuda.empty_cache()
     return out
 
+def refshape_leg(dev, n_nodes, steps, warmup, batch=128, korder=10, block_dura=15):
+    """The shape the reference's own ``training.py`` builds (SURVEY.md 8 / VERDICT r2 item 7): an atlas-sized graph
+    (MMP atlas: 360 regions, ``configure_fmri.py:11``; 1000 = the largest atlas the reference names), kNN-8,
+    ``coarsening_levels = 1`` (``configure_fmri.py:41``, ``model.py:136-141``), ChebNet ``K = 10`` x 6 (``training.py:34``,
+    ``model.py:271-280``), F = 32, p = 1, b2relu, FC 512-256-22, batch 128 (``configure_fmri.py:28``), block_dura 15.
+    At these sizes a step is a chain of short kernels: timed eagerly and as ONE captured HIP graph
+    (``cgcnn.enable_step_graph``)."""
+    import torch
+    from gcn_fmri_decoding_amd import graph, models_gcn, ops
+    Ls, perm, _ = graph.synthetic_graph(n_nodes, k=8, levels=1)
+    cfg = dict(F=[32] * 6, K=[korder] * 6, p=[1] * 6, M=[512, 256, 22])
+    out = {'shape': {'N': n_nodes, 'M': int(Ls[0].shape[0]), 'K': korder, 'F': 32, 'layers': 6, 'batch': batch,
+                     'block_dura': block_dura}, 'steps': steps, 'warmup': warmup,
+           'what': "the reference's default training shape (training.py / model.py:271-280 / configure_fmri.py), full step "
+                   'fwd+loss+bwd+Adam, batch gathered on device'}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    S = 4 * batch
+    data = torch.randn((S, n_nodes, block_dura), generator=gen, device=dev)
+    labels = torch.randint(0, 21, (S,), generator=gen, device=dev)
+    perm_dev = torch.as_tensor(np.asarray(perm, np.int32)).to(dev)
+    order = torch.stack([torch.randperm(S, generator=gen, device=dev)[:batch].to(torch.int32) for _ in range(steps + warmup)])
+    for mode in ('eager', 'hip_graph'):
+        torch.manual_seed(0)
+        net = models_gcn.cgcnn({'device': dev}, [Ls[0]] * 6, cfg['F'], cfg['K'], cfg['p'], cfg['M'], filter='chebyshev5',
+                               brelu='b2relu', pool='mpool1', initial='he', channel=block_dura, regularization=5e-4,
+                               dropout=0.5, batch_size=batch, learning_rate=0.001, decay_rate=0.9, momentum=0.9, verbose=False)
+        if mode == 'hip_graph':
+            net.enable_step_graph(True)
+        xbuf = ops.plane_empty(batch, block_dura, int(Ls[0].shape[0]), dev)
+
+        def step(i):
+            idx = order[i]
+            x = ops.perm_data(data, perm_dev, idx, out=xbuf)
+            return net.train_step(x, labels[idx.long()])
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            _, loss = step(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[mode] = {'ms_per_step': 1e3 * dt, 'windows_per_s': batch / dt, 'final_loss': float(loss)}
+        del net
+    torch.cuda.empty_cache()
+    return out
+
+
+def dp_overhead_leg(net, step, first, steps, plain_ms, dev):
+    """Fixed cost of the data-parallel plumbing, visible at N = 1: the same training step with the model wrapped in
+    ``dist.DataParallel`` on backend nccl (RCCL) with a world of ONE rank -- the broadcast, the gradient hooks and
+    the three asynchronous all-reduces of ``bench.py --gpus N``, each a self-copy -- against the plain step."""
+    import torch
+    import torch.distributed as dist
+    from gcn_fmri_decoding_amd import dist as gdist
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % free_port(), rank=0, world_size=1, device_id=dev)
+    try:
+        dp = gdist.DataParallel(net)
+        for i in range(first, first + 3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(first + 3, first + 3 + steps):
+            step(i)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        dp.remove()
+    finally:
+        dist.destroy_process_group()
+    return {'plain_ms_per_step': plain_ms, 'dp_world1_ms_per_step': ms, 'overhead_ms': ms - plain_ms, 'steps': steps,
+            'what': 'same step under dist.DataParallel on RCCL with world_size 1 (hooks + 3 async all-reduces + waits) vs plain'}
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: start N fresh rank processes
+    (``python -m torch.distributed.run``, rendezvous on 127.0.0.1) as a CHILD -- this process has not imported torch
+    or touched a GPU, and is not replaced -- relay rank 0's JSON line and the child's exit code."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        sys.stderr.write('bench.py: the rank processes ended without a result line\n')
+        rc = 1
+    sys.exit(rc)
+
+
+def ranks_seen(dist, dev):
+    """Sum over ranks of 1: what the collective library itself counts (the driver can tell RCCL saw N ranks)."""
+    import torch
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def stub_main(args, world, rank):
+    """``--stub``: the launcher / rendezvous / timing / reporting path with a stand-in step on CPU tensors (backend
+    gloo) -- what tests/test_bench_launcher.py runs where there is no GPU.  Not a measurement."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(args.backend if args.backend != 'nccl' else 'gloo', rank=rank, world_size=world)
+    w = torch.zeros(1000)
+    for _ in range(args.warmup):
+        w += 1
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g = torch.full((1000,), float(rank + 1))
+        if world > 1:
+            dist.all_reduce(g)
+        w += g / world
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    seen = 1
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        seen = ranks_seen(dist, 'cpu')
+    if rank == 0:
+        print(json.dumps({'metric': METRIC, 'value': args.batch * world * args.steps / dt, 'unit': 'windows/s', 'n_gpus': world,
+                          'n_ranks_seen': seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'STUB (launcher test, no kernels)', 'global_batch': args.batch * world,
+                                     'parallelism': 'dp%d' % world}, 'stub': True,
+                          'checksum': float(w.sum())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -227,27 +382,37 @@ def main():
     ap.add_argument('--cpu-windows', type=int, default=16, help='0 disables the CPU baseline leg')
     ap.add_argument('--kernel-legs', type=int, default=1,
                     help='1: also time the recurrence kernels alone at the north-star shape (K=5, Fin=32, batch 256) and at '
-                         'configs[3] (K=25, Fin=64, batch 64), and the wide layer of configs[4] (Fin=60, Fout=256) forward + '
-                         'backward in fp32 / bf16 / split bf16; N=1 only')
-    ap.add_argument('--no-timers', action='store_true')
+                         'configs[3] (K=25, Fin=64, batch 64), the wide layer of configs[4] (Fin=60, Fout=256) forward + '
+                         'backward in fp32 / bf16 / split bf16, the reference\'s own training shape (atlas graph, K=10, batch 128) '
+                         'and the data-parallel plumbing on a world of one; N=1 only')
     ap.add_argument('--overlap-bwd-w', type=int, default=1, help='contract_bwd_w on a second stream (ops.overlap_bwd_w)')
-    ap.add_argument('--timer-every', type=int, default=10,
-                    help='per-kernel HIP-event timing on every n-th timed step (event markers cost ~5 %% of a step when on every step)')
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='the timed region (exactly --steps steps) is run this many times; `value` comes from the FIRST, the '
+                         'others are reported beside it (ms_per_step_repeats)')
+    ap.add_argument('--instrumented-steps', type=int, default=10,
+                    help='steps of the separate instrumented pass AFTER the timed regions (HIP events around every hot-kernel '
+                         'launch, no second stream): the source of `roofline` and `kernels`; 0 disables it')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL)')
+    ap.add_argument('--stub', action='store_true', help='launcher / reporting path with a stand-in CPU step (tests)')
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        self_launch(args.gpus, sys.argv[1:])            # does not return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs torch.distributed.run with %d processes' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but the launcher started %d rank processes' % (args.gpus, world))
+    if args.stub:
+        return stub_main(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if world > 1:
@@ -266,8 +431,10 @@ def main():
                            brelu='b2relu', pool='mpool1', initial='he', channel=cfg['channel'], regularization=5e-4,
                            dropout=0.5, batch_size=args.batch, learning_rate=0.001, decay_rate=0.9, momentum=0.9,
                            verbose=False)
+    n_seen = 1
     if world > 1:
         gdist.DataParallel(net)
+        n_seen = ranks_seen(dist, dev)
 
     # synthetic dataset resident in HBM: [S, N, block_dura] z-scored signals, uniform labels
     S = 4 * args.batch
@@ -276,8 +443,10 @@ def main():
     data = torch.randn((S, args.nodes, args.block_dura), generator=g, device=dev)
     labels = torch.randint(0, 21, (S,), generator=g, device=dev)
     perm_dev = torch.as_tensor(perm.astype(np.int32)).to(dev)
-    order = torch.stack([torch.randperm(S, generator=g, device=dev)[:args.batch].to(torch.int32)
-                         for _ in range(args.steps + args.warmup)])
+    repeats = max(1, args.repeats)
+    n_dp = 13 if (world == 1 and args.kernel_legs) else 0
+    n_order = args.warmup + repeats * args.steps + args.instrumented_steps + n_dp
+    order = torch.stack([torch.randperm(S, generator=g, device=dev)[:args.batch].to(torch.int32) for _ in range(n_order)])
 
     def step(i):
         idx = order[i]
@@ -286,31 +455,44 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if not args.no_timers:
-        ops.timers = ops.KernelTimers(every=args.timer_every)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        if ops.timers is not None:
-            ops.timers.next_step()        # per-kernel HIP events on every timer_every-th step of the timed region
-        _, loss = step(i)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kern = ops.timers.summary() if ops.timers is not None else {}
-    sampled = ops.timers.sampled_steps if ops.timers is not None else 0
-    ops.timers = None
+    # ---- the timed region: exactly --steps steps of ONE step variant (no event timers), barrier + synchronize on both sides
+    region_ms = []
+    nxt = args.warmup
+    for r in range(repeats):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nxt, nxt + args.steps):
+            _, loss = step(i)
+        torch.cuda.synchronize()
+        barrier()
+        dt_r = time.perf_counter() - t0
+        nxt += args.steps
+        if world > 1:
+            t = torch.tensor([dt_r], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_r = float(t.item())
+        region_ms.append(1e3 * dt_r / args.steps)
+    dt = region_ms[0] * args.steps / 1e3
     loss = float(loss)
+    # ---- separate instrumented pass: HIP events around every hot-kernel launch on the launch stream (no second stream
+    # on these steps: a kernel's time must not include a neighbour)
+    kern, sampled = {}, 0
+    if args.instrumented_steps > 0:
+        ops.timers = ops.KernelTimers(every=1)
+        for i in range(nxt, nxt + args.instrumented_steps):
+            ops.timers.next_step()
+            step(i)
+        kern = ops.timers.summary()
+        sampled = ops.timers.sampled_steps
+        ops.timers = None
+        nxt += args.instrumented_steps
 
     if rank == 0:
         global_batch = args.batch * world
         line = {
             'metric': METRIC, 'value': global_batch * args.steps / dt, 'unit': 'windows/s', 'n_gpus': world,
+            'n_ranks_seen': n_seen,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: ChebNet K=%d x6 conv (F=32, p=1, b2relu), FC 512-256-22, '
@@ -319,6 +501,10 @@ def main():
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world,
                        'step': 'fwd+loss+bwd+allreduce+Adam, batch gathered on device'},
             'final_loss': loss,
+            'ms_per_step_repeats': {'all': region_ms, 'median': float(np.median(region_ms)), 'min': float(np.min(region_ms)),
+                                    'max': float(np.max(region_ms)),
+                                    'what': '%d timed regions of %d steps each, back to back; `value` / `ms_per_step` are the first'
+                                            % (repeats, args.steps)},
         }
         if kern:
             dom = max(kern, key=lambda k: kern[k]['total_ms'])
@@ -334,21 +520,28 @@ def main():
                                                   'tools/pmc_traffic.sh at this shape, not measured in this run)',
                                 'avg_launch_ms': d['avg_ms'], 'launches': d['launches'],
                                 'algorithmic_bytes_per_launch': d['bytes'] / d['launches']}
+            step_ms = float(np.median(region_ms))
             line['kernels'] = {k: {'avg_ms': v['avg_ms'], 'launches': v['launches'],
                                    'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
+                                   'frac_hbm': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    'TFLOPs': v['flops'] / (v['total_ms'] * 1e-3) / 1e12,
-                                   'share_of_step': v['total_ms'] / max(sampled, 1) / (1e3 * dt / args.steps)}
+                                   'share_of_step': v['total_ms'] / max(sampled, 1) / step_ms}
                                for k, v in kern.items()}
-            line['kernel_timing'] = 'HIP events around every launch of these kernels on %d of the %d timed steps' % (sampled, args.steps)
+            line['kernel_timing'] = ('HIP events around every launch of these kernels on the launch stream, in a separate '
+                                     'instrumented pass of %d steps AFTER the timed regions (the timed steps carry no events)' % sampled)
         if world == 1 and args.kernel_legs:
             g0 = net.graphs[0]
-            line['northstar'] = kernel_leg(g0, 256, 32, 5, 50, 'north-star shape of BASELINE.json: K=5 recurrence, Fin=32, batch 256, '
-                                                               'M=10466; target frac >= 0.40')
-            line['config4'] = kernel_leg(g0, 64, 64, 25, 20, 'BASELINE configs[3]: K=25, Fin=Fout=64, batch 64 (SpMM-bound regime)')
+            line['northstar'] = kernel_leg(g0, 256, 32, 5, 100, 'north-star shape of BASELINE.json: K=5 recurrence, Fin=32, batch 256, '
+                                                                'M=10466; target frac >= 0.40')
+            line['config4'] = kernel_leg(g0, 64, 64, 25, 30, 'BASELINE configs[3]: K=25, Fin=Fout=64, batch 64 (SpMM-bound regime)')
             line['config5'] = config5_leg(g0, 64, 60, 5, 256, 10)
+            line['dp_overhead'] = dp_overhead_leg(net, step, nxt, 10, float(np.median(region_ms)), dev)
+            del net, data
+            torch.cuda.empty_cache()
+            line['refshape'] = {'n360': refshape_leg(dev, 360, 100, 10), 'n1000': refshape_leg(dev, 1000, 100, 10)}
         if world == 1 and args.cpu_windows > 0:
             line['cpu_baseline'] = cpu_baseline(Ls[:1], cfg, args.cpu_windows)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -41,7 +41,8 @@ SIGNATURES = {
     'chebgcn_contract_bwd_w_bf16_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'chebgcn_contract_bwd_w_bf16': (_i, [_p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _i, _p]),
     'chebgcn_brelu_pool_fwd': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    'chebgcn_brelu_pool_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'chebgcn_brelu_pool_bwd_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
+    'chebgcn_brelu_pool_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p]),
     'chebgcn_contract_bwd_w_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'chebgcn_contract_bwd_w': (_i, [_p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_x': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -53,7 +54,9 @@ SIGNATURES = {
     'chebgcn_feature_mean_fwd': (_i, [_p, _p, _i, _i, _i, _p]),
     'chebgcn_feature_mean_bwd': (_i, [_p, _p, _i, _i, _i, _p]),
     'chebgcn_adam_step': (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
+    'chebgcn_adam_step_dev': (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _p]),
     'chebgcn_metis_one_level_f32': (_i, [_i64, _p, _p, _p, _p, _p, _i64, _p]),
+    'chebgcn_metis_one_level_f32p': (_i, [_i64, _p, _p, _p, _p, _p, _i64, _p]),
     'chebgcn_metis_one_level_f64': (_i, [_i64, _p, _p, _p, _p, _p, _i64, _p]),
     'chebgcn_compute_perm_level': (_i, [_p, _i64, _p, _i64, _p]),
 }

@@ -16,22 +16,35 @@ import scipy.sparse as sp
 from . import _lib
 
 
+# How the matching score ``vv*(1.0/weights[tid] + 1.0/weights[nid])`` (:153) is evaluated on a float32 graph.
+# False (default): in float32 -- what NumPy >= 2 makes of the reference's expression (NEP 50), what this image
+# runs and what the golden fixtures hold.  True: float32 values promoted to float64 -- what NumPy 1.x, the
+# generation the reference was written for, did (``python float / np.float32`` was a float64); near-ties of the
+# strict ``>`` can then fall differently (tests/golden/coarsen_unit_n300.npz records both outcomes).  float64
+# graphs are unaffected.  ``metis`` / ``coarsen`` take ``promote=`` per call; this is their default.
+NUMPY1_SCORE_PROMOTION = False
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def metis_one_level(rr, cc, vv, rid, weights):
+def metis_one_level(rr, cc, vv, rid, weights, promote=None):
     """One greedy heavy-edge matching pass over edges sorted by row (:120-166).
 
     Returns ``cluster_id`` (int32, one entry per vertex).  Works in the precision of
-    ``vv`` (float32 or float64), like NumPy evaluates the reference's expression.
+    ``vv`` (float32 or float64), like NumPy evaluates the reference's expression;
+    ``promote`` (default ``NUMPY1_SCORE_PROMOTION``): float32 inputs, score in float64.
     """
+    if promote is None:
+        promote = NUMPY1_SCORE_PROMOTION
     rr = np.ascontiguousarray(rr, np.int64)
     cc = np.ascontiguousarray(cc, np.int64)
     rid = np.ascontiguousarray(rid, np.int64)
     vv = np.ascontiguousarray(vv)
     if vv.dtype == np.float32:
-        fn, ft = _lib.lib().chebgcn_metis_one_level_f32, np.float32
+        fn = _lib.lib().chebgcn_metis_one_level_f32p if promote else _lib.lib().chebgcn_metis_one_level_f32
+        ft = np.float32
     else:
         fn, ft = _lib.lib().chebgcn_metis_one_level_f64, np.float64
         vv = vv.astype(np.float64)
@@ -45,7 +58,7 @@ def metis_one_level(rr, cc, vv, rid, weights):
     return out
 
 
-def metis(W, levels, rid=None):
+def metis(W, levels, rid=None, promote=None):
     """``levels`` rounds of Graclus-weighted matching and contraction (:34-116).
 
     Returns (graphs, parents): ``levels + 1`` weight matrices (finest first) and, per
@@ -63,7 +76,7 @@ def metis(W, levels, rid=None):
         r, c, v = sp.find(W)
         order = np.argsort(r, kind='stable')
         rr, cc, vv = r[order], c[order], v[order]
-        cid = metis_one_level(rr, cc, vv, rid, weights)
+        cid = metis_one_level(rr, cc, vv, rid, weights, promote)
         parents.append(cid)
         n_new = int(cid.max()) + 1
         W = sp.csr_matrix((vv, (cid[rr], cid[cc])), shape=(n_new, n_new))
@@ -136,13 +149,13 @@ def perm_adjacency(A, indices):
     return sp.coo_matrix((A.data, (new_pos[A.row], new_pos[A.col])), shape=(Mnew, Mnew), dtype=A.dtype)
 
 
-def coarsen(A, levels, self_connections=False, verbose=True):
+def coarsen(A, levels, self_connections=False, verbose=True, promote=None):
     """Coarsen ``A`` ``levels`` times and order every level as a binary tree (:5-31).
 
     Returns (graphs, perm): CSR adjacencies, the first ``levels`` padded with fake
     vertices and permuted, and the permutation to apply to the input data (None for
     levels == 0)."""
-    graphs, parents = metis(A, levels)
+    graphs, parents = metis(A, levels, promote=promote)
     perms = compute_perm(parents)
     for i, G in enumerate(graphs):
         M = G.shape[0]

@@ -13,7 +13,9 @@ namespace {
 // boundary test runs after the increment: the first run is one entry too long (it also
 // sees the first entry of the second run), the last run one entry short; runs are
 // numbered in order of appearance.  Ties keep the first maximum (strict >).
-template <typename T>
+// T = storage type of the weights, S = type the score is evaluated in (S = double with T = float is
+// NumPy 1.x's promotion of `python float / float32 scalar`; the conversions float -> double are exact).
+template <typename T, typename S = T>
 int metis_one_level(int64_t nnz, const int64_t* rr, const int64_t* cc, const T* vv, const int64_t* rid,
                     const T* weights, int64_t N, int32_t* cluster_id) {
     using chebgcn::fail;
@@ -38,7 +40,7 @@ int metis_one_level(int64_t nnz, const int64_t* rr, const int64_t* cc, const T* 
         const int64_t tid = rid[ii];
         if (tid < 0 || tid >= N) return fail(CHEBGCN_EINVAL, "metis_one_level: rid[%lld] out of range", (long long)ii);
         if (marked[tid]) continue;
-        T wmax = 0;
+        S wmax = 0;
         const int64_t rs = rowstart[tid];
         marked[tid] = 1;
         int64_t best = -1;
@@ -46,14 +48,14 @@ int metis_one_level(int64_t nnz, const int64_t* rr, const int64_t* cc, const T* 
             if (rs + jj >= nnz) return fail(CHEBGCN_EINVAL, "metis_one_level: row extent past nnz");
             const int64_t nid = cc[rs + jj];
             if (nid < 0 || nid >= N) return fail(CHEBGCN_EINVAL, "metis_one_level: column out of range");
-            T tval;
+            S tval;
             if (marked[nid]) {
                 tval = 0;
             } else {
-                const T a = T(1) / weights[tid];
-                const T b = T(1) / weights[nid];
-                const T s = a + b;
-                tval = vv[rs + jj] * s;
+                const S a = S(1) / S(weights[tid]);
+                const S b = S(1) / S(weights[nid]);
+                const S s = a + b;
+                tval = S(vv[rs + jj]) * s;
             }
             if (tval > wmax) {
                 wmax = tval;
@@ -76,6 +78,12 @@ extern "C" int chebgcn_metis_one_level_f32(int64_t nnz, const int64_t* rr, const
                                            const int64_t* rid, const float* weights, int64_t N,
                                            int32_t* cluster_id) {
     return metis_one_level<float>(nnz, rr, cc, vv, rid, weights, N, cluster_id);
+}
+
+extern "C" int chebgcn_metis_one_level_f32p(int64_t nnz, const int64_t* rr, const int64_t* cc, const float* vv,
+                                            const int64_t* rid, const float* weights, int64_t N,
+                                            int32_t* cluster_id) {
+    return metis_one_level<float, double>(nnz, rr, cc, vv, rid, weights, N, cluster_id);
 }
 
 extern "C" int chebgcn_metis_one_level_f64(int64_t nnz, const int64_t* rr, const int64_t* cc, const double* vv,

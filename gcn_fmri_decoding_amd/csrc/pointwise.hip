@@ -15,8 +15,8 @@ template <int BIAS, int PARTS>
 __global__ void __launch_bounds__(256)
 brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                       const uint8_t* __restrict__ argmax, float* __restrict__ dy,
-                      float* __restrict__ dbias, int B, int M, int Mp, int F, int pool, int pool_kind,
-                      int relu, int Mpo) {
+                      float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F, int pool,
+                      int pool_kind, int relu, int Mpo) {
     constexpr int VB = 256 / PARTS;                  // vertices per block
     __shared__ float red[4];
     __shared__ float psum[PARTS > 1 ? 256 : 1];
@@ -68,7 +68,8 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dbias + f, (red[0] + red[1]) + (red[2] + red[3]));
+        // per-filter sum (b1relu): one partial per workgroup, summed in a fixed order by bias_filter_reduce_kernel
+        if (threadIdx.x == 0) fpart[(size_t)f * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -79,7 +80,7 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
 template <int BIAS>
 __global__ void __launch_bounds__(256)
 bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dy,
-                      float* __restrict__ dbias, int B, int M, int Mp, int F) {
+                      float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F) {
     __shared__ float4 psum[256];
     const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int Mq = Mp >> 2;
@@ -121,9 +122,21 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
         } else {
             float s = (t.x + t.y) + (t.z + t.w);
             for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
-            if (ql == 0) atomicAdd(dbias + f, s);
+            if (ql == 0) fpart[(size_t)f * gridDim.x + blockIdx.x] = s;
         }
     }
+}
+
+// second stage of the per-filter bias gradient (b1relu, models_gcn.py:619-623): one wave per filter adds the
+// per-workgroup partials in a fixed order (lane l takes partials l, l+64, ... in sequence, then a fixed
+// butterfly) -- the result does not depend on the order the workgroups of the first stage ran in
+__global__ void __launch_bounds__(64)
+bias_filter_reduce_kernel(const float* __restrict__ fpart, float* __restrict__ dbias, int nblk) {
+    const int f = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 64) s += fpart[(size_t)f * nblk + i];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (threadIdx.x == 0) dbias[f] = s;
 }
 
 // ---- standalone bias + ReLU + pooling forward (b1relu / b2relu / mpool1 / apool1 called on
@@ -242,6 +255,24 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
     }
 }
 
+// the same with the step size read from device memory: a captured HIP graph of the training step replays with the
+// value the host wrote before the launch (lr_t changes every step)
+__global__ void __launch_bounds__(256)
+adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                float* __restrict__ v, int64_t n, const float* __restrict__ lr_t_dev, float b1, float b2, float eps,
+                float gscale, float l2) {
+    const float lr_t = *lr_t_dev;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = fmaf(l2, pi, gscale * g[i]);
+        const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+        const float vi = v[i] + (1.f - b2) * (gi * gi - v[i]);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
 }  // namespace chebgcn
 
 using namespace chebgcn;
@@ -264,9 +295,30 @@ extern "C" int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bia
     return CHEBGCN_OK;
 }
 
+// workgroups along the vertex axis of the gradient kernels below (= per-filter partials of a b1relu layer)
+static int brelu_bwd_blocks(int M, int F, int pool, int relu, bool have_mask, int* parts_out) {
+    const int Mp = plane_stride(M);
+    if (pool == 1 && relu && have_mask) {
+        if (parts_out) *parts_out = 0;
+        return (Mp / 4 + 63) / 64;
+    }
+    // enough workgroups for the chip: small graphs split the batch over 4 or 8 thread groups
+    const int parts = ((M + 255) / 256) * F >= 1024 ? 1 : ((M + 63) / 64) * F >= 1024 ? 4 : 8;
+    if (parts_out) *parts_out = parts;
+    return (M + 256 / parts - 1) / (256 / parts);
+}
+
+extern "C" size_t chebgcn_brelu_pool_bwd_workspace(int B, int M, int F, int pool, int bias_kind) {
+    (void)B;
+    (void)pool;
+    if (bias_kind != CHEBGCN_BIAS_FILTER || M <= 0 || F <= 0) return 0;
+    return (size_t)F * ((size_t)(M + 31) / 32 + 1) * sizeof(float);       // the finest split: 32 vertices per workgroup
+}
+
 extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const uint8_t* argmax, float* dy,
                                       float* dbias, int bias_kind, int B, int M, int F, int pool,
-                                      int pool_kind, int relu, chebgcn_stream stream_) {
+                                      int pool_kind, int relu, void* workspace, size_t workspace_bytes,
+                                      chebgcn_stream stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CG_REQUIRE(dout && (dy || (dbias && bias_kind != CHEBGCN_BIAS_NONE)), "brelu_pool_bwd: NULL argument");
     CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "brelu_pool_bwd: bad shape");
@@ -275,40 +327,47 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
     CG_REQUIRE(pool == 1 || argmax || (pool_kind == CHEBGCN_POOL_AVG && !relu), "brelu_pool_bwd: pooling needs argmax/mask");
     CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || dbias, "brelu_pool_bwd: dbias is NULL");
     const int Mp = plane_stride(M), Mpo = plane_stride(M / pool);
-    if (pool == 1 && relu && argmax) {                  // ReLU mask of contract_fwd: vertices in fours, dy optional
-        const dim3 grid((Mp / 4 + 63) / 64, F);
-        if (bias_kind == CHEBGCN_BIAS_FILTER) {
-            CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, B, M,
-                               Mp, F);
-        } else if (bias_kind == CHEBGCN_BIAS_VERTEX) {
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, B, M,
-                               Mp, F);
-        } else {
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_NONE>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, B, M,
-                               Mp, F);
-        }
-        CG_HIP(hipGetLastError());
-        return CHEBGCN_OK;
+    int parts = 0;
+    const int nblk = brelu_bwd_blocks(M, F, pool, relu, argmax != nullptr, &parts);
+    float* fpart = nullptr;
+    if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        CG_REQUIRE(workspace && workspace_bytes >= (size_t)F * nblk * sizeof(float),
+                   "brelu_pool_bwd: the per-filter bias gradient needs a workspace of chebgcn_brelu_pool_bwd_workspace() bytes");
+        fpart = static_cast<float*>(workspace);
     }
-    // enough workgroups for the chip: small graphs split the batch over 4 or 8 thread groups
-    const int parts = ((M + 255) / 256) * F >= 1024 ? 1 : ((M + 63) / 64) * F >= 1024 ? 4 : 8;
-    if (bias_kind == CHEBGCN_BIAS_FILTER) CG_HIP(hipMemsetAsync(dbias, 0, (size_t)F * sizeof(float), stream));
+    if (pool == 1 && relu && argmax) {                  // ReLU mask of contract_fwd: vertices in fours, dy optional
+        const dim3 grid(nblk, F);
+        if (bias_kind == CHEBGCN_BIAS_FILTER) {
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
+                               B, M, Mp, F);
+        } else if (bias_kind == CHEBGCN_BIAS_VERTEX) {
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
+                               B, M, Mp, F);
+        } else {
+            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_NONE>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
+                               B, M, Mp, F);
+        }
+    } else {
 #define CG_BRELU(BK, PARTS)                                                                                       \
-    hipLaunchKernelGGL((brelu_pool_bwd_kernel<BK, PARTS>), dim3((M + 256 / PARTS - 1) / (256 / PARTS), F), dim3(256), \
-                       0, stream, dout, out, argmax, dy, dbias, B, M, Mp, F, pool, pool_kind, relu, Mpo)
+    hipLaunchKernelGGL((brelu_pool_bwd_kernel<BK, PARTS>), dim3(nblk, F), dim3(256), 0, stream, dout, out, argmax, dy, \
+                       dbias, fpart, B, M, Mp, F, pool, pool_kind, relu, Mpo)
 #define CG_BRELU_P(BK)                                                        \
     do {                                                                      \
         if (parts == 1) CG_BRELU(BK, 1);                                      \
         else if (parts == 4) CG_BRELU(BK, 4);                                 \
         else CG_BRELU(BK, 8);                                                 \
     } while (0)
-    if (bias_kind == CHEBGCN_BIAS_FILTER) CG_BRELU_P(CHEBGCN_BIAS_FILTER);
-    else if (bias_kind == CHEBGCN_BIAS_VERTEX) CG_BRELU_P(CHEBGCN_BIAS_VERTEX);
-    else CG_BRELU_P(CHEBGCN_BIAS_NONE);
+        if (bias_kind == CHEBGCN_BIAS_FILTER) CG_BRELU_P(CHEBGCN_BIAS_FILTER);
+        else if (bias_kind == CHEBGCN_BIAS_VERTEX) CG_BRELU_P(CHEBGCN_BIAS_VERTEX);
+        else CG_BRELU_P(CHEBGCN_BIAS_NONE);
 #undef CG_BRELU_P
 #undef CG_BRELU
+    }
     CG_HIP(hipGetLastError());
+    if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
+        CG_HIP(hipGetLastError());
+    }
     return CHEBGCN_OK;
 }
 
@@ -371,6 +430,20 @@ extern "C" int chebgcn_adam_step(float* p, const float* g, float* m, float* v, i
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t, beta1, beta2,
+                       eps, grad_scale, l2);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_t_dev,
+                                     float beta1, float beta2, float eps, float grad_scale, float l2,
+                                     chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(p && g && m && v && lr_t_dev && n >= 0, "adam_step_dev: bad argument");
+    if (n == 0) return CHEBGCN_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t_dev, beta1, beta2,
                        eps, grad_scale, l2);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;

@@ -78,6 +78,17 @@ class DataParallel:
     def barrier(self):
         dist.barrier(group=self.group)
 
+    def check_equal(self, value, what):
+        """Raise on every rank unless ``value`` (an int) is the same on all of them -- e.g. the shard size that
+        fixes the number of steps (and so of collectives) a rank runs in ``fit``."""
+        dev = self.model._flat.device
+        t = torch.tensor([int(value), -int(value)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        lo, hi = -int(t[1]), int(t[0])
+        if lo != hi:
+            raise ValueError('%s differs between ranks (min %d, max %d, rank %d has %d): every rank must run the same '
+                             'number of steps' % (what, lo, hi, self.rank, int(value)))
+
     # called by cgcnn.train_step -----------------------------------------------------
     def begin_step(self):
         self._pending = set(self._head_names)

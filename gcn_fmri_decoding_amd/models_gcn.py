@@ -62,6 +62,7 @@ class base_model(object):
         self._specs = None              # filled during the build pass
         self._params = {}
         self._dp = None                 # optional data-parallel helper (dist.DataParallel)
+        self._step_graph_on, self._sg, self._sg_warm = False, None, 0      # enable_step_graph()
         self.record_fit = False         # keep the sampled indices and the loss_average series of fit()
 
     # ---------------------------------------------------------------- run-time API
@@ -150,11 +151,21 @@ class base_model(object):
         """Mini-batch training loop (:112-184): ``int(num_epochs*S/batch)`` steps, samples
         drawn without replacement from a shuffled deque (:137-140), evaluation on the
         validation set every ``eval_frequency`` steps, top-3 checkpoints by validation
-        accuracy.  Returns (accuracies, losses, t_step)."""
+        accuracy.  Returns (accuracies, losses, t_step).
+
+        Under ``dist.DataParallel`` every rank calls ``fit`` with ITS OWN shard of the training set -- shards of
+        equal size (checked: a rank with fewer samples would run fewer steps and the others would wait in the
+        all-reduce forever) -- and a NumPy seed of its own (``np.random.seed(base + rank)``; the sampling below
+        draws from the global NumPy RNG like the reference, so equal seeds on equal data would make every rank
+        train on the same batches).  The validation set is evaluated by every rank (same variables, same
+        result); rank 0 alone prints and owns the checkpoint directory."""
         t_process, t_wall = time.process_time(), time.time()
         # data parallel (dist.DataParallel): rank 0 owns the checkpoint directory, and every rank
         # restarts from rank 0's freshly drawn variables (the reference re-runs op_init here, :123)
         rank0 = self._dp is None or self._dp.rank == 0
+        say = print if rank0 else (lambda *a, **k: None)
+        if self._dp is not None:
+            self._dp.check_equal(int(np.shape(train_data)[0]), 'fit(): training samples per rank')
         if rank0:
             shutil.rmtree(self._get_path('checkpoints'), ignore_errors=True)
             os.makedirs(self._get_path('checkpoints'), exist_ok=True)
@@ -170,7 +181,7 @@ class base_model(object):
         indices = collections.deque()
         n_train = train_dev.shape[0]
         num_steps = int(self.num_epochs * n_train / self.batch_size)
-        print('training with {} steps in total with batch_size={} and epochs={} for training_set={}:'.format(
+        say('training with {} steps in total with batch_size={} and epochs={} for training_set={}:'.format(
             num_steps, self.batch_size, self.num_epochs, n_train))
         for step in range(1, num_steps + 1):
             if len(indices) < self.batch_size:
@@ -187,19 +198,19 @@ class base_model(object):
                 if np.isnan(loss_average) or np.isinf(loss_average):
                     loss_average = 0
                 epoch = step * self.batch_size / n_train
-                print('step {} / {} (epoch {:.2f} / {}):'.format(step, num_steps, epoch, self.num_epochs))
-                print('  learning_rate = {:.2e}, loss_average = {:.2e}'.format(learning_rate, loss_average))
+                say('step {} / {} (epoch {:.2f} / {}):'.format(step, num_steps, epoch, self.num_epochs))
+                say('  learning_rate = {:.2e}, loss_average = {:.2e}'.format(learning_rate, loss_average))
                 # a session is passed, as in the reference (:157): evaluate() then leaves its own time line out
                 string, accuracy, f1, loss = self.evaluate(val_dev, val_labels, self._session(), isTrain=True)
                 accuracies.append(accuracy)
                 losses.append(loss)
-                print('  validation {}'.format(string))
-                print('  time: {:.0f}s (wall {:.0f}s)'.format(time.process_time() - t_process, time.time() - t_wall))
+                say('  validation {}'.format(string))
+                say('  time: {:.0f}s (wall {:.0f}s)'.format(time.process_time() - t_process, time.time() - t_wall))
                 if rank0:
                     self._save_best(accuracy, step, best)
                 if self._dp is not None:
                     self._dp.barrier()          # checkpoint files are complete before any rank restores
-        print('validation accuracy: peak = {:.2f}, mean = {:.2f}'.format(max(accuracies), np.mean(accuracies[-10:])))
+        say('validation accuracy: peak = {:.2f}, mean = {:.2f}'.format(max(accuracies), np.mean(accuracies[-10:])))
         torch.cuda.synchronize(self.device)
         if self.record_fit:
             self.fit_log['loss_average'] = [float(v) for v in self.fit_log['loss_average']]
@@ -252,10 +263,16 @@ class base_model(object):
         self.training_mode = False
         self._init_variables()
 
+    def _reset_counters(self):
+        self.global_step = 0
+        if getattr(self, '_loss_ema', None) is not None and getattr(self, '_sg', None) is not None:
+            self._loss_ema.zero_()          # a captured step holds this tensor: reset it in place
+        else:
+            self._loss_ema = None
+
     def _init_variables(self):
         """``tf.global_variables_initializer`` (:213, run at :123)."""
-        self.global_step = 0
-        self._loss_ema = None
+        self._reset_counters()
         if self.device.type == 'meta':
             return
         with torch.no_grad():
@@ -275,8 +292,7 @@ class base_model(object):
             self._adam_m.zero_()
             self._adam_v.zero_()
             self._grad.zero_()
-        self.global_step = 0
-        self._loss_ema = None
+        self._reset_counters()
 
     def variable(self, name):
         """The variable called ``name`` in the reference's shape (a view, no copy)."""
@@ -328,10 +344,34 @@ class base_model(object):
     def train_step(self, x_storage, labels):
         """One optimisation step on a batch in plane storage ``[B, channel, Mp]``:
         forward, loss, backward, (gradient all-reduce), TF-form Adam.  Returns
-        (reported learning rate, loss_average tensor)."""
+        (reported learning rate, loss_average tensor).  With ``enable_step_graph(True)`` the step is captured
+        once as a HIP graph and replayed (small graphs: the step is a chain of short kernels and launch-bound)."""
+        if self._step_graph_on and self._dp is None and self.momentum != 0 and self._fusable():
+            return self._train_step_graphed(x_storage, labels)
+        t = self.global_step + 1
+        loss_average = self._step_body(x_storage, labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
+        reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
+        self.global_step += 1
+        return reported_lr, loss_average
+
+    @staticmethod
+    def _adam_lr_t(t, lr=0.001, b1=0.9, b2=0.999):
+        """Step size of step ``t`` of tf.train.AdamOptimizer(0.001) (:296): lr * sqrt(1 - b2^t) / (1 - b1^t)."""
+        return lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+
+    def _step_body(self, x_storage, labels, lr_t, ema_correction):
+        """The device work of one step.  ``lr_t`` / ``ema_correction``: Python floats (eager) or one-element device
+        tensors that are read when the kernels run (captured step)."""
         self.training_mode = True
         if not self._fusable():
             self._grad.zero_()          # autograd accumulates into .grad there; the fused path writes every gradient
+        else:
+            # the fused path WRITES each gradient; a variable that takes no gradient (requires_grad off) would keep
+            # the slice of an earlier step -- already all-reduced under data parallelism -- and Adam would apply it again
+            for name, p in self._params.items():
+                if not p.requires_grad:
+                    a, b = self._slices[name]
+                    self._grad[a:b].zero_()
         if self._dp is not None:
             self._dp.begin_step()
         logits = self._inference_storage(x_storage, self.dropout)
@@ -343,19 +383,67 @@ class base_model(object):
         with torch.no_grad():       # the loss of this step is evaluated on the pre-update variables
             v = self._flat[:self._n_reg]
             loss = torch.add(cross_entropy.detach(), torch.dot(v, v), alpha=0.5 * self.regularization)   # + reg * sum l2_loss
-        self._apply_adam(grad_scale)
-        reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
-        self.global_step += 1
+        self._apply_adam(grad_scale, lr_t)
         with torch.no_grad():
             # tf.train.ExponentialMovingAverage(0.9) over a Tensor: zero-initialised shadow,
-            # zero-debiased on read (:269-275)
-            # shadow = 0.9 * shadow + 0.1 * loss, as one kernel
-            self._loss_ema = 0.1 * loss if self._loss_ema is None else torch.lerp(self._loss_ema, loss, 0.1)
-            loss_average = self._loss_ema * (1.0 / (1 - 0.9 ** self.global_step))
+            # zero-debiased on read (:269-275); shadow = 0.9 * shadow + 0.1 * loss, in place, as one kernel
+            if self._loss_ema is None:
+                self._loss_ema = torch.zeros((), dtype=torch.float32, device=self.device)
+            self._loss_ema.lerp_(loss, 0.1)
+            loss_average = self._loss_ema * ema_correction
         self.training_mode = False
-        return reported_lr, loss_average
+        return loss_average
 
-    def _apply_adam(self, grad_scale=1.0):
+    # ---------------------------------------------------------------- captured step (HIP graph)
+
+    def enable_step_graph(self, on=True):
+        """Run ``train_step`` as ONE captured HIP graph (``torch.cuda.CUDAGraph`` on ROCm = hipGraph): the first two
+        calls run eagerly (library initialisation), the third captures -- forward, loss, backward, Adam and the loss
+        bookkeeping, the second stream of ``contract_bwd_w`` included -- and every later call copies the batch into
+        the graph's input buffers, writes this step's two scalars (Adam's lr_t, the EMA's debiasing factor) and
+        replays.  Same kernels, same arithmetic, same results as the eager step; the batch shape must stay fixed.
+        Not used under data parallelism (the all-reduces are issued from Python while backward runs)."""
+        self._step_graph_on = bool(on)
+        self._sg = None
+        self._sg_warm = 0
+
+    def _train_step_graphed(self, x_storage, labels):
+        sg = self._sg
+        if sg is None or tuple(sg['x'].shape) != tuple(x_storage.shape):
+            if self._sg_warm < 2:
+                self._sg_warm += 1
+                t = self.global_step + 1
+                loss_average = self._step_body(x_storage, labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
+                self.global_step += 1
+                return self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum), loss_average
+            sg = self._sg = self._capture_step(x_storage, labels)
+        if sg['x'].data_ptr() != x_storage.data_ptr():
+            sg['x'].copy_(x_storage)
+        sg['labels'].copy_(labels)
+        t = self.global_step + 1
+        sg['lr_t'].fill_(self._adam_lr_t(t))
+        sg['ema_c'].fill_(1.0 / (1 - 0.9 ** t))
+        sg['graph'].replay()
+        reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
+        self.global_step += 1
+        return reported_lr, sg['loss_average'].clone()
+
+    def _capture_step(self, x_storage, labels):
+        if ops.timers is not None:
+            raise RuntimeError('per-kernel event timers cannot run inside a captured step')
+        dev = self.device
+        sg = {'x': x_storage.detach().clone(), 'labels': labels.detach().clone(),
+              'lr_t': torch.zeros(1, dtype=torch.float32, device=dev), 'ema_c': torch.zeros(1, dtype=torch.float32, device=dev)}
+        if self._loss_ema is None:
+            self._loss_ema = torch.zeros((), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            sg['loss_average'] = self._step_body(sg['x'], sg['labels'], sg['lr_t'], sg['ema_c'][0])
+        sg['graph'] = graph
+        return sg
+
+    def _apply_adam(self, grad_scale=1.0, lr_t=None):
         if self.momentum == 0:
             # tf.train.GradientDescentOptimizer branch (:288-289)
             lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
@@ -364,9 +452,9 @@ class base_model(object):
                 g[:self._n_reg] += self.regularization * self._flat[:self._n_reg]
                 self._flat -= lr * g
             return
-        t = self.global_step + 1
-        b1, b2, lr = 0.9, 0.999, 0.001
-        lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        b1, b2 = 0.9, 0.999
+        if lr_t is None:
+            lr_t = self._adam_lr_t(self.global_step + 1)
         r, n = self._n_reg, self._n_total
         if r > 0:
             ops.adam_step(self._flat[:r], self._grad[:r], self._adam_m[:r], self._adam_v[:r], lr_t, b1, b2, 1e-8,
@@ -558,9 +646,9 @@ class cgcnn(base_model):
         self.regularization, self.dropout = regularization, dropout
         self.batch_size, self.eval_frequency = batch_size, eval_frequency
         self.dir_name = dir_name
-        # arithmetic of the forward contraction: 'f32' (exact, default), 'bf16' or 'bf16x3' (bf16
-        # matrix cores for wide layers, ops.contract_fwd_into); not a reference keyword -- set it
-        # on the instance
+        # arithmetic of the contraction AND of its two gradients (ops.ChebConv): 'f32' (exact, default), 'bf16' or
+        # 'bf16x3' (bf16 matrix cores for wide layers); not a reference keyword -- set it on the instance.  It is
+        # part of the checkpoint's architecture record: a model rebuilt from a checkpoint computes as it was trained
         self.contraction = 'f32'
         self.filter = getattr(self, filter)
         self.brelu = getattr(self, brelu)
@@ -583,6 +671,7 @@ class cgcnn(base_model):
         arch = {k: v for k, v in self._ctor.items() if k != 'L'}
         arch = {k: ([int(x) if float(x).is_integer() else float(x) for x in v] if isinstance(v, list) else v)
                 for k, v in arch.items()}
+        arch['contraction'] = self.contraction
         arch['L'] = []
         for Li in self._ctor['L']:
             Li = sp.csr_matrix(Li)
@@ -599,7 +688,9 @@ class cgcnn(base_model):
         Ls = [sp.csr_matrix((np.asarray(l['data']), np.asarray(l['indices']), np.asarray(l['indptr'])), shape=tuple(l['shape']))
               for l in arch.pop('L')]
         arch.update(overrides)
+        contraction = arch.pop('contraction', 'f32')
         model = cls(config, Ls, verbose=False, **arch)
+        model.contraction = contraction
         model.load_state_dict(sd)
         return model
 

@@ -248,6 +248,15 @@ def _workspace(nbytes, device):
     return ws
 
 
+def _brelu_bwd_ws(B, M, F, pool, bias_kind, device):
+    """Scratch of chebgcn_brelu_pool_bwd: the per-workgroup partials of a per-filter (b1relu) bias gradient."""
+    n = _lib.lib().chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, bias_kind)
+    if n == 0:
+        return None, 0
+    ws = torch.empty(n, dtype=torch.uint8, device=device)
+    return ws, n
+
+
 def _check_grad_buffer(buf, shape, what):
     if tuple(buf.shape) != tuple(shape) or not buf.is_contiguous() or buf.dtype != torch.float32 or not buf.is_cuda:
         raise ValueError('%s buffer must be a contiguous float32 device tensor of shape %s' % (what, tuple(shape)))
@@ -368,15 +377,19 @@ class ChebConv(torch.autograd.Function):
             # mask); what is left of this pass is the bias reduction, which writes nothing but dbias
             dy, mask = gout, argmax
             if dbias is not None:
+                bws, nbws = _brelu_bwd_ws(B, M, Fout, 1, bias_kind, dev)
                 _lib.check(_launch('bias_grad', B * Fout * M * (4.0 + 0.25), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
-                    _p(gout), None, _p(mask), None, _p(dbias), bias_kind, B, M, Fout, 1, pool_kind, 1, _stream())), 'brelu_pool_bwd')
+                    _p(gout), None, _p(mask), None, _p(dbias), bias_kind, B, M, Fout, 1, pool_kind, 1, _p(bws), nbws,
+                    _stream())), 'brelu_pool_bwd')
         else:
             dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev), None
             # with the ReLU mask of a pool == 1 layer `out` is not read (a byte per four vertices instead)
             nbytes = B * Fout * M * (8.0 + 0.25) if out is None else 4.0 * B * Fout * (2 * Mo + M)
+            bk = bias_kind if dbias is not None else BIAS_NONE
+            bws, nbws = _brelu_bwd_ws(B, M, Fout, pool, bk, dev)
             _lib.check(_launch('brelu_pool_bwd', nbytes, 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
-                _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bias_kind if dbias is not None else BIAS_NONE, B, M, Fout,
-                pool, pool_kind, relu, _stream())), 'brelu_pool_bwd')
+                _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bk, B, M, Fout,
+                pool, pool_kind, relu, _p(bws), nbws, _stream())), 'brelu_pool_bwd')
         dW = None
         if ctx.needs_input_grad[1]:
             passes = PRECISIONS[ctx.precision]
@@ -501,9 +514,10 @@ class BiasReluPool(torch.autograd.Function):
         dbias = None
         if bias_kind != BIAS_NONE and ctx.needs_input_grad[1]:
             dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=gout.device)
-        _lib.check(_lib.lib().chebgcn_brelu_pool_bwd(_p(gout), _p(out), _p(argmax), _p(dy), _p(dbias),
-                                                     bias_kind if dbias is not None else BIAS_NONE, B, M, F, pool,
-                                                     pool_kind, relu, _stream()), 'brelu_pool_bwd')
+        bk = bias_kind if dbias is not None else BIAS_NONE
+        bws, nbws = _brelu_bwd_ws(B, M, F, pool, bk, gout.device)
+        _lib.check(_lib.lib().chebgcn_brelu_pool_bwd(_p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bk, B, M, F, pool,
+                                                     pool_kind, relu, _p(bws), nbws, _stream()), 'brelu_pool_bwd')
         return dy, dbias, None, None, None, None, None
 
 
@@ -530,10 +544,18 @@ class FeatureMean(torch.autograd.Function):
 
 
 def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
-    """In-place TF-form Adam on flat fp32 buffers (models_gcn.py:296)."""
+    """In-place TF-form Adam on flat fp32 buffers (models_gcn.py:296).  ``lr_t``: a Python float, or a one-element
+    fp32 DEVICE tensor read when the kernel runs (chebgcn_adam_step_dev: the form a captured step graph replays)."""
     _require_cuda(p, g, m, v)
     n = p.numel()
     if not (g.numel() == m.numel() == v.numel() == n):
         raise ValueError('adam_step: size mismatch')
+    if isinstance(lr_t, torch.Tensor):
+        _require_cuda(lr_t)
+        if lr_t.dtype != torch.float32 or lr_t.numel() != 1:
+            raise ValueError('adam_step: a device lr_t must be one float32')
+        _lib.check(_lib.lib().chebgcn_adam_step_dev(_p(p), _p(g), _p(m), _p(v), n, _p(lr_t), float(beta1), float(beta2),
+                                                    float(eps), float(grad_scale), float(l2), _stream()), 'adam_step_dev')
+        return
     _lib.check(_lib.lib().chebgcn_adam_step(_p(p), _p(g), _p(m), _p(v), n, float(lr_t), float(beta1), float(beta2),
                                             float(eps), float(grad_scale), float(l2), _stream()), 'adam_step')

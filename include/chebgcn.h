@@ -152,10 +152,16 @@ int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bias_kind, flo
  * dout, out: [B][F][Mp(M/pool)] (out = forward result); argmax as written by the
  * forward; dy: [B][F][Mp(M)] receives d(loss)/d(pre-bias activation); dbias: [F] or
  * [F][Mp(M)] (overwritten) or NULL.  pool == 1 with relu: a non-NULL argmax is the ReLU mask of
- * contract_fwd and replaces `out` (which may then be NULL).  dy == NULL: only dbias is computed. */
+ * contract_fwd and replaces `out` (which may then be NULL).  dy == NULL: only dbias is computed.
+ * workspace: device scratch of at least chebgcn_brelu_pool_bwd_workspace() bytes -- 0 (NULL allowed)
+ * unless bias_kind is CHEBGCN_BIAS_FILTER: the per-filter sum of b1relu (models_gcn.py:619-623) is a
+ * two-stage reduction in a fixed order (per-workgroup partials, then one wave per filter), so every
+ * gradient this library returns is bit-reproducible from run to run. */
+size_t chebgcn_brelu_pool_bwd_workspace(int B, int M, int F, int pool, int bias_kind);
 int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const uint8_t* argmax,
                            float* dy, float* dbias, int bias_kind, int B, int M, int F,
-                           int pool, int pool_kind, int relu, chebgcn_stream stream);
+                           int pool, int pool_kind, int relu, void* workspace, size_t workspace_bytes,
+                           chebgcn_stream stream);
 
 /* ---- gradients of the contraction (MatMul grads) ---------------------------------
  * dW[fin*K+k][o] = sum_{b,m} stack[k][b][fin][m] * dy[b][o][m]      (overwritten)
@@ -202,15 +208,27 @@ int chebgcn_feature_mean_bwd(const float* dy, float* dx, int B, int M, int F, ch
 int chebgcn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t,
                       float beta1, float beta2, float eps, float grad_scale, float l2,
                       chebgcn_stream stream);
+/* The same step with lr_t read from DEVICE memory when the kernel runs: the form a captured HIP graph of
+ * the training step replays (the host writes this step's lr_t into *lr_t_dev ahead of the launch). */
+int chebgcn_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_t_dev,
+                          float beta1, float beta2, float eps, float grad_scale, float l2,
+                          chebgcn_stream stream);
 
 /* ---- host-side index maps (no GPU): lib_new/coarsening.py -----------------------
  * metis_one_level (:120-166): one greedy matching pass, bit-exact incl. the
  * reference's row-length quirk.  rr/cc: int64 [nnz] sorted by rr; vv/weights in the
  * given precision; rid: int64 [N] visiting order; cluster_id: int32 [N] out.
+ * The matching score vv*(1.0/weights[tid] + 1.0/weights[nid]) (:153) is evaluated as NumPy evaluates it
+ * on scalars of that dtype: _f32 entirely in float32 (NumPy >= 2, NEP 50: a Python float does not widen
+ * a float32 scalar), _f64 in float64, and _f32p on float32 inputs PROMOTED to float64 -- what NumPy 1.x
+ * (the generation the reference was written for) does with a float32 graph; near-ties of the strict `>`
+ * can fall differently between _f32 and _f32p (tests/golden/coarsen_unit_n*.npz holds both outcomes).
  * compute_perm (:168-215) for ONE level: children of `order` (length n_order) among
  * the fine vertices with `parent` (length n_fine); out must hold 2*n_order. */
 int chebgcn_metis_one_level_f32(int64_t nnz, const int64_t* rr, const int64_t* cc, const float* vv,
                                 const int64_t* rid, const float* weights, int64_t N, int32_t* cluster_id);
+int chebgcn_metis_one_level_f32p(int64_t nnz, const int64_t* rr, const int64_t* cc, const float* vv,
+                                 const int64_t* rid, const float* weights, int64_t N, int32_t* cluster_id);
 int chebgcn_metis_one_level_f64(int64_t nnz, const int64_t* rr, const int64_t* cc, const double* vv,
                                 const int64_t* rid, const double* weights, int64_t N, int32_t* cluster_id);
 int chebgcn_compute_perm_level(const int32_t* parent, int64_t n_fine, const int64_t* order,

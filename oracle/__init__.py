@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
 only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py`` may import it, and there only as the checker / the timed CPU
 baseline -- never as the thing shipped.  ``gcn_fmri_decoding_amd`` must not
-import from here (``tests/test_no_oracle_in_product.py`` enforces that).
+import from here (``tests/test_abi_and_host.py::test_product_does_not_import_oracle``
+enforces that).
 
 What it is: a NumPy/SciPy restatement of the algorithm of
 ``zhangyu2ustc/GCN_fmri_decoding`` for the path named by BASELINE.json

@@ -18,8 +18,12 @@ import numpy as np
 import scipy.sparse as sp
 
 
-def metis_one_level(rr, cc, vv, rid, weights):
+def metis_one_level(rr, cc, vv, rid, weights, promote=False):
     """One greedy heavy-edge matching pass (coarsening.py:120-166).
+
+    ``promote``: evaluate the score in float64 on float32 inputs -- what NumPy 1.x
+    (value-based casting: ``1.0 / np.float32`` is a float64) made of :153; the default is
+    what NumPy >= 2 does (NEP 50: the expression stays float32).
 
     ``rr`` is assumed sorted.  Row extents are derived exactly like the
     reference's counting loop (:134-139): the boundary test runs *after* the
@@ -28,6 +32,8 @@ def metis_one_level(rr, cc, vv, rid, weights):
     appearance (``count``), not by row id, which only matters for graphs with
     empty rows.
     """
+    if promote:
+        vv, weights = np.asarray(vv, np.float64), np.asarray(weights, np.float64)
     nnz = rr.shape[0]
     N = int(rr[nnz - 1]) + 1
     # positions ii where rr[ii] exceeds everything seen before it
@@ -68,7 +74,7 @@ def metis_one_level(rr, cc, vv, rid, weights):
     return cluster_id
 
 
-def metis(W, levels, rid=None):
+def metis(W, levels, rid=None, promote=False):
     """``levels`` rounds of matching + graph contraction (coarsening.py:34-116)."""
     N = W.shape[0]
     if rid is None:
@@ -82,7 +88,7 @@ def metis(W, levels, rid=None):
         r, c, v = sp.find(W)
         order = np.argsort(r, kind='stable')
         rr, cc, vv = r[order], c[order], v[order]
-        cid = metis_one_level(rr, cc, vv, rid, weights)
+        cid = metis_one_level(rr, cc, vv, rid, weights, promote)
         parents.append(cid)
         Nnew = int(cid.max()) + 1
         # duplicate (row, col) pairs are summed by the CSR constructor (:99)

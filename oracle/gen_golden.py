@@ -363,6 +363,51 @@ def main():
         print('   ', {k: (v.tolist() if v.ndim else v.item()) for k, v in out.items()
                       if k.endswith('sizes') or k.endswith('nnz')})
 
+    near_tie_fixture(rgraph, rcoarse, save)
+
+
+def near_tie_fixture(rgraph, rcoarse, save):
+    """A graph whose matching scores (coarsening.py:153) hold exact ties and near-ties: small-integer edge weights
+    (1..7) on a kNN pattern, so the scores v*(1/d_i + 1/d_j) are ratios of small integers and the precision the
+    expression is evaluated in decides some matches of the strict ``>``.  (Unit weights alone do not: for a fixed
+    vertex the score is monotone in 1/d_j in either precision -- six unit-weight graphs tried, no difference.)
+    Two runs of the REFERENCE's ``metis`` (stable argsort shim as everywhere): as this NumPy (>= 2) evaluates it --
+    float32 throughout -- and with its ``metis_one_level`` handed the same float32 numbers as float64 arrays, which
+    is exactly NumPy 1.x's value-based promotion of ``1.0 / np.float32`` (the reference file is untouched; ``metis``
+    finds the wrapper through its module's global name)."""
+    N, k, levels, seed, hi = 300, 10, 3, 5, 7
+    z = np.random.RandomState(seed).rand(N, 3).astype(np.float32)
+    d, idx = rgraph.distance_sklearn_metrics(z, k=k, metric='euclidean')
+    U = sp.triu(rgraph.adjacency(d, idx), 1).tocoo()
+    w = np.random.RandomState(seed + 100).randint(1, hi + 1, U.nnz).astype(np.float32)
+    U = sp.csr_matrix((w, (U.row, U.col)), shape=U.shape)
+    A = (U + U.T).tocsr().astype(np.float32)
+    out = dict(levels=np.int64(levels))
+    out.update(_csr_fields('A', A))
+    orig = rcoarse.metis_one_level
+    res = {}
+    for tag in ('f32', 'f32p'):
+        if tag == 'f32p':
+            rcoarse.metis_one_level = lambda rr, cc, vv, rid, w: orig(rr, cc, np.asarray(vv, np.float64), rid,
+                                                                     np.asarray(w, np.float64))
+        try:
+            graphs, parents = _quiet(_with_stable, rcoarse, lambda: rcoarse.metis(A, levels))
+            perms = rcoarse.compute_perm(parents)
+        finally:
+            rcoarse.metis_one_level = orig
+        res[tag] = parents
+        for i, par in enumerate(parents):
+            out['%s_parents%d' % (tag, i)] = np.asarray(par)
+        out['%s_perm' % tag] = np.array(perms[0], np.int64)
+        for i, G in enumerate(graphs):
+            out.update(_csr_fields('%s_metis%d' % (tag, i), G))
+    ndiff = int((res['f32'][0] != res['f32p'][0]).sum())
+    assert ndiff > 0, 'choose another graph: the two evaluations agree at the first level'
+    out['first_level_parents_differing'] = np.int64(ndiff)
+    save('coarsen_ties_n300', **out)
+    print('    integer weights 1..%d: float32 and promoted-float64 scores give different first-level parents for %d of %d '
+          'vertices' % (hi, ndiff, N))
+
 
 def _with_stable(rcoarse, fn):
     saved = rcoarse.np

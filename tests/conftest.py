@@ -20,7 +20,11 @@ def pytest_configure(config):
         import shutil
         import subprocess
         if shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc'):
-            subprocess.run(['make', '-s', '-C', os.path.join(ROOT, 'gcn_fmri_decoding_amd', 'csrc')], check=False)
+            r = subprocess.run(['make', '-s', '-C', os.path.join(ROOT, 'gcn_fmri_decoding_amd', 'csrc')], check=False)
+            if r.returncode != 0 or not os.path.exists(so):
+                # say so here: otherwise the failure only shows up later as "libchebgcn.so not found"
+                pytest.exit('building libchebgcn.so failed (make exit code %d); see the compiler output above'
+                            % r.returncode, returncode=3)
 
 
 def load_golden(name):

@@ -435,7 +435,7 @@ def test_contraction_bench_launch_b64(ops, dev):
     assert err <= GREL, 'contract_bwd_x_relu: %.3e' % err
 
     dbias = torch.full((Fout, Mp), float('nan'), device=dev)
-    _lib.check(lib.chebgcn_brelu_pool_bwd(P(gout), None, P(mask), None, P(dbias), ops.BIAS_VERTEX, B, M, Fout, 1, 0, 1, st), 'bias')
+    _lib.check(lib.chebgcn_brelu_pool_bwd(P(gout), None, P(mask), None, P(dbias), ops.BIAS_VERTEX, B, M, Fout, 1, 0, 1, None, 0, st), 'bias')
     db_ref = dy.sum(0)
     err = float((dbias[:, :M].double() - db_ref).abs().max() / db_ref.abs().max())
     assert err <= GREL, 'bias gradient: %.3e' % err

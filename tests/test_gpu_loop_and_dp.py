@@ -249,5 +249,6 @@ def test_cgcnn_data_parallel_on_rccl_world_one(dev, tmp_path):
     assert int(dp['nb']) == 2 and dp['sent'].tolist() == [0, 1]
     assert np.array_equal(dp['flat0'], one['flat0'])
     for k in ('g0', 'g2', 'flat'):
-        scale = np.abs(one[k]).max()
-        assert np.abs(dp[k] - one[k]).max() <= 1e-6 * scale, k      # per-filter bias sums are atomic: not bit-reproducible
+        # bit-identical: every gradient of the library is a fixed-order sum (the per-filter bias sums of this b1relu
+        # model too: two-stage reduction since round 3), and a sum over one rank is the identity
+        assert np.array_equal(dp[k], one[k]), k

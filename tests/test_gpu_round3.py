@@ -1,0 +1,190 @@
+"""GPU tests added in round 3 (all through the C ABI): the fixed-order per-filter bias gradient of ``b1relu``, the
+training step captured as one HIP graph against the eager step, and the full network at the shape the reference's
+own ``training.py`` builds (atlas-sized graph, K = 10 x 6, batch 128) against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import layers_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gcn_fmri_decoding_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize('M,F,B,pool,relu_mask', [(10466, 32, 64, 1, True), (232, 8, 5, 1, True), (232, 8, 5, 1, False),
+                                                  (792, 16, 6, 4, False), (10466, 32, 3, 2, False)])
+def test_b1relu_bias_gradient_is_a_fixed_order_sum(ops, dev, M, F, B, pool, relu_mask):
+    """``chebgcn_brelu_pool_bwd`` with ``CHEBGCN_BIAS_FILTER`` (b1relu, models_gcn.py:619-623): per-workgroup partials
+    plus one wave per filter instead of a float atomicAdd across workgroups.  Twenty launches give BIT-identical sums
+    (the atomics differed from run to run), equal to a float64 sum of the same gated gradient to fp32 round-off; a
+    missing workspace is refused."""
+    from gcn_fmri_decoding_amd import _lib
+    lib, P, st = _lib.lib(), ops._p, ops._stream()
+    Mp, Mo = _lib.plane_stride(M), M // pool
+    Mpo = _lib.plane_stride(Mo)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(M + F)
+    gout = torch.randn((B, F, Mpo), generator=gen, device=dev)
+    gout[:, :, Mo:] = 1e30                                  # plane pads must not leak into the sums
+    nws = lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, ops.BIAS_FILTER)
+    assert nws > 0 and lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, ops.BIAS_VERTEX) == 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    if relu_mask:                                           # pool == 1 layer: the ReLU bit mask contract_fwd leaves
+        bits = torch.randint(0, 16, (B, F, Mp // 4), generator=gen, device=dev, dtype=torch.uint8)
+        keep = torch.stack([(bits >> i) & 1 for i in range(4)], -1).reshape(B, F, Mp)[:, :, :M].bool()
+        gated = torch.where(keep, gout[:, :, :M], torch.zeros((), device=dev))
+        args = lambda db: (P(gout), None, P(bits), None, P(db), ops.BIAS_FILTER, B, M, F, 1, 0, 1, P(ws), nws, st)
+    else:                                                   # forward output + argmax of a max-pooling layer
+        out = torch.randn((B, F, Mpo), generator=gen, device=dev)
+        arg = torch.randint(0, pool, (B, F, Mpo), generator=gen, device=dev, dtype=torch.uint8)
+        gated = torch.where(out[:, :, :Mo] > 0, gout[:, :, :Mo], torch.zeros((), device=dev))
+        dy = torch.empty((B, F, Mp), device=dev)
+        args = lambda db: (P(gout), P(out), P(arg) if pool > 1 else None, P(dy), P(db), ops.BIAS_FILTER, B, M, F, pool, 0, 1,
+                           P(ws), nws, st)
+    ref = gated.double().sum((0, 2))
+    results = []
+    for _ in range(20):
+        db = torch.full((F,), float('nan'), device=dev)
+        _lib.check(lib.chebgcn_brelu_pool_bwd(*args(db)), 'brelu_pool_bwd')
+        results.append(db.clone())
+    for r in results[1:]:
+        assert torch.equal(r, results[0])
+    err = float((results[0].double() - ref).abs().max() / gated.double().abs().sum((0, 2)).max())
+    assert err <= 1e-6, err
+    db = torch.zeros((F,), device=dev)
+    a = list(args(db))
+    a[-3], a[-2] = None, 0
+    assert lib.chebgcn_brelu_pool_bwd(*a) != 0 and b'workspace' in lib.chebgcn_last_error()
+
+
+def _build(z, dev, **kw):
+    from conftest import csr_from
+    from gcn_fmri_decoding_amd import models_gcn
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    net = models_gcn.cgcnn({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                           channel=int(z['channel']), brelu=str(z['brelu']), batch_size=int(z['x'].shape[0]), verbose=False, **kw)
+    for k in z.files:
+        if k.startswith('param:'):
+            net.set_variable(k[len('param:'):], z[k])
+    return net
+
+
+@pytest.mark.parametrize('name', ['inference_flat_n212', 'inference_pool_n212', 'inference_pool6_n512'])
+def test_captured_step_equals_eager_step(ops, dev, name):
+    """``cgcnn.enable_step_graph``: the training step captured as ONE HIP graph (forward, loss, backward with the second
+    stream of contract_bwd_w, Adam reading lr_t from device memory, EMA bookkeeping) replays the same kernels on the
+    same operands: after six steps (two eager warm-up steps, capture at the third, three replays) on changing batches
+    the variables, the Adam moments and the reported loss_average series are BIT-identical to six eager steps."""
+    z = load_golden(name)
+    B, M0, C = z['x'].shape
+    rs = np.random.RandomState(3)
+    batches = [rs.randn(B, M0, C).astype(np.float32) for _ in range(6)]
+    labels = [rs.randint(0, int(z['M'][-1]), B) for _ in range(6)]
+    runs = []
+    for graphed in (False, True):
+        net = _build(z, dev, regularization=5e-4, dropout=1)
+        net.enable_step_graph(graphed)
+        series = []
+        for xb, lb in zip(batches, labels):
+            x = ops.plane_storage(torch.as_tensor(xb).to(dev)).contiguous()
+            lr, la = net.train_step(x, torch.as_tensor(lb).to(dev))
+            series.append(la)
+        torch.cuda.synchronize()
+        assert net.global_step == 6 and (net._sg is not None) == graphed
+        runs.append((net._flat.clone(), net._adam_m.clone(), net._adam_v.clone(), [float(v) for v in series]))
+    for a, b in zip(runs[0][:3], runs[1][:3]):
+        assert torch.equal(a, b)
+    assert runs[0][3] == runs[1][3]
+
+
+def test_captured_step_with_dropout_trains(ops, dev):
+    """With dropout (keep 0.5, as the reference trains) the captured step draws a fresh mask per replay (graph-safe
+    Philox offsets): losses stay finite and differ between replays of the same batch."""
+    z = load_golden('inference_flat_n212')
+    net = _build(z, dev, regularization=5e-4, dropout=0.5)
+    net.enable_step_graph(True)
+    x = ops.plane_storage(torch.as_tensor(z['x']).to(dev)).contiguous()
+    lb = torch.as_tensor(np.arange(z['x'].shape[0]) % int(z['M'][-1])).to(dev)
+    before = net._flat.clone()
+    torch.manual_seed(0)
+    logits = []
+    for _ in range(6):
+        net.train_step(x, lb)
+    # two replays of the forward alone on the same variables differ only through the dropout masks
+    vals = [float(net.train_step(x, lb)[1]) for _ in range(3)]
+    assert all(np.isfinite(v) for v in vals) and not torch.equal(before, net._flat)
+
+
+@pytest.mark.parametrize('n_nodes', [360, 1000])
+def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
+    """The network the reference's ``training.py`` actually builds (model.py:271-280, training.py:34,
+    configure_fmri.py:28, 41): atlas-sized graph (360 = MMP atlas; 1000), kNN-8, one coarsening level, ChebNet
+    K = 10 x 6, F = 32, p = 1, b2relu, FC 512-256-22, batch 128, block_dura 15 -- logits, loss, every gradient and
+    one TF-form Adam step against the oracle, on the kernels this shape selects (generic four-plane recurrence, batch
+    split of the bias gradient), eagerly and through the captured HIP graph."""
+    from gcn_fmri_decoding_amd import graph, models_gcn
+    from conftest import assert_adam_params_close
+    Ls, perm, _ = graph.synthetic_graph(n_nodes, k=8, levels=1)
+    L = Ls[0]
+    M, B, C = L.shape[0], 128, 15
+    F, K, p, Mfc = [32] * 6, [10] * 6, [1] * 6, [512, 256, 22]
+    reg = 5e-4
+    torch.manual_seed(0)
+    net = models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he',
+                           channel=C, regularization=reg, dropout=1, batch_size=B, learning_rate=0.001, decay_rate=0.9,
+                           momentum=0.9, verbose=False)
+    params = {k: net.get_var(k).copy() for k in net.variables()}
+    onet = R.Net([L] * 6, F, K, p, Mfc, channel=C, brelu='b2relu', regularization=reg)
+    rs = np.random.RandomState(1)
+    x = np.zeros((B, M, C), np.float32)
+    keep = np.asarray(perm) < n_nodes
+    x[:, keep, :] = rs.randn(B, int(keep.sum()), C).astype(np.float32)      # fake vertices carry zeros (perm_data_3d)
+    labels = rs.randint(0, 21, B)
+    logits, cache = onet.forward(params, x)
+    loss, dlogits = onet.loss(params, logits, labels)
+    grads = onet.backward(params, cache, dlogits)
+    xs = ops.plane_storage(torch.as_tensor(x).to(dev)).contiguous()
+    with torch.no_grad():
+        got = net._inference_storage(xs, 1).cpu().numpy()
+    assert np.abs(got - logits).max() <= 2e-5 * np.abs(logits).max()
+    ld = torch.as_tensor(labels).to(dev)
+    _, loss_avg = net.train_step(xs, ld)
+    assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
+    for k in params:
+        spec = next(s for s in net._spec_list if s.name == k)
+        g = net._params[k].grad
+        if spec.group == 'convb':
+            g = g[:, :spec.ref_shape[1]].t().unsqueeze(0)
+        ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
+        err = np.abs(g.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
+        assert err <= 5e-5, 'grad %s: %.3e' % (k, err)
+    state, ill = {}, {}
+    R.adam_tf_step(params, grads, state)
+    for k in params:
+        assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], 0, ill, k, rel=2e-5)
+    # the same model through the captured graph: two more eager steps, capture, replay -- bit-identical to a twin that
+    # runs all of them eagerly
+    twin = models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he',
+                            channel=C, regularization=reg, dropout=1, batch_size=B, learning_rate=0.001, decay_rate=0.9,
+                            momentum=0.9, verbose=False)
+    twin.load_state_dict(net.state_dict())
+    twin._loss_ema = net._loss_ema.clone()
+    net.enable_step_graph(True)
+    for _ in range(4):
+        net.train_step(xs, ld)
+        twin.train_step(xs, ld)
+    torch.cuda.synchronize()
+    assert net._sg is not None and torch.equal(net._flat, twin._flat)

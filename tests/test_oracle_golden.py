@@ -102,3 +102,20 @@ def test_inference_vs_reference_source(name):
     logits, _ = net.forward(params, z['x'])
     ref = z['logits']
     np.testing.assert_allclose(logits, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('tag, promote', [('f32', False), ('f32p', True)])
+def test_coarsening_near_ties_both_numpy_generations(tag, promote):
+    """Integer-weight graph full of ties and near-ties of the matching score (coarsening.py:153): the fixture holds the
+    REFERENCE's output as NumPy >= 2 evaluates the score (float32, ``f32_*``) and as NumPy 1.x did (float32 values
+    promoted to float64, ``f32p_*``).  23 first-level parents differ between the two; each mode reproduces its own."""
+    z = load_golden('coarsen_ties_n300')
+    A = csr_from(z, 'A')
+    levels = int(z['levels'])
+    assert int(z['first_level_parents_differing']) == int((z['f32_parents0'] != z['f32p_parents0']).sum()) > 0
+    graphs, parents = C.metis(A, levels, promote=promote)
+    for i in range(levels):
+        assert np.array_equal(parents[i], z['%s_parents%d' % (tag, i)])
+    for i in range(levels + 1):
+        assert_csr_equal(graphs[i], csr_from(z, '%s_metis%d' % (tag, i)))
+    assert C.compute_perm(parents)[0] == z['%s_perm' % tag].tolist()

@@ -117,7 +117,7 @@ def main():
                                     B * M * (4.0 * (Fin * K + Fout) + Fout / 4.0), 2.0 * B * M * Fin * K * Fout),
             'contract_bwd_x_relu': (lambda: lib.chebgcn_contract_bwd_x_relu(P(dy), P(mask), P(W), P(gstack), B, M, Fin, K, Fout, st),
                                     B * M * (4.0 * (Fin * K + Fout) + Fout / 4.0), 2.0 * B * M * Fin * K * Fout),
-            'bias_grad_relu': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), None, P(mask), None, P(dbias), 2, B, M, Fout, 1, 0, 1, st),
+            'bias_grad_relu': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), None, P(mask), None, P(dbias), 2, B, M, Fout, 1, 0, 1, None, 0, st),
                                B * Fout * M * 4.25, 0.0),
             'contract_bwd_w_bf16': (lambda: lib.chebgcn_contract_bwd_w_bf16(P(stack), P(dy), P(dW), P(wsw16), wsw16.numel(), B, M, Fin,
                                                                             K, Fout, 1, st),
@@ -132,7 +132,7 @@ def main():
                                                                               wsx16.numel(), st),
                                       4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
             'brelu_pool_bwd': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), P(out), None, P(dx) if Fin == Fout else P(out),
-                                                                  P(dbias), 2, B, M, Fout, 1, 0, 1, st),
+                                                                  P(dbias), 2, B, M, Fout, 1, 0, 1, None, 0, st),
                                4.0 * B * Fout * 3 * M, 0.0),
         }
         for name in args.kernels:
