@@ -48,6 +48,12 @@ struct Ell {
     uint4* colo = nullptr;        // [(nquads + kQuadPad)/2*64]  the same ids, quads 2o and 2o+1 in one record
     float4* valq = nullptr;       // [(nquads + kQuadPad)*64]
     float4* valp = nullptr;       // the same, with the two ids of a short third quad in .z / .w (graph.hip)
+    // Fixed-stride image of the first 12 entries of every row group (P = 4, recurrence4.hip): offsets are compile-time
+    // constants of the group's slot, so the gather needs no per-group table lookups.  uval[g*4 + r][lane]: r = 0, 1 the
+    // values of quads 0 and 1; r = 2 {value 8, value 9, slot ids (8, 9), slot ids (10, 11)}; r = 3 {value 10, value 11, 0, 0};
+    // uids[g][lane] = the eight 16-bit slot ids of quads 0 and 1.  Entries beyond 12 stay in colo / valq.
+    float4* uval = nullptr;       // [ngroups*4*64]
+    uint4* uids = nullptr;        // [ngroups*64]
     uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> LDS slot of that row, 0xFFFF for padding ranks
     uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> LDS slot, 0xFFFF = none (isolated / pad)
     // plain CSR for the out-of-LDS fallback
@@ -66,10 +72,12 @@ struct EllView {
     const uint16_t* rowslot;
     const uint16_t* nodeslot;
     int ngroups, zero_slot;
+    const float4* uval;
+    const uint4* uids;
 };
 
 static inline EllView view(const Ell& e) {
-    return EllView{e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot};
+    return EllView{e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot, e.uval, e.uids};
 }
 
 }  // namespace chebgcn

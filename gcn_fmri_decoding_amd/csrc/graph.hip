@@ -33,7 +33,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 static void free_ell(Ell& e) {
-    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval};
+    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval, e.uval, e.uids};
     for (void* p : ptrs) (void)hipFree(p);
     e = Ell();
 }
@@ -246,6 +246,36 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
         }
     }
     if ((rc = upload(&out->valp, valp))) return rc;
+    if (planes == 4) {
+        // fixed-stride image of entries 0..11 (common.h): every group has at least four stored quads
+        // a kernel shape requests the records of every slot of every wave (up to 20 slots x 8 waves), also those beyond
+        // the last group: padded with empty groups (values 0, ids = the zero slot)
+        const int ngpad = std::max(((ngroups + 7) / 8) * 8, 160);
+        std::vector<float4> uval((size_t)ngpad * 4 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+        std::vector<uint4> uids((size_t)ngpad * 64, make_uint4(zz, zz, zz, zz));
+        for (size_t i = (size_t)ngroups * 4 * 64 + 2 * 64; i < uval.size(); i += 4 * 64)      // record 2 of a padding group: its two id words
+            for (int lane = 0; lane < 64; ++lane) {
+                memcpy(&uval[i + lane].z, &zz, 4);
+                memcpy(&uval[i + lane].w, &zz, 4);
+            }
+        for (int g = 0; g < ngroups; ++g) {
+            const size_t q0 = (size_t)ginfo[g].x;
+            for (int lane = 0; lane < 64; ++lane) {
+                const uint2 c0 = colq[q0 * 64 + lane], c1 = colq[(q0 + 1) * 64 + lane], c2 = colq[(q0 + 2) * 64 + lane];
+                const float4 v2 = valq[(q0 + 2) * 64 + lane];
+                uids[(size_t)g * 64 + lane] = make_uint4(c0.x, c0.y, c1.x, c1.y);
+                uval[((size_t)g * 4 + 0) * 64 + lane] = valq[q0 * 64 + lane];
+                uval[((size_t)g * 4 + 1) * 64 + lane] = valq[(q0 + 1) * 64 + lane];
+                float4 r2 = make_float4(v2.x, v2.y, 0.f, 0.f);
+                memcpy(&r2.z, &c2.x, 4);
+                memcpy(&r2.w, &c2.y, 4);
+                uval[((size_t)g * 4 + 2) * 64 + lane] = r2;
+                uval[((size_t)g * 4 + 3) * 64 + lane] = make_float4(v2.z, v2.w, 0.f, 0.f);
+            }
+        }
+        if ((rc = upload(&out->uval, uval))) return rc;
+        if ((rc = upload(&out->uids, uids))) return rc;
+    }
     if ((rc = upload(&out->rowslot, rowslot))) return rc;
     if ((rc = upload(&out->nodeslot, nodeslot))) return rc;
     return CHEBGCN_OK;

@@ -26,6 +26,8 @@
 //     next group's input are ONE pass -- a thread reads the old entries of its linear pieces and
 //     overwrites them with the new input, no barrier in between; the input was requested behind
 //     the barrier that ended the last gather, so its HBM latency hides under the last rotate.
+#include <type_traits>
+
 #include "common.h"
 
 namespace chebgcn {
@@ -34,7 +36,13 @@ extern int g_ablate;
 extern int g_stagger;
 
 #ifndef CG_X
-#define CG_X 0               // 64: in-kernel phase stamps (tools/xbuild.sh, tools/kbench.py --stamps); 0 in production
+#define CG_X 0               // 64: in-kernel phase stamps (tools/vbuild.sh, tools/kbench.py --stamps); 0 in production
+#endif
+#ifndef CG_GATHER_ASM
+// 2 (shipped): C++ gather on the fixed-stride operator image (compile-time record offsets, length classes by scalar tests);
+// 1: the same records gathered by one asm statement per row group with EXEC-masked optional entries (gather12; measured
+//    slower, kept for the experiments of EXPERIMENTS.md); 0: the round-2 gather on the variable-stride image
+#define CG_GATHER_ASM 2
 #endif
 // In-kernel phase stamps (CG_X & 64, tools/xbuild.sh): lane 0 of every wave of workgroup 37 records the
 // cycle counter at the phase boundaries of its SECOND plane group (tools/kbench.py --stamps).
@@ -97,12 +105,132 @@ __device__ __forceinline__ void add_comp(float4& v, int i, float x) {
 __device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ uint2 opaque(uint2 x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); return x; }
 __device__ __forceinline__ float4 opaque(float4 x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); return x; }
+// the same for a uniform value (SGPR): what is derived from it is recomputed at its use (one scalar add or compare)
+// instead of being hoisted out of the step loop -- 20 slots x 5 offsets and 3 conditions would occupy over a hundred
+// SGPRs, spilled to VGPR lanes and read back with v_readlane + wait states in front of every load
+__device__ __forceinline__ unsigned opaque_s(unsigned x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 __device__ __forceinline__ float4 fma4(float s, const float4& t, const float4& a) {
     return make_float4(fmaf(s, t.x, a.x), fmaf(s, t.y, a.y), fmaf(s, t.z, a.z), fmaf(s, t.w, a.w));
 }
 // plane p of the four vertices whose entries are t[0..3]
 __device__ __forceinline__ float4 plane_of_entries(const float4 (&t)[4], int p) {
     return make_float4(comp(t[0], p), comp(t[1], p), comp(t[2], p), comp(t[3], p));
+}
+
+// ---- the gather of one row group as ONE asm statement without control flow (CG_GATHER_ASM) ----------------------
+// Round 3 measurements on the benchmark graph (profiles/r03_recurrence4_gather_ablations.txt): of the 15.5-17.4k cycles a
+// gather step took, LDS reads were 2.8k, the multiply-adds 0.1k, the operator loads 3k -- and 7k were the skeleton around
+// them: per row group six v_readlane (table lookups of {offset, length}) feeding scalar compares, and eight branches (length
+// classes 8 / 10 / 12 / longer, conditional operator requests).  With lengths and offsets known at compile time (wrong
+// results) the same gather ran in 9.0k cycles.  Bank conflicts turned out not to matter (a conflict-free address pattern
+// changed nothing), nor did issuing more than four LDS reads at a time (-12 %).  So the gather is built without control flow:
+//   * the operator image has a FIXED stride per row group (common.h, uval / uids): the offset of a record is a constant
+//     of the group's slot j plus one per-wave base -- no table lookups;
+//   * rows are sorted by length, so the slots of a wave are [nB groups beyond 10 entries | up to nA beyond 8 | the rest];
+//     entries 8..9 and 10..11 of every group are gathered under an EXEC mask derived from j < nA, j < nB with two scalar
+//     instructions (s_cmp + s_cselect into exec): an inactive part costs its issue slots, never a branch;
+//   * the only branches left are the two scalar-only tests that skip the optional operator requests two groups ahead, and
+//     the tail of rows longer than 12 entries in the first slots.
+// The statement issues the eight reads of quads 0 and 1, consumes the first quad, sends the masked reads of entries 8..11
+// into the freed registers and finishes behind counted `s_waitcnt lgkmcnt(n)`; nothing is in flight when it ends (hipcc
+// neither counts nor moves these loads, cdna_hip_programming.md 5.7).  The thresholds behind the masked reads are the
+// ones that are safe whether or not the hardware counts a read issued with EXEC = 0.  The 16-byte results live in a fixed
+// block of registers (v[224:255], named in the clobber list): an asm operand cannot name the halves of a 128-bit tuple, and
+// v_pk_fma_f32 wants them (planes 0-1 / 2-3 of one entry).  The address of a read is computed into the first register of
+// its own destination.  A scalar of a value pair is broadcast with op_sel (low dword) / op_sel + op_sel_hi (high dword) --
+// hipcc copies the odd components to an even register first.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// slot n of the register block: the 16-byte result (R), its halves (L = planes 0-1, H = planes 2-3), its first register (A)
+#define CG_R0 "v[224:227]"
+#define CG_L0 "v[224:225]"
+#define CG_H0 "v[226:227]"
+#define CG_A0 "v224"
+#define CG_R1 "v[228:231]"
+#define CG_L1 "v[228:229]"
+#define CG_H1 "v[230:231]"
+#define CG_A1 "v228"
+#define CG_R2 "v[232:235]"
+#define CG_L2 "v[232:233]"
+#define CG_H2 "v[234:235]"
+#define CG_A2 "v232"
+#define CG_R3 "v[236:239]"
+#define CG_L3 "v[236:237]"
+#define CG_H3 "v[238:239]"
+#define CG_A3 "v236"
+#define CG_R4 "v[240:243]"
+#define CG_L4 "v[240:241]"
+#define CG_H4 "v[242:243]"
+#define CG_A4 "v240"
+#define CG_R5 "v[244:247]"
+#define CG_L5 "v[244:245]"
+#define CG_H5 "v[246:247]"
+#define CG_A5 "v244"
+#define CG_R6 "v[248:251]"
+#define CG_L6 "v[248:249]"
+#define CG_H6 "v[250:251]"
+#define CG_A6 "v248"
+#define CG_R7 "v[252:255]"
+#define CG_L7 "v[252:253]"
+#define CG_H7 "v[254:255]"
+#define CG_A7 "v252"
+// address of the entry named by the low / high 16 bits of id register c into slot n, and its read
+#define CG_RDLO(n, c) "v_lshlrev_b32_sdwa " CG_A##n ", 4, " c " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\tds_read_b128 " CG_R##n ", " CG_A##n "\n\t"
+#define CG_RDHI(n, c) "v_lshlrev_b32_sdwa " CG_A##n ", 4, " c " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\tds_read_b128 " CG_R##n ", " CG_A##n "\n\t"
+#define CG_W(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
+// acc (+)= v.lo * slot n / v.hi * slot n for both plane pairs; F0 starts the sums
+#define CG_F0(n, v) "v_pk_fma_f32 %[a01], " v ", " CG_L##n ", 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a23], " v ", " CG_H##n ", 0 op_sel_hi:[0,1,0]\n\t"
+#define CG_FL(n, v) "v_pk_fma_f32 %[a01], " v ", " CG_L##n ", %[a01] op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %[a23], " v ", " CG_H##n ", %[a23] op_sel_hi:[0,1,1]\n\t"
+#define CG_FH(n, v) "v_pk_fma_f32 %[a01], " v ", " CG_L##n ", %[a01] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %[a23], " v ", " CG_H##n ", %[a23] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+// EXEC = all lanes if the scalar n is greater than the constant slot number, else none
+#ifndef CG_UNIFORM12
+#define CG_UNIFORM12 0             // 1: entries 8..11 of every group are gathered (zero padded) and requested: no masks, no branches
+#endif
+#if CG_UNIFORM12
+#define CG_MASK(n) ""
+#define CG_UNMASK ""
+#else
+#define CG_MASK(n) "s_cmp_gt_u32 " n ", %[slot]\n\ts_cselect_b64 exec, -1, 0\n\t"
+#define CG_UNMASK "s_mov_b64 exec, -1\n\t"
+#endif
+#define CG_GATHER_CLOBBERS                                                                                                 \
+    "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238",   \
+        "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252",       \
+        "v253", "v254", "v255", "scc"
+
+// Sum over the first 12 entries of the row of every lane: ids / values of quads 0 and 1 (c0..c3, v0, v1), entries 8..9
+// (values v2xy, ids c4) for slots below nA, entries 10..11 (values v3xy, ids c5) for slots below nB.
+template <int SLOT>
+__device__ __forceinline__ float4 gather12(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned c4, unsigned c5, f32x2 v0xy,
+                                           f32x2 v0zw, f32x2 v1xy, f32x2 v1zw, f32x2 v2xy, f32x2 v3xy, int nA, int nB) {
+    f32x2 a01, a23;
+    asm volatile(
+        CG_RDLO(0, "%[c0]") CG_RDHI(1, "%[c0]") CG_RDLO(2, "%[c1]") CG_RDHI(3, "%[c1]") CG_RDLO(4, "%[c2]") CG_RDHI(5, "%[c2]")
+            CG_RDLO(6, "%[c3]") CG_RDHI(7, "%[c3]")
+        CG_W(7) CG_F0(0, "%[v0xy]") CG_W(6) CG_FH(1, "%[v0xy]") CG_W(5) CG_FL(2, "%[v0zw]") CG_W(4) CG_FH(3, "%[v0zw]")
+#if !(CG_X & 8192)
+        CG_MASK("%[nA]") CG_RDLO(0, "%[c4]") CG_RDHI(1, "%[c4]") CG_MASK("%[nB]") CG_RDLO(2, "%[c5]") CG_RDHI(3, "%[c5]") CG_UNMASK
+#endif
+        // (reads issued with EXEC = 0 may or may not be counted: 3 = the reads certainly behind slot 4, and so on)
+        CG_W(3) CG_FL(4, "%[v1xy]") CG_W(2) CG_FH(5, "%[v1xy]") CG_W(1) CG_FL(6, "%[v1zw]") CG_W(0) CG_FH(7, "%[v1zw]")
+#if !(CG_X & 8192)
+        CG_MASK("%[nA]") CG_FL(0, "%[v2xy]") CG_FH(1, "%[v2xy]") CG_MASK("%[nB]") CG_FL(2, "%[v3xy]") CG_FH(3, "%[v3xy]") CG_UNMASK
+#endif
+        : [a01] "=&v"(a01), [a23] "=&v"(a23)
+        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [v0xy] "v"(v0xy), [v0zw] "v"(v0zw),
+          [v1xy] "v"(v1xy), [v1zw] "v"(v1zw), [v2xy] "v"(v2xy), [v3xy] "v"(v3xy), [nA] "s"(nA), [nB] "s"(nB), [slot] "i"(SLOT)
+        : CG_GATHER_CLOBBERS);
+    return make_float4(a01.x, a01.y, a23.x, a23.y);
+}
+
+// compile-time loop: f(std::integral_constant<int, J>) for J = FIRST .. LAST-1 (the slot number of a row group must be a
+// constant inside the asm statement of its gather)
+template <int FIRST, int LAST, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (FIRST < LAST) {
+        f(std::integral_constant<int, FIRST>{});
+        static_for<FIRST + 1, LAST>(f);
+    }
 }
 
 // ENT = LDS entries (16 B each), NJ = row slices per thread (ceil(groups / 8)), NQ = linear
@@ -114,6 +242,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     __shared__ float4 T[ENT];                        // slot-indexed: the four planes of one vertex
     constexpr int NW4 = NT4 / 64;
     static_assert(NJ <= 64 && NQ <= NJ && (NJ % 2) == 0, "shape");
+    static_assert(NJ * (NT4 / 64) <= 160, "the fixed-stride operator image is padded to 160 row groups (graph.hip)");
     const int copy_t0 = flags & 1;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -156,6 +285,13 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     }
     int2 gtab = make_int2(0, 0);                     // lane j: {quad offset, length} of group j*8 + wave
     if (lane < NJ && lane * NW4 + wave < e.ngroups) gtab = e.ginfo[lane * NW4 + wave];
+    // slots of this wave are sorted by length: the first nB have more than 10 entries, the first nA more than 8; bit j of
+    // mC: slot j has more than 12 (uniform values: SGPRs)
+    const int nA = (CG_X & 32768) ? (int)(flags >> 30) : __popcll(__ballot(lane < NJ && gtab.y > 8));       // (32768: timing experiment)
+    const int nB = (CG_X & 32768) ? (int)(flags >> 30) : __popcll(__ballot(lane < NJ && gtab.y > 10));
+    const unsigned mC = (CG_X & 32768) ? 0u : (unsigned)__ballot(lane < NJ && gtab.y > 12);
+    const __amdgpu_buffer_rsrc_t uval_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.uval, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t uids_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.uids, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t colo_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colo, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valp, 0, 0x7FFFFFFF, 0x00020000);
     if (tid == 0) T[zslot] = zero4;                  // never written again
@@ -451,6 +587,105 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             const bool do_out = !ADJ && step > 1;
             const rsrc_t out_slab = slab_rsrc(dst + (size_t)(step - 1) * slab, slab_bytes);
 
+#if CG_GATHER_ASM
+            // ---- gather: st <- f * (A T_{k-1})[own rows] - st, without control flow (see gather12) ----------
+            // Operator records of slot j (group j*NW4 + wave) sit at compile-time offsets behind one per-wave base; they
+            // travel through a ring two slots deep: values of quads 0 / 1, the record of entries 8..11, the eight ids of
+            // quads 0 and 1.  The two optional requests are skipped by scalar-only tests (j is a constant, nA / nB SGPRs).
+            float4 uq[3][2];
+            float2 ub[2];
+            uint4 uo[2];
+            const unsigned vsoff = (unsigned)wave * 4096u, isoff = (unsigned)wave * 1024u;
+            auto urequest = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr unsigned vo = (unsigned)j * NW4 * 4096u, io = (unsigned)j * NW4 * 1024u;
+                const unsigned vs = opaque_s(vsoff), is = opaque_s(isoff);
+                const f32x4 a = __builtin_amdgcn_raw_buffer_load_b128(uval_rsrc, lane * 16, vs + vo, 0);
+                const f32x4 b = __builtin_amdgcn_raw_buffer_load_b128(uval_rsrc, lane * 16, vs + (vo + 1024u), 0);
+                const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(uids_rsrc, lane * 16, is + io, 0);
+                uq[0][j & 1] = make_float4(a.x, a.y, a.z, a.w);
+                uq[1][j & 1] = make_float4(b.x, b.y, b.z, b.w);
+                uo[j & 1] = make_uint4(c.x, c.y, c.z, c.w);
+                if (CG_UNIFORM12 || (!(CG_X & 16384) && j < opaque_s(nA))) {
+                    const f32x4 d = __builtin_amdgcn_raw_buffer_load_b128(uval_rsrc, lane * 16, vs + (vo + 2048u), 0);
+                    uq[2][j & 1] = make_float4(d.x, d.y, d.z, d.w);
+                }
+                if (CG_UNIFORM12 || (!(CG_X & 16384) && __builtin_expect(j < opaque_s(nB), 0))) {
+                    const f32x2 h = __builtin_amdgcn_raw_buffer_load_b64(uval_rsrc, lane * 16, vs + (vo + 3072u), 0);
+                    ub[j & 1] = make_float2(h.x, h.y);
+                }
+            };
+            auto lds_quad = [&](const uint2 c, const float4 v, float4& acc) {
+                const unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
+                const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3);
+                acc = fma4(v.x, t0, acc);
+                acc = fma4(v.y, t1, acc);
+                acc = fma4(v.z, t2, acc);
+                acc = fma4(v.w, t3, acc);
+            };
+            urequest(std::integral_constant<int, 0>{});
+            if constexpr (NJ > 1) urequest(std::integral_constant<int, 1>{});
+            static_for<0, NJ>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                // waves that are ahead yield to the ones behind (see recurrence.hip)
+                if constexpr (j == 0 || (4 * j) / NJ != (4 * (j - 1)) / NJ) {
+                    constexpr int pr = 3 - (4 * j) / NJ;
+                    if constexpr (pr == 3) __builtin_amdgcn_s_setprio(3);
+                    else if constexpr (pr == 2) __builtin_amdgcn_s_setprio(2);
+                    else if constexpr (pr == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+                const uint4 o01 = uo[j & 1];
+                const float4 v0 = uq[0][j & 1], v1 = uq[1][j & 1], v2 = uq[2][j & 1];
+                const float2 v3 = ub[j & 1];
+                const f32x2 v0xy = {v0.x, v0.y}, v0zw = {v0.z, v0.w}, v1xy = {v1.x, v1.y}, v1zw = {v1.z, v1.w};
+                const f32x2 v2xy = {v2.x, v2.y}, v3xy = {v3.x, v3.y};
+#if CG_GATHER_ASM == 2
+                // the same records gathered by compiler-scheduled C++ (no fixed register block): length classes chosen by
+                // scalar-only tests of the slot number against nA / nB
+                float4 acc = zero4;
+                lds_quad(make_uint2(o01.x, o01.y), v0, acc);
+                lds_quad(make_uint2(o01.z, o01.w), v1, acc);
+                if (j < opaque_s(nA)) {
+                    const unsigned c4 = __float_as_uint(v2.z);
+                    const float4 t0 = lds(ofs_lo(c4)), t1 = lds(ofs_hi(c4));
+                    acc = fma4(v2.x, t0, acc);
+                    acc = fma4(v2.y, t1, acc);
+                    if (j < opaque_s(nB)) {
+                        const unsigned c5 = __float_as_uint(v2.w);
+                        const float4 t2 = lds(ofs_lo(c5)), t3 = lds(ofs_hi(c5));
+                        acc = fma4(v3.x, t2, acc);
+                        acc = fma4(v3.y, t3, acc);
+                    }
+                }
+                (void)v0xy; (void)v0zw; (void)v1xy; (void)v1zw; (void)v2xy; (void)v3xy;
+#else
+                float4 acc = gather12<j>(o01.x, o01.y, o01.z, o01.w, __float_as_uint(v2.z), __float_as_uint(v2.w), v0xy, v0zw, v1xy,
+                                         v1zw, v2xy, v3xy, nA, nB);
+#endif
+                if constexpr (j + 2 < NJ) urequest(std::integral_constant<int, j + 2>{});      // refill the ring slots just consumed
+                st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
+                                    fmaf(f, acc.w, -st[j].w));
+            });
+            // Rows beyond 12 entries (rare; rows are sorted, so they sit in the first slots of a wave): the sum over their
+            // further quads, from the variable-stride image the round-2 way, is added afterwards -- st = f * (sum) - st_old
+            // is linear in the sum.  One test per step when there are none.
+            if (opaque_s(mC) != 0u) {
+                static_for<0, NJ>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if ((opaque_s(mC) >> j) & 1u) {
+                        const int qoff = __builtin_amdgcn_readlane(gtab.x, j), len = __builtin_amdgcn_readlane(gtab.y, j);
+                        float4 acc = zero4;
+                        for (int q = 3; 4 * q < len; ++q) {
+                            const uint4 o = e.colo[(size_t)((qoff >> 1) + (q >> 1)) * 64 + lane];
+                            const float4 v = e.valq[(size_t)(qoff + q) * 64 + lane];
+                            lds_quad((q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y), v, acc);
+                        }
+                        st[j] = make_float4(fmaf(f, acc.x, st[j].x), fmaf(f, acc.y, st[j].y), fmaf(f, acc.z, st[j].z), fmaf(f, acc.w, st[j].w));
+                    }
+                });
+            }
+#else
             // ---- gather: st <- f * (A T_{k-1})[own rows] - st -----------------------------------
             // Operator entries travel through a ring of RING quads (4 entries of each of the 64 rows):
             // every group stores QMAX zero-padded quads, quad n = QMAX*j + q lives in ring slot
@@ -542,6 +777,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
                                     fmaf(f, acc.w, -st[j].w));
             }
+#endif
             CG_STAMP(24 + step);
             // forward: slab step-1 (the image the gather just read) goes out now, before the barrier --
             // waves that finish their rows early stream while the others still gather; kept out of the

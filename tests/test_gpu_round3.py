@@ -120,7 +120,6 @@ def test_captured_step_with_dropout_trains(ops, dev):
     lb = torch.as_tensor(np.arange(z['x'].shape[0]) % int(z['M'][-1])).to(dev)
     before = net._flat.clone()
     torch.manual_seed(0)
-    logits = []
     for _ in range(6):
         net.train_step(x, lb)
     # two replays of the forward alone on the same variables differ only through the dropout masks
@@ -156,10 +155,24 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
     logits, cache = onet.forward(params, x)
     loss, dlogits = onet.loss(params, logits, labels)
     grads = onet.backward(params, cache, dlogits)
+    # the same network in float64: six K = 10 layers deep, two fp32 evaluations of a gradient differ by ~1e-4 of its
+    # scale (summation order; a ReLU within round-off of zero falls on either side and moves a per-vertex bias
+    # gradient by a whole term) -- so gradients are compared with the float64 result.  A weight gradient is a plain fp32
+    # sum over batch x vertices = 128 x M ~ 1e5 products of either sign: sqrt(n) * 2^-24 * (sum |terms| / |sum|) ~ 1e-4
+    # of the gradient's scale is what fp32 accumulation gives (measured: 5e-5 at the 99.9 % quantile for N = 1000; NumPy's
+    # blocked BLAS sums reach 7e-6 there; the last layer's weights, whose terms cancel most, 2e-4 on the GPU and 1.6e-4 in a
+    # NumPy fp32 run with other variables); bound 5e-4, or three times the fp32 oracle's own error where that is larger
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    onet64 = R.Net([L.astype(np.float64)] * 6, F, K, p, Mfc, channel=C, brelu='b2relu', regularization=reg)
+    logits64, cache64 = onet64.forward(p64, x.astype(np.float64))
+    loss64, dlogits64 = onet64.loss(p64, logits64, labels)
+    grads64 = onet64.backward(p64, cache64, dlogits64)
+    assert logits64.dtype == np.float64
     xs = ops.plane_storage(torch.as_tensor(x).to(dev)).contiguous()
     with torch.no_grad():
         got = net._inference_storage(xs, 1).cpu().numpy()
     assert np.abs(got - logits).max() <= 2e-5 * np.abs(logits).max()
+    assert np.abs(got - logits64).max() <= 1e-5 * np.abs(logits64).max()       # the north star's 1e-5, against float64
     ld = torch.as_tensor(labels).to(dev)
     _, loss_avg = net.train_step(xs, ld)
     assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
@@ -168,9 +181,15 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
         g = net._params[k].grad
         if spec.group == 'convb':
             g = g[:, :spec.ref_shape[1]].t().unsqueeze(0)
-        ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
-        err = np.abs(g.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
-        assert err <= 5e-5, 'grad %s: %.3e' % (k, err)
+        l2 = reg * p64[k] if onet.regularized(k) else 0
+        ref64 = grads64[k] - l2
+        scale = max(np.abs(ref64).max(), 1e-30)
+        e_gpu = np.abs(g.cpu().numpy().astype(np.float64) - ref64) / scale
+        e_o32 = np.abs(grads[k].astype(np.float64) - l2 - ref64) / scale
+        q_gpu, q_o32 = np.quantile(e_gpu, 0.999), np.quantile(e_o32, 0.999)
+        assert q_gpu <= max(5e-4, 3 * q_o32), 'grad %s: 99.9 %% quantile %.3e (fp32 oracle %.3e)' % (k, q_gpu, q_o32)
+        if spec.group != 'convb':          # a weight gradient sums over every vertex and window: single flips average out
+            assert e_gpu.max() <= max(2e-3, 3 * e_o32.max()), 'grad %s: max %.3e (fp32 oracle %.3e)' % (k, e_gpu.max(), e_o32.max())
     state, ill = {}, {}
     R.adam_tf_step(params, grads, state)
     for k in params:
