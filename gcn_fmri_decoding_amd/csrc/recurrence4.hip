@@ -38,6 +38,9 @@ extern int g_stagger;
 #ifndef CG_X
 #define CG_X 0               // 64: in-kernel phase stamps (tools/vbuild.sh, tools/kbench.py --stamps); 0 in production
 #endif
+#ifndef CG_INTERLEAVE_OUT
+#define CG_INTERLEAVE_OUT 0  // 1 (experiment, measured equal): forward copy-out pieces between the row groups of the gather instead of a burst behind it
+#endif
 #ifndef CG_GATHER_ASM
 // 2 (shipped): C++ gather on the fixed-stride operator image (compile-time record offsets, length classes by scalar tests);
 // 1: the same records gathered by one asm statement per row group with EXEC-masked optional entries (gather12; measured
@@ -402,13 +405,18 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             // patch registers overlay the row state, which died with the last rotate.
             constexpr int NB = (NQ + 1) / 2;
             float4 px[NB][4];
+            const int grp = pg;                          // (for the stamps)
             if (K > 2) load_patch(px, pg, 0, NB);
             if (have_next) load_planes(src, ng); else clear_planes();
+            CG_STAMP(42);
             copy_out(rs_out, pg, 0, NQ);
+            CG_STAMP(43);
             if (K > 2) {
                 fix_isolated(px, pg, 0, NB);
+                CG_STAMP(44);
                 load_patch(px, pg, NB, NQ);
                 fix_isolated(px, pg, NB, NQ);
+                CG_STAMP(45);
             }
         }
         if (have_prev && ADJ) {
@@ -640,7 +648,39 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 const float2 v3 = ub[j & 1];
                 const f32x2 v0xy = {v0.x, v0.y}, v0zw = {v0.z, v0.w}, v1xy = {v1.x, v1.y}, v1zw = {v1.z, v1.w};
                 const f32x2 v2xy = {v2.x, v2.y}, v3xy = {v3.x, v3.y};
-#if CG_GATHER_ASM == 2
+#if CG_GATHER_ASM == 3
+                // C++ gather with every LDS read of the group issued before the first multiply-add: the scheduling barrier
+                // keeps hipcc from sinking the second quad's reads behind the first quad's arithmetic (it does, to save
+                // registers: four reads in flight per wave instead of eight)
+                float4 acc = zero4;
+                {
+                    const unsigned a0 = ofs_lo(o01.x), a1 = ofs_hi(o01.x), a2 = ofs_lo(o01.y), a3 = ofs_hi(o01.y);
+                    const unsigned a4 = ofs_lo(o01.z), a5 = ofs_hi(o01.z), a6 = ofs_lo(o01.w), a7 = ofs_hi(o01.w);
+                    const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3), t4 = lds(a4), t5 = lds(a5), t6 = lds(a6), t7 = lds(a7);
+                    if (j < opaque_s(nA)) {
+                        const unsigned c4 = __float_as_uint(v2.z);
+                        const float4 t8 = lds(ofs_lo(c4)), t9 = lds(ofs_hi(c4));
+                        if (j < opaque_s(nB)) {
+                            const unsigned c5 = __float_as_uint(v2.w);
+                            const float4 t10 = lds(ofs_lo(c5)), t11 = lds(ofs_hi(c5));
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc = fma4(v0.x, t0, acc); acc = fma4(v0.y, t1, acc); acc = fma4(v0.z, t2, acc); acc = fma4(v0.w, t3, acc);
+                            acc = fma4(v1.x, t4, acc); acc = fma4(v1.y, t5, acc); acc = fma4(v1.z, t6, acc); acc = fma4(v1.w, t7, acc);
+                            acc = fma4(v2.x, t8, acc); acc = fma4(v2.y, t9, acc); acc = fma4(v3.x, t10, acc); acc = fma4(v3.y, t11, acc);
+                        } else {
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc = fma4(v0.x, t0, acc); acc = fma4(v0.y, t1, acc); acc = fma4(v0.z, t2, acc); acc = fma4(v0.w, t3, acc);
+                            acc = fma4(v1.x, t4, acc); acc = fma4(v1.y, t5, acc); acc = fma4(v1.z, t6, acc); acc = fma4(v1.w, t7, acc);
+                            acc = fma4(v2.x, t8, acc); acc = fma4(v2.y, t9, acc);
+                        }
+                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc = fma4(v0.x, t0, acc); acc = fma4(v0.y, t1, acc); acc = fma4(v0.z, t2, acc); acc = fma4(v0.w, t3, acc);
+                        acc = fma4(v1.x, t4, acc); acc = fma4(v1.y, t5, acc); acc = fma4(v1.z, t6, acc); acc = fma4(v1.w, t7, acc);
+                    }
+                }
+                (void)v0xy; (void)v0zw; (void)v1xy; (void)v1zw; (void)v2xy; (void)v3xy;
+#elif CG_GATHER_ASM == 2
                 // the same records gathered by compiler-scheduled C++ (no fixed register block): length classes chosen by
                 // scalar-only tests of the slot number against nA / nB
                 float4 acc = zero4;
@@ -666,6 +706,18 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 if constexpr (j + 2 < NJ) urequest(std::integral_constant<int, j + 2>{});      // refill the ring slots just consumed
                 st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
                                     fmaf(f, acc.w, -st[j].w));
+#if CG_INTERLEAVE_OUT
+                // forward: the slab the gather reads (step - 1) goes out piece by piece BETWEEN the row groups instead of in
+                // one burst behind them: a burst of 168 KB of stores drains at the CU's share of HBM bandwidth (~12 B/clk)
+                // and everything queued behind it in the CU's in-order memory pipeline -- the operator requests of the next
+                // gather, the loads of the turn-over -- waits for that (measured: 16-20k cycles to ISSUE the turn-over's
+                // loads, the first gather of a group 7k slower than the others)
+                if constexpr (!ADJ) {
+                    constexpr int u = (2 * NQ * j + NQ) / (2 * NJ);              // piece whose turn comes at this slot
+                    if constexpr (u < NQ && ((2 * u + 1) * NJ) / (2 * NQ) == j)
+                        if (do_out) copy_out(out_slab, grp, u, u + 1);
+                }
+#endif
             });
             // Rows beyond 12 entries (rare; rows are sorted, so they sit in the first slots of a wave): the sum over their
             // further quads, from the variable-stride image the round-2 way, is added afterwards -- st = f * (sum) - st_old
@@ -782,7 +834,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             // forward: slab step-1 (the image the gather just read) goes out now, before the barrier --
             // waves that finish their rows early stream while the others still gather; kept out of the
             // gather loop: its 40-odd temporaries do not fit next to the row state and the operator ring
-            if (do_out) copy_out(out_slab, grp, 0, NQ);
+            if (do_out && !(CG_GATHER_ASM && CG_INTERLEAVE_OUT)) copy_out(out_slab, grp, 0, NQ);
         }
         finish_step(K - 1, true);
         // ---- the final image goes out, the next group's input comes in -------------------------

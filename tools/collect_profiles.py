@@ -12,14 +12,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'refresh')
 DST = os.path.join(ROOT, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 
 for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats.csv', '%s_bench_kernel_stats.csv'),
                  ('kbench.txt', '%s_kbench.txt'), ('kbench.json', '%s_kbench.json'),
                  ('kbench_config4.txt', '%s_kbench_config4_K25_F64.txt'), ('kbench_config5.txt', '%s_kbench_config5_bf16.txt'),
                  ('traffic_raw.json', '%s_traffic_raw.json'), ('kbench_two_planes.txt', '%s_kbench_two_plane_recurrence.txt'),
                  ('mfma.txt', '%s_contraction_mfma_counters.txt'), ('stamps4.txt', '%s_recurrence4_phase_stamps.txt'), ('mfma_counters_available.txt', '%s_mfma_counters_available.txt'),
-                 ('config4_kernel_stats.csv', '%s_config4_kernel_stats.csv'), ('config5_kernel_stats.csv', '%s_config5_kernel_stats.csv')]:
+                 ('config4_kernel_stats.csv', '%s_config4_kernel_stats.csv'), ('config5_kernel_stats.csv', '%s_config5_kernel_stats.csv'),
+                 ('northstar_kernel_stats.csv', '%s_northstar_kernel_stats.csv'), ('refshape_n360_kernel_stats.csv', '%s_refshape_n360_kernel_stats.csv'),
+                 ('refshape_n360_line.json', '%s_refshape_n360_line.json')]:
     p = os.path.join(SRC, src)
     if os.path.exists(p):
         if src.endswith('.txt') or src == 'bench_line.json':

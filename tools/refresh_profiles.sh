@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): refreshes everything profiles/ holds for the current kernels.
-#   bench line, rocprofv3 --kernel-trace --stats of the same bench command, per-kernel micro-bench at the
+#   bench line, rocprofv3 --kernel-trace --stats of the same bench command (and of the north-star launches and the
+#   reference's own training shape), per-kernel micro-bench at the
 #   bench / north-star shapes and at BASELINE configs 4 and 5 (with their own rocprofv3 kernel stats), PMC
 #   traffic per kernel, matrix-core counters of the contraction kernels.
 out=$GRAFT_REPO_ROOT/gpurun_out/refresh
@@ -22,5 +23,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4 -o c4 -- pyth
 find $out/prof4 -name "*kernel_stats.csv" -exec cp {} $out/config4_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -o c5 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 5 --kernels recurrence_fwd_inplace contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 > $out/prof5.log 2>&1
 find $out/prof5 -name "*kernel_stats.csv" -exec cp {} $out/config5_kernel_stats.csv \;
-rm -rf $out/prof $out/prof4 $out/prof5
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/profn -o ns -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 256 --iters 50 --kernels recurrence_fwd_inplace recurrence_fwd recurrence_bwd > $out/profn.log 2>&1
+find $out/profn -name "*kernel_stats.csv" -exec cp {} $out/northstar_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/profr -o rs -- python3 $GRAFT_REPO_ROOT/tools/refshape.py --nodes 360 > $out/profr.log 2>&1
+find $out/profr -name "*kernel_stats.csv" -exec cp {} $out/refshape_n360_kernel_stats.csv \;
+tail -1 $out/profr.log > $out/refshape_n360_line.json
+rm -rf $out/prof $out/prof4 $out/prof5 $out/profn $out/profr
 ls -la $out
