@@ -43,6 +43,8 @@ struct Ell {
     int64_t nslots = 0;           // sum of (even) group lengths
     int64_t nquads = 0;
     int64_t cost_before = 0, cost_after = 0, cost_ideal = 0;   // bank-conflict statistics of build_ell (graph_query 9, 10)
+    int iso_max512 = 0;           // P = 4: most isolated vertices (inside the graph, no slot) among the linear pieces of one thread
+                                  // of a 512-thread workgroup (piece q belongs to thread q % 512); recurrence4.hip keeps up to 4 in registers
     int2* ginfo = nullptr;        // [ngroups] {quad offset, even length}
     uint2* colq = nullptr;        // [(nquads + kQuadPad)*64]
     uint4* colo = nullptr;        // [(nquads + kQuadPad)/2*64]  the same ids, quads 2o and 2o+1 in one record

@@ -247,6 +247,10 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     }
     if ((rc = upload(&out->valp, valp))) return rc;
     if (planes == 4) {
+        std::vector<int> per_thread(512, 0);
+        for (int v = 0; v < M; ++v)
+            if (nodeslot[v] == 0xFFFF) per_thread[(v / 4) % 512]++;
+        out->iso_max512 = *std::max_element(per_thread.begin(), per_thread.end());
         // fixed-stride image of entries 0..11 (common.h): every group has at least four stored quads
         // a kernel shape requests the records of every slot of every wave (up to 20 slots x 8 waves), also those beyond
         // the last group: padded with empty groups (values 0, ids = the zero slot)

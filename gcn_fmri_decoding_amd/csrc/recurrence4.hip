@@ -38,6 +38,9 @@ extern int g_stagger;
 #ifndef CG_X
 #define CG_X 0               // 64: in-kernel phase stamps (tools/vbuild.sh, tools/kbench.py --stamps); 0 in production
 #endif
+#ifndef CG_SLOT_PREFETCH
+#define CG_SLOT_PREFETCH 0   // 1 (experiment, measured slower): the piece slot ids of ISOREG kernels re-fetched three groups before the end of a gather instead of at the start of a copy-out
+#endif
 #ifndef CG_INTERLEAVE_OUT
 #define CG_INTERLEAVE_OUT 0  // 1 (experiment, measured equal): forward copy-out pieces between the row groups of the gather instead of a burst behind it
 #endif
@@ -238,7 +241,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ENT = LDS entries (16 B each), NJ = row slices per thread (ceil(groups / 8)), NQ = linear
 // 16-byte pieces per thread and plane (ceil(Mp/4 / 512)).
-template <int ENT, int NJ, int NQ, int NT4, bool ADJ>
+// ISOREG: every thread holds at most NISO isolated vertices among its linear pieces (graph.hip checks): their values ride
+// in registers for the whole plane group instead of being re-read from HBM when slabs go out (see `xi` below).
+constexpr int NISO = 4;
+template <int ENT, int NJ, int NQ, int NT4, bool ADJ, bool ISOREG>
 __global__ void __launch_bounds__(NT4)
 cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, int M, int Mp, int nplanes, int K,
              size_t slab, int flags) {
@@ -286,6 +292,21 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
         for (int i = 0; i < 4; ++i)
             if (((w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu) == 0xFFFFu && 4 * q + i < M) isomask |= 1u << (4 * u + i);
     }
+    // ISOREG (forward) -- isolated vertices in registers.  T_k of an isolated vertex is 0 for odd k and (-1)^(k/2) x for even
+    // k; x is in this thread's staging registers when the group's input is staged, so the (at most NISO) values are kept
+    // (xi[n][plane], n = rank of the vertex among the thread's isolated ones) and every even slab goes out with sign * x
+    // selected into place -- no re-read of x, no 4-byte patch stores, no second round trip when the group is turned over
+    // (round 2 re-read x there: 10-13k of the turn-over's 35k cycles were one exposed memory latency, plus ~190 mostly-empty
+    // store instructions per wave; the first gather of a group ran 7k cycles behind that traffic).  Measured at the north-star
+    // shape: 0.555 against 0.580 ms in place, 0.54 against 0.59 ms with the copy of x; K = 25: 1.47 against 1.60 ms.
+    // Tried and rejected: fetching x (adjoint: the even G_j) at the isolated vertices with 4-byte loads beside the plane
+    // loads and storing sign * x behind the copy-out with 4-byte stores (no selects: 0.585 ms forward, 0.64 adjoint); the
+    // register scheme for the adjoint (accumulating the isolated components of every even G_j: 0.597 against 0.578 ms).
+    float xi[ISOREG ? NISO : 1][4];
+#pragma unroll
+    for (int n = 0; n < (ISOREG ? NISO : 1); ++n)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) xi[n][p] = 0.f;
     int2 gtab = make_int2(0, 0);                     // lane j: {quad offset, length} of group j*8 + wave
     if (lane < NJ && lane * NW4 + wave < e.ngroups) gtab = e.ginfo[lane * NW4 + wave];
     // slots of this wave are sorted by length: the first nB have more than 10 entries, the first nA more than 8; bit j of
@@ -310,7 +331,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     // plane offsets of a group (uniform); planes beyond nplanes alias the last one and are never stored
     const unsigned slab_bytes = (unsigned)(slab * sizeof(float));     // < 4 GB (checked by the dispatcher)
     const unsigned vb = (unsigned)tid * 16u;                            // this thread's byte offset inside a run of 512 pieces
-    auto plane_off = [&](int g, int p, int u) -> unsigned {             // uniform: plane p of group g, piece run u
+    auto plane_off = [&](int g, int p, int u) __attribute__((always_inline)) -> unsigned {             // uniform: plane p of group g, piece run u
         const int i = g * 4 + p;
         return (unsigned)(i < nplanes ? i : nplanes - 1) * (unsigned)Mp * 4u + (unsigned)u * (NT4 * 16u);
     };
@@ -325,7 +346,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     // linear staging registers: the next group's input, G_j of the adjoint.  Live only while the
     // operator ring and (between groups) the row state are idle.
     float4 gx[NQ][4];
-    auto load_planes = [&](const float* base, int g, int u0 = 0, int u1 = NQ) {
+    auto load_planes = [&](const float* base, int g, int u0 = 0, int u1 = NQ) __attribute__((always_inline)) {
         const rsrc_t rs = slab_rsrc(base, slab_bytes);
 #pragma unroll
         for (int u = u0; u < u1; ++u) {
@@ -338,7 +359,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             }
         }
     };
-    auto clear_planes = [&]() {
+    auto clear_planes = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < NQ; ++u)
 #pragma unroll
@@ -378,7 +399,23 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     };
     // One slab of the forward stack from the LDS image, pieces [u0, u1): t[i] = LDS entry of vertex 4q+i
     // (zero for a vertex without a slot: pads and isolated vertices)
-    auto copy_out = [&](rsrc_t out, int g, int u0, int u1) {
+    // The slot ids of the linear pieces (12 registers) are not kept across a gather in the ISOREG kernels: with the isolated
+    // values in registers hipcc spilled them and reloaded each one with `s_waitcnt vmcnt(0)` in front of its piece -- every
+    // copy-out drained its own stores six times.  They are fetched again (L2, all requests together) when a linear phase
+    // starts; the opaque thread id keeps the loads from being hoisted back out of the step loop.
+    auto reload_piece_slots = [&]() __attribute__((always_inline)) {
+        const int t = (int)opaque((unsigned)tid);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int q = t + u * NT4;
+            nsreg[u] = (q < Mq) ? reinterpret_cast<const uint2*>(e.nodeslot)[q] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+    };
+    // One slab of the forward stack (or dx) from the LDS image, pieces [u0, u1): t[i] = LDS entry of vertex 4q+i (zero for
+    // a vertex without a slot: pads and isolated vertices).  ISOREG: iso_sign = what an isolated vertex holds in this slab
+    // relative to x (0 in odd slabs -- what the zero slot gave anyway --, -1 / +1 in even ones).
+    auto copy_out = [&](rsrc_t out, int g, int u0, int u1, float iso_sign = 0.f) __attribute__((always_inline)) {
+        if (ISOREG && !CG_SLOT_PREFETCH && u0 == 0) reload_piece_slots();
 #pragma unroll
         for (int u = u0; u < u1; ++u) {
             const int q = tid + u * NT4;
@@ -388,16 +425,62 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 float4 t[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) t[i] = T[id[i] == 0xFFFFu ? zslot : id[i]];
+                bool is[4] = {false, false, false, false};
+                int rk[4] = {0, 0, 0, 0};
+                const bool do_iso = ISOREG && iso_sign != 0.f;      // uniform
+                if (do_iso) {
+                    const unsigned im = opaque(isomask);            // (opaque: see iso_take)
 #pragma unroll
-                for (int p = 0; p < 4; ++p) stp(out, vb, plane_off(g, p, u), plane_of_entries(t, p));
+                    for (int i = 0; i < 4; ++i) {
+                        is[i] = (im >> (4 * u + i)) & 1u;
+                        rk[i] = __popc(im & ((1u << (4 * u + i)) - 1u));       // rank among this thread's isolated vertices
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float4 o = plane_of_entries(t, p);
+                    if (do_iso) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = xi[0][p];
+#pragma unroll
+                            for (int n = 1; n < (ISOREG ? NISO : 1); ++n) v[i] = (rk[i] == n) ? xi[n][p] : v[i];
+                            v[i] *= iso_sign;
+                        }
+                        o = make_float4(is[0] ? v[0] : o.x, is[1] ? v[1] : o.y, is[2] ? v[2] : o.z, is[3] ? v[3] : o.w);
+                    }
+                    stp(out, vb, plane_off(g, p, u), o);
+                }
             }
+            if (ISOREG) __builtin_amdgcn_sched_barrier(0);      // one piece at a time: interleaved, their selects spill
         }
     };
+    // xi = the isolated components of the staging registers gx (straight-line selects: a branch per vertex made hipcc spill
+    // hundreds of registers; the mask goes through an opaque identity: ranks and comparisons derived from it are loop
+    // invariant, and hipcc would otherwise keep them in SGPR pairs across the whole kernel)
+    auto iso_take = [&]() __attribute__((always_inline)) {
+        const unsigned im = opaque(isomask);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool is = (im >> (4 * u + i)) & 1u;
+                const int r = __popc(im & ((1u << (4 * u + i)) - 1u));
+#pragma unroll
+                for (int n = 0; n < NISO; ++n) {
+                    const bool hit = is && r == n;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) xi[ISOREG ? n : 0][p] = hit ? comp(gx[u][p], i) : xi[ISOREG ? n : 0][p];
+                }
+            }
+    };
+    auto slab_iso_sign = [&](int k) -> float { return (k & 1) ? 0.f : ((k & 2) ? -1.f : 1.f); };
 
     // The pass between two groups: the final image of group `pg` (forward: slab K-1; adjoint: dx)
     // goes out and the input of group `ng` (already in gx) takes its place.  Every linear piece is read
     // and then overwritten by the thread that owns it in every linear phase: no barrier in between.
-    auto turn_over = [&](bool have_prev, int pg, bool have_next, int ng) {
+    auto turn_over = [&](bool have_prev, int pg, bool have_next, int ng) __attribute__((always_inline)) {
         const rsrc_t rs_out = slab_rsrc(ADJ ? dst : dst + (size_t)(K - 1) * slab, slab_bytes);   // dx / slab K-1
         if (have_prev && !ADJ) {
             // Requests, in the order their data is needed (the vector memory pipeline returns in order): x
@@ -406,12 +489,12 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             constexpr int NB = (NQ + 1) / 2;
             float4 px[NB][4];
             const int grp = pg;                          // (for the stamps)
-            if (K > 2) load_patch(px, pg, 0, NB);
+            if (!ISOREG && K > 2) load_patch(px, pg, 0, NB);
             if (have_next) load_planes(src, ng); else clear_planes();
             CG_STAMP(42);
-            copy_out(rs_out, pg, 0, NQ);
+            copy_out(rs_out, pg, 0, NQ, slab_iso_sign(K - 1));
             CG_STAMP(43);
-            if (K > 2) {
+            if (!ISOREG && K > 2) {
                 fix_isolated(px, pg, 0, NB);
                 CG_STAMP(44);
                 load_patch(px, pg, NB, NQ);
@@ -507,6 +590,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                     }
                 }
             }
+            if (ISOREG) iso_take();                  // x of this thread's isolated vertices, for the even slabs of the group
+            // isolated vertices: forward x itself; adjoint the first term G_{K-1} of dx = G_0 - G_2 + ... (0 if K-1 is odd)
+
         }
     };
 
@@ -527,7 +613,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
         // <- T_{k-1} of the own rows (adjoint: then c_j += G_j).  Runs at the top of the next step and,
         // for the last step (where the next group's input is requested), after the loop -- kept out of
         // the loop so that the staging registers are not live across a gather.
-        auto finish_step = [&](int sdone, bool last) {
+        auto finish_step = [&](int sdone, bool last) __attribute__((always_inline)) {
             CG_STAMP(4 * sdone + 0);
             __syncthreads();                         // every gather (and copy-out read) of this step is done
             CG_STAMP(4 * sdone + 1);
@@ -604,7 +690,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             float2 ub[2];
             uint4 uo[2];
             const unsigned vsoff = (unsigned)wave * 4096u, isoff = (unsigned)wave * 1024u;
-            auto urequest = [&](auto jc) {
+            auto urequest = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 constexpr unsigned vo = (unsigned)j * NW4 * 4096u, io = (unsigned)j * NW4 * 1024u;
                 const unsigned vs = opaque_s(vsoff), is = opaque_s(isoff);
@@ -623,7 +709,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                     ub[j & 1] = make_float2(h.x, h.y);
                 }
             };
-            auto lds_quad = [&](const uint2 c, const float4 v, float4& acc) {
+            auto lds_quad = [&](const uint2 c, const float4 v, float4& acc) __attribute__((always_inline)) {
                 const unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
                 const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3);
                 acc = fma4(v.x, t0, acc);
@@ -704,6 +790,8 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                                          v1zw, v2xy, v3xy, nA, nB);
 #endif
                 if constexpr (j + 2 < NJ) urequest(std::integral_constant<int, j + 2>{});      // refill the ring slots just consumed
+                // (ISOREG) the slot ids of the linear pieces for the phases behind this gather, requested three groups early
+                if constexpr (ISOREG && CG_SLOT_PREFETCH && j == (NJ > 3 ? NJ - 3 : 0)) reload_piece_slots();
                 st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
                                     fmaf(f, acc.w, -st[j].w));
 #if CG_INTERLEAVE_OUT
@@ -715,7 +803,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 if constexpr (!ADJ) {
                     constexpr int u = (2 * NQ * j + NQ) / (2 * NJ);              // piece whose turn comes at this slot
                     if constexpr (u < NQ && ((2 * u + 1) * NJ) / (2 * NQ) == j)
-                        if (do_out) copy_out(out_slab, grp, u, u + 1);
+                        if (do_out) copy_out(out_slab, grp, u, u + 1, slab_iso_sign(step - 1));
                 }
 #endif
             });
@@ -834,7 +922,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             // forward: slab step-1 (the image the gather just read) goes out now, before the barrier --
             // waves that finish their rows early stream while the others still gather; kept out of the
             // gather loop: its 40-odd temporaries do not fit next to the row state and the operator ring
-            if (do_out && !(CG_GATHER_ASM && CG_INTERLEAVE_OUT)) copy_out(out_slab, grp, 0, NQ);
+            if (do_out && !(CG_GATHER_ASM && CG_INTERLEAVE_OUT)) copy_out(out_slab, grp, 0, NQ, slab_iso_sign(step - 1));
         }
         finish_step(K - 1, true);
         // ---- the final image goes out, the next group's input comes in -------------------------
@@ -847,12 +935,22 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
 template <int ENT, int NJ, int NQ, int NT4, bool ADJ>
 int launch4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
             hipStream_t stream) {
+    static_assert(NT4 == 512, "Ell::iso_max512 counts isolated vertices per thread of a 512-thread workgroup");
     const int ngrp = (nplanes + 3) / 4;
     int grid = g->num_cus * ((160 * 1024) / (ENT * 16) < 1 ? 1 : (160 * 1024) / (ENT * 16));
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
-    hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, NT4, ADJ>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M, g->Mp,
-                       nplanes, K, slab, copy_t0 | (g_stagger << 20));
+    bool launched = false;
+    if constexpr (!ADJ) {                            // (the adjoint keeps the round-2 scheme: see `xi` in the kernel)
+        if (ell.iso_max512 <= NISO) {
+            hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, NT4, ADJ, true>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M,
+                               g->Mp, nplanes, K, slab, copy_t0 | (g_stagger << 20));
+            launched = true;
+        }
+    }
+    if (!launched)
+        hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, NT4, ADJ, false>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M,
+                           g->Mp, nplanes, K, slab, copy_t0 | (g_stagger << 20));
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -10,6 +10,7 @@ contiguous *storage* tensor ``[N, F, Mp]`` (vertex axis fastest, ``Mp = plane_st
 without copying; ``plane_storage(x)`` goes back (zero-copy when ``x`` is such a view).
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -112,6 +113,8 @@ class Graph:
         (chebgcn_graph_create_planes; a choice of speed, not of results)."""
         self.M = int(L.shape[0])
         self.Mp = plane_stride(self.M)
+        if not planes:
+            planes = int(os.environ.get('CHEBGCN_PLANES', '0'))      # A/B experiments (tools/ab_bench.sh): 2 or 4 for every graph
         indptr, indices, data = _graph.rescaled_laplacian_csr(L)
         self.nnz = int(len(data))
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)

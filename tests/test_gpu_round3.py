@@ -186,8 +186,13 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
         scale = max(np.abs(ref64).max(), 1e-30)
         e_gpu = np.abs(g.cpu().numpy().astype(np.float64) - ref64) / scale
         e_o32 = np.abs(grads[k].astype(np.float64) - l2 - ref64) / scale
-        q_gpu, q_o32 = np.quantile(e_gpu, 0.999), np.quantile(e_o32, 0.999)
-        assert q_gpu <= max(5e-4, 3 * q_o32), 'grad %s: 99.9 %% quantile %.3e (fp32 oracle %.3e)' % (k, q_gpu, q_o32)
+        # per-vertex bias gradients are sums over the 128 windows only: there a ReLU that falls on the other side of zero
+        # (its pre-activation within round-off of 0) moves single elements by a whole term -- 0.1 % of the elements of the
+        # deeper layers in either fp32 evaluation -- so they are compared at the 99 % quantile, weights at 99.9 %
+        qq = 0.99 if spec.group == 'convb' else 0.999
+        q_gpu, q_o32 = np.quantile(e_gpu, qq), np.quantile(e_o32, qq)
+        assert q_gpu <= max(1e-4 if spec.group == 'convb' else 5e-4, 3 * q_o32), \
+            'grad %s: %.1f %% quantile %.3e (fp32 oracle %.3e)' % (k, 100 * qq, q_gpu, q_o32)
         if spec.group != 'convb':          # a weight gradient sums over every vertex and window: single flips average out
             assert e_gpu.max() <= max(2e-3, 3 * e_o32.max()), 'grad %s: max %.3e (fp32 oracle %.3e)' % (k, e_gpu.max(), e_o32.max())
     state, ill = {}, {}
