@@ -112,6 +112,9 @@ struct chebgcn_graph {
     chebgcn::Ell fwd2, adj2;
 };
 
+#ifndef CG_PICK4_GROUPS_PER_CU
+#define CG_PICK4_GROUPS_PER_CU 4     // four planes per workgroup from this many plane groups per CU (pick_ell)
+#endif
 namespace chebgcn {
 // the operator image a launch over `nplanes` planes uses
 inline const Ell& pick_ell(const chebgcn_graph* g, bool adjoint, int nplanes) {
@@ -119,7 +122,7 @@ inline const Ell& pick_ell(const chebgcn_graph* g, bool adjoint, int nplanes) {
     // few groups per CU: the two-plane image keeps more workgroups in flight.  Measured in the configs[1] step
     // (M = 10466, 2048 planes per launch): both directions on two planes 4.235 ms, adjoint on four 4.27, both on
     // four 4.37 -- although the isolated adjoint launch is 5 % faster on four planes (tools/kbench.py)
-    if (g->has_alt2 && e.planes == 4 && (nplanes + 3) / 4 < 4 * g->num_cus) return adjoint ? g->adj2 : g->fwd2;
+    if (g->has_alt2 && e.planes == 4 && (nplanes + 3) / 4 < CG_PICK4_GROUPS_PER_CU * g->num_cus) return adjoint ? g->adj2 : g->fwd2;
     return e;
 }
 }  // namespace chebgcn

@@ -32,7 +32,7 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
 
 raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
 names = {'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd',
-         'cheb4_kernel<10240, 20, 6, 512, false>': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true>': 'recurrence_bwd_4planes',
+         'cheb4_kernel<10240, 20, 6, 512, false,': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true,': 'recurrence_bwd_4planes',
          'contract_fwd_kernel<1>': 'contract_fwd', 'contract_bwd_w_kernel<5, true>': 'contract_bwd_w',
          'contract_bwd_x_kernel<true, true>': 'contract_bwd_x', 'bias_grad_relu_kernel<2>': 'bias_grad',
          'contract_bwd_w_kernel<5, false>': 'contract_bwd_w_unfolded', 'contract_bwd_x_kernel<true, false>': 'contract_bwd_x_unfolded',
