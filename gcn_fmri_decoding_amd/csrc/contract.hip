@@ -130,6 +130,70 @@ contract_fwd_kernel(FwdArgs a) {
     }
 }
 
+// Small launches (atlas-sized graphs: the reference's own 246..1000-node atlases give one to nine 128-vertex tiles per
+// window): one wave per tile leaves most of the chip without work -- at M = 380, batch 128 the kernel above runs 384 waves
+// on 256 CUs, each through the whole reduction (0.049 ms for 68 MB).  Here the four waves of a workgroup share ONE tile and
+// take every fourth pair of reduction rows each; the four partial accumulators are added through LDS in a fixed order (wave
+// 0, 1, 2, 3), and every wave finishes a quarter of the filter rows (bias, ReLU, pooling, store).  Four times the waves,
+// a quarter of the chain per wave.  (The sum is the same products in four chains instead of one: fp32 round-off differs
+// from the big-launch kernel in the last bits, deterministic for a given shape.)
+__global__ void __launch_bounds__(256)
+contract_fwd_splitk_kernel(FwdArgs a) {
+    __shared__ float red[4][64][64];                   // [wave][accumulator register r*16+j][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int m0 = blockIdx.x * 128;
+    const int n0 = m0 + 4 * c;
+    const bool valid = n0 < a.Mp;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+    const float* base = a.stack + (size_t)b * a.Fin * a.Mp + (valid ? n0 : 0);
+    const int npairs = (a.FinK + 1) >> 1;
+    const int fo = c;
+    for (int i0 = wave; i0 < npairs; i0 += 4 * FWD_UNROLL) {
+        float4 bv[FWD_UNROLL];
+        float av[FWD_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FWD_UNROLL; ++u) {
+            const int kk = 2 * (i0 + 4 * u) + h;
+            const bool live = kk < a.FinK;
+            const int kkc = live ? kk : a.FinK - 1;         // dead iterations re-read the last plane against a zero weight
+            const int fc = kkc / a.K, kc = kkc - fc * a.K;
+            const float* p = base + (size_t)kc * a.slab + (size_t)fc * a.Mp;
+            bv[u] = valid ? ld_stream(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+            av[u] = (live && fo < a.Fout) ? a.W[(size_t)kk * a.Fout + fo] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FWD_UNROLL; ++u) {
+            acc[0] = mfma(av[u], bv[u].x, acc[0]);
+            acc[1] = mfma(av[u], bv[u].y, acc[1]);
+            acc[2] = mfma(av[u], bv[u].z, acc[2]);
+            acc[3] = mfma(av[u], bv[u].w, acc[3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[wave][r * 16 + j][lane] = acc[r][j];
+    __syncthreads();
+    // wave w finishes the accumulator registers j = 4w .. 4w+3 (filter rows acc_row(j, h))
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * wave + jj;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            v[r] = ((red[0][r * 16 + j][lane] + red[1][r * 16 + j][lane]) + red[2][r * 16 + j][lane]) + red[3][r * 16 + j][lane];
+        fwd_epilogue_row(a, b, acc_row(j, h), v, n0, valid, c);
+    }
+}
+
 // --------------------------------------------------------------------------------------
 // bwd_x:  D[kk][m] = sum_o W[kk][o] dy[o][m]
 // --------------------------------------------------------------------------------------
@@ -141,14 +205,16 @@ struct BwdXArgs {
 };
 
 // HOLD: dy tile (Fout <= 32 -> 16 float4 per lane) stays in registers across the row tiles.
-template <bool HOLD, bool MASK>
+// SPLIT (small launches, see contract_fwd_splitk_kernel): the four waves of a workgroup share one 128-vertex tile and take
+// every fourth tile of 32 output rows each -- no reduction involved, the dy tile is loaded by each of them.
+template <bool HOLD, bool MASK, bool SPLIT = false>
 __global__ void __launch_bounds__(256, CG_LB_BWX)
 contract_bwd_x_kernel(BwdXArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    const int m0 = (blockIdx.x * 4 + wave) * 128;
+    const int m0 = SPLIT ? blockIdx.x * 128 : (blockIdx.x * 4 + wave) * 128;
     if (m0 >= a.M) return;
     const int n0 = m0 + 4 * c;
     const bool valid = n0 < a.Mp;
@@ -175,7 +241,7 @@ contract_bwd_x_kernel(BwdXArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) hold[j] = gated(hold[j], (valid && 2 * j + h < a.Fout) ? bits[j] : 0);
     }
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = SPLIT ? wave : 0; t < ntiles; t += SPLIT ? 4 : 1) {
         f32x16 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -424,7 +490,7 @@ reduce_partials_stage2(const float* __restrict__ stage, float* __restrict__ dW, 
 }
 
 static int bw_rt(int ntiles) { return ntiles < 5 ? ntiles : 5; }
-static int bw_grid_x(int B, int M) {
+static int num_cus() {
     static int cus = 0;                       // cached: hipGetDeviceProperties is slow
     if (cus == 0) {
         int dev = 0;
@@ -432,6 +498,12 @@ static int bw_grid_x(int B, int M) {
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
                   ? prop.multiProcessorCount : 256;
     }
+    return cus;
+}
+// a launch of one wave per 128-vertex tile that gives the chip fewer than two workgroups per CU: share the tiles
+static bool small_launch(int B, int M) { return ((M + 511) / 512) * B < 2 * num_cus(); }
+static int bw_grid_x(int B, int M) {
+    const int cus = num_cus();
     int total = B * ((M + 63) / 64);
     int gx = cus * 3;                          // 48 KB of LDS per workgroup -> three per CU
     if (gx > total) gx = total;
@@ -471,6 +543,9 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
     if (Fout > 32) {
         dim3 grid(gx, B, (Fout + 63) / 64);
         hipLaunchKernelGGL(contract_fwd_kernel<2>, grid, dim3(256), 0, stream, a);
+    } else if (small_launch(B, M)) {
+        dim3 grid((M + 127) / 128, B, 1);
+        hipLaunchKernelGGL(contract_fwd_splitk_kernel, grid, dim3(256), 0, stream, a);
     } else {
         dim3 grid(gx, B, 1);
         hipLaunchKernelGGL(contract_fwd_kernel<1>, grid, dim3(256), 0, stream, a);
@@ -485,6 +560,18 @@ static int launch_bwd_x(const float* dy, const uint8_t* mask, const float* W, fl
     a.dy = dy; a.W = W; a.gstack = gstack; a.mask = mask;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
     a.slab = (size_t)B * Fin * a.Mp;
+    if (small_launch(B, M)) {
+        dim3 sgrid((M + 127) / 128, B, 1);
+        if (mask) {
+            if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, true, true>), sgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((contract_bwd_x_kernel<false, true, true>), sgrid, dim3(256), 0, stream, a);
+        } else {
+            if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, false, true>), sgrid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((contract_bwd_x_kernel<false, false, true>), sgrid, dim3(256), 0, stream, a);
+        }
+        CG_HIP(hipGetLastError());
+        return CHEBGCN_OK;
+    }
     dim3 grid((M + 511) / 512, B, 1);
     if (mask) {
         if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, true>), grid, dim3(256), 0, stream, a);

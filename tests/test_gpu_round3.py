@@ -198,7 +198,9 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
     state, ill = {}, {}
     R.adam_tf_step(params, grads, state)
     for k in params:
-        assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], 0, ill, k, rel=2e-5)
+        # (lr = 2e-3 in the bound: where a ReLU flipped, the two gradients of a bias element can have opposite signs and the
+        # first Adam update, -lr * sign(g), differs by two learning rates)
+        assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], 0, ill, k, rel=2e-5, lr=2e-3, quantile=0.999)
     # the same model through the captured graph: two more eager steps, capture, replay -- bit-identical to a twin that
     # runs all of them eagerly
     twin = models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he',
