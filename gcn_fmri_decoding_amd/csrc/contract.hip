@@ -506,7 +506,10 @@ static int bw_grid_x(int B, int M) {
     const int cus = num_cus();
     int total = B * ((M + 63) / 64);
     int gx = cus * 3;                          // 48 KB of LDS per workgroup -> three per CU
-    if (gx > total) gx = total;
+    // small launches: at least four chunks per workgroup -- every workgroup leaves a partial of the whole row-tile group
+    // (20 KB at five row tiles) that the reduce kernels read back; one chunk per workgroup made the partials of an
+    // atlas-sized layer (N = 360, batch 128) 31 MB and reduce_partials_stage1 18 us beside a 38 us kernel
+    if (gx > (total + 3) / 4) gx = (total + 3) / 4;
     return gx < 1 ? 1 : gx;
 }
 

@@ -20,7 +20,11 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
                  ('traffic_raw.json', '%s_traffic_raw.json'), ('kbench_two_planes.txt', '%s_kbench_two_plane_recurrence.txt'),
                  ('mfma.txt', '%s_contraction_mfma_counters.txt'), ('stamps4.txt', '%s_recurrence4_phase_stamps.txt'), ('mfma_counters_available.txt', '%s_mfma_counters_available.txt'),
                  ('config4_kernel_stats.csv', '%s_config4_kernel_stats.csv'), ('config5_kernel_stats.csv', '%s_config5_kernel_stats.csv'),
-                 ('northstar_kernel_stats.csv', '%s_northstar_kernel_stats.csv'), ('refshape_n360_kernel_stats.csv', '%s_refshape_n360_kernel_stats.csv'),
+                 ('northstar_recurrence_fwd_inplace_kernel_stats.csv', '%s_northstar_fwd_inplace_kernel_stats.csv'),
+                 ('northstar_recurrence_fwd_kernel_stats.csv', '%s_northstar_fwd_copy_x_kernel_stats.csv'),
+                 ('northstar_recurrence_bwd_kernel_stats.csv', '%s_northstar_bwd_kernel_stats.csv'),
+                 ('config4_recurrence_fwd_inplace_kernel_stats.csv', '%s_config4_recurrence_fwd_kernel_stats.csv'),
+                 ('config4_recurrence_bwd_kernel_stats.csv', '%s_config4_recurrence_bwd_kernel_stats.csv'), ('refshape_n360_kernel_stats.csv', '%s_refshape_n360_kernel_stats.csv'),
                  ('refshape_n360_line.json', '%s_refshape_n360_line.json')]:
     p = os.path.join(SRC, src)
     if os.path.exists(p):

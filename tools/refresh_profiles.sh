@@ -19,14 +19,24 @@ cp gpurun_out/pmcmfma_refresh/available.txt $out/mfma_counters_available.txt 2>/
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-windows 0 --kernel-legs 0 > $out/prof.log 2>&1
 find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4 -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 5 --kernels recurrence_fwd_inplace recurrence_bwd contract_fwd contract_bwd_w contract_bwd_x > $out/prof4.log 2>&1
+# configs[3] (K = 25, Fin = Fout = 64, batch 64): one program per recurrence entry, 30 launches each (the three warm-up launches of
+# kbench are in the average: with 5 launches, as in round 2, they skewed it by 10-15 %)
+for kern in recurrence_fwd_inplace recurrence_bwd; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4_$kern -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 30 --kernels $kern > $out/prof4_$kern.log 2>&1
+  find $out/prof4_$kern -name "*kernel_stats.csv" -exec cp {} $out/config4_${kern}_kernel_stats.csv \;
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4 -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 10 --kernels contract_fwd contract_bwd_w contract_bwd_x > $out/prof4.log 2>&1
 find $out/prof4 -name "*kernel_stats.csv" -exec cp {} $out/config4_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -o c5 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 5 --kernels recurrence_fwd_inplace contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 > $out/prof5.log 2>&1
 find $out/prof5 -name "*kernel_stats.csv" -exec cp {} $out/config5_kernel_stats.csv \;
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/profn -o ns -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 256 --iters 50 --kernels recurrence_fwd_inplace recurrence_fwd recurrence_bwd > $out/profn.log 2>&1
-find $out/profn -name "*kernel_stats.csv" -exec cp {} $out/northstar_kernel_stats.csv \;
+# the north-star shape (K = 5, Fin = 32, batch 256): one program per entry, so that the in-place forward, the forward with the
+# copy of x and the adjoint each have their own average (the first two are the same kernel)
+for kern in recurrence_fwd_inplace recurrence_fwd recurrence_bwd; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/profn_$kern -o ns -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 256 --iters 100 --kernels $kern > $out/profn_$kern.log 2>&1
+  find $out/profn_$kern -name "*kernel_stats.csv" -exec cp {} $out/northstar_${kern}_kernel_stats.csv \;
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profr -o rs -- python3 $GRAFT_REPO_ROOT/tools/refshape.py --nodes 360 > $out/profr.log 2>&1
 find $out/profr -name "*kernel_stats.csv" -exec cp {} $out/refshape_n360_kernel_stats.csv \;
 tail -1 $out/profr.log > $out/refshape_n360_line.json
-rm -rf $out/prof $out/prof4 $out/prof5 $out/profn $out/profr
+rm -rf $out/prof $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr
 ls -la $out
