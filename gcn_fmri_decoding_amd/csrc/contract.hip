@@ -130,6 +130,110 @@ contract_fwd_kernel(FwdArgs a) {
     }
 }
 
+// Forward, ring version (Fout <= 32, W small enough for LDS).  The memory system gives the same access pattern with no
+// arithmetic 6.6-6.9 TB/s at twelve waves per CU and 4-8 KB in flight each (tools/probes/hbm_stream_probe.hip); the kernel
+// above reaches 4.2-4.6: a wave issues eight loads, waits for ALL of them, then runs 32 matrix instructions (2048 cycles)
+// with nothing of its own in flight, and every row of its epilogue pays one L2 round trip for its bias.  Here:
+//   * a ring of RING operand registers per wave that is refilled as it is consumed (step u: four matrix instructions on
+//     slot u, then the load of the pair RING steps ahead into slot u): RING - 1 loads stay in flight THROUGH the matrix work
+//     (hipcc turns the in-order uses into s_waitcnt vmcnt(RING - 1));
+//   * W and the row offsets (k * slab + fin * Mp, 64 bit) in LDS, filled once per workgroup: the A operand is one
+//     conflict-free ds_read_b32, the address of a load one ds_read_b64 + one 64-bit add (the kernel above spent ~25 vector
+//     instructions and two branches per load on it); rows beyond Fin*K (padding to whole ring rounds) alias the last
+//     row against zero weights, lanes beyond the plane alias vertex 0 and are never stored: no branches in the loop;
+//   * the per-vertex bias rows of the epilogue fetched eight at a time into the ring's registers as they fall free.
+// Same products in the same order as contract_fwd_kernel<1>: bit-identical results.  Measured (one box, A/B): batch 256
+// 0.447 -> 0.385 ms (57.5 -> 67 % of 8 TB/s), batch 64 alone 0.141 -> 0.122 ms, inside the training step 0.114 -> 0.100 ms
+// (52 -> 60 %), step 4.07 -> 3.99 ms.  What is left (timing experiments, EXPERIMENTS.md): with a quarter of the matrix
+// work the kernel takes 0.372 ms at batch 256 (memory side: 5.5 TB/s for this mix of reads and writes), without the loads
+// 0.269 ms; four waves per SIMD (ring of 4, or spilling into 128 registers) and no s_setprio are 2-5 % slower.
+#ifndef CG_FWD_RING
+#define CG_FWD_RING 8
+#endif
+#if CG_FWD_RING
+constexpr int RING = CG_FWD_RING;
+
+#ifndef CG_LB_RING
+#define CG_LB_RING 3
+#endif
+__global__ void __launch_bounds__(256, CG_LB_RING)
+contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
+    extern __shared__ __align__(16) unsigned char ring_smem[];
+    long long* roff = reinterpret_cast<long long*>(ring_smem);                    // [nrows_pad] element offset of row kk
+    float* Ws = reinterpret_cast<float*>(ring_smem + (size_t)nrows_pad * 8);       // [nrows_pad][32]
+    for (int idx = threadIdx.x; idx < nrows_pad * 32; idx += 256) {
+        const int kk = idx >> 5, fo = idx & 31;
+        Ws[idx] = (kk < a.FinK && fo < a.Fout) ? a.W[(size_t)kk * a.Fout + fo] : 0.f;
+    }
+    for (int kk = threadIdx.x; kk < nrows_pad; kk += 256) {
+        const int kc = kk < a.FinK ? kk : a.FinK - 1;
+        roff[kk] = (long long)(kc % a.K) * (long long)a.slab + (long long)(kc / a.K) * a.Mp;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int m0 = (blockIdx.x * 4 + wave) * 128;
+    if (m0 >= a.M) return;
+    const int n0 = m0 + 4 * c;
+    const bool valid = n0 < a.Mp;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
+
+    const float* base = a.stack + (size_t)b * a.Fin * a.Mp + (valid ? n0 : 0);
+    const int rounds = nrows_pad / (2 * RING);
+    float4 bv[RING];
+    float av[RING];
+    auto issue = [&](int u, int i) __attribute__((always_inline)) {
+        const int kk = 2 * i + h;
+        bv[u] = ld_stream(base + roff[kk]);
+        av[u] = Ws[kk * 32 + c];
+    };
+    auto step = [&](int u) __attribute__((always_inline)) {
+        CG_PRIO_HI();
+        acc[0] = mfma(av[u], bv[u].x, acc[0]);
+        acc[1] = mfma(av[u], bv[u].y, acc[1]);
+        acc[2] = mfma(av[u], bv[u].z, acc[2]);
+        acc[3] = mfma(av[u], bv[u].w, acc[3]);
+        CG_PRIO_LO();
+    };
+#pragma unroll
+    for (int u = 0; u < RING; ++u) issue(u, u);
+    for (int r = 1; r < rounds; ++r) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            step(u);
+            issue(u, r * RING + u);
+        }
+    }
+    // last round; with a per-vertex bias, slot u takes the bias of accumulator row j = u as it falls free
+    const bool vb = a.bias_kind == CHEBGCN_BIAS_VERTEX;
+    auto bias_row = [&](int j) __attribute__((always_inline)) -> float4 {
+        const int fo = acc_row(j, h);
+        const float* p = a.bias + (size_t)(fo < a.Fout ? fo : 0) * a.Mp + (valid ? n0 : 0);
+        return *reinterpret_cast<const float4*>(p);
+    };
+#pragma unroll
+    for (int u = 0; u < RING; ++u) {
+        step(u);
+        if (vb) bv[u] = bias_row(u);
+    }
+    // ---- epilogue: bias, relu, pool, store ----------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int fo = acc_row(j, h);
+        float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+        fwd_epilogue_row(a, b, fo, v, n0, valid, c, vb, bv[j % RING]);
+        if (vb && j + RING < 16) bv[j % RING] = bias_row(j + RING);
+    }
+}
+#endif
+
 // Small launches (atlas-sized graphs: the reference's own 246..1000-node atlases give one to nine 128-vertex tiles per
 // window): one wave per tile leaves most of the chip without work -- at M = 380, batch 128 the kernel above runs 384 waves
 // on 256 CUs, each through the whole reduction (0.049 ms for 68 MB).  Here the four waves of a workgroup share ONE tile and
@@ -551,6 +655,15 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
         hipLaunchKernelGGL(contract_fwd_splitk_kernel, grid, dim3(256), 0, stream, a);
     } else {
         dim3 grid(gx, B, 1);
+#if CG_FWD_RING
+        // whole ring rounds of row pairs; W and the row offsets of the padded rows in LDS (136 bytes per row)
+        const int nrows_pad = ((a.FinK + 2 * RING - 1) / (2 * RING)) * (2 * RING);
+        if ((size_t)nrows_pad * 136 <= 48 * 1024 && RING <= 8) {
+            hipLaunchKernelGGL(contract_fwd_ring_kernel, grid, dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
+            CG_HIP(hipGetLastError());
+            return CHEBGCN_OK;
+        }
+#endif
         hipLaunchKernelGGL(contract_fwd_kernel<1>, grid, dim3(256), 0, stream, a);
     }
     CG_HIP(hipGetLastError());

@@ -54,6 +54,7 @@ def main():
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
           g.query(11), flush=True)
     M, Mp = g.M, g.Mp
+    print('M = %d, Mp = %d (plane stride %d bytes)' % (M, Mp, 4 * Mp), flush=True)
     results = []
 
     def timeit(fn, iters):
