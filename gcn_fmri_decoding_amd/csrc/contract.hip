@@ -18,6 +18,7 @@
 // r feeds accumulator r (vertex <-> MFMA column is a free permutation).  The A operand
 // (a 32 x 2 sliver of W) is 8 B per lane from L1/L2.
 #include "contract_common.h"
+#include <type_traits>
 
 // Waves per SIMD the register allocation is held to (second __launch_bounds__ argument).  Left alone the
 // compiler parks the accumulators in AGPRs and spends VGPRs freely: 171 registers for contract_bwd_w_kernel<5>,
@@ -406,6 +407,129 @@ contract_bwd_x_kernel(BwdXArgs a) {
     }
 }
 
+// bwd_x, big launches with Fout <= 32: matrix work and stores interleaved inside every wave.
+// What the kernel above does per tile of 32 output rows: 16 four-byte loads of W per lane behind the previous tile's 16 KB
+// of stores in the CU's in-order memory pipeline, 64 matrix instructions (4096 cycles) with none of the wave's own memory
+// traffic in flight, then 16 stores that each wait for ALL FOUR accumulators (the four vertices of a lane's float4 live in
+// four accumulators) and compute kk / K, kk % K and a 64-bit address.  Timing experiments (EXPERIMENTS.md): the matrix work
+// alone 0.31 ms, the stores alone 0.32 ms, together 0.47 ms at batch 256 -- they add up more than they overlap.  Here:
+//   * vertex <-> accumulator mapping: accumulator r holds vertices m0 + 32 r + c (not 4 c + r), so one accumulator register
+//     is one 4-byte store of a full 128-byte line per half-wave, straight from the accumulator file, and accumulator r is
+//     finished and storable on its own;
+//   * two phases per row tile: the 32 matrix instructions of accumulators 0, 1 run while accumulators 2, 3 of the previous
+//     tile are stored, then 2, 3 run while 0, 1 of this tile are stored: every wave keeps the matrix pipe and the store
+//     stream busy at the same time (the first instruction of a chain takes C = 0: no zeroing);
+//   * W^T and the row offsets (k * slab + fin * Mp, 64 bit) in LDS: the A operand is a conflict-free ds_read_b32, the
+//     address of a row one ds_read_b64 + one add; the memory pipeline carries nothing but the stores.
+// Every output element is the same chain of products in the same order as above: bit-identical results.
+#ifndef CG_BWX_LDS
+#define CG_BWX_LDS 1
+#endif
+#ifndef CG_LB_BWXL
+#define CG_LB_BWXL 1
+#endif
+#if CG_BWX_LDS
+template <bool MASK>
+__global__ void __launch_bounds__(256, CG_LB_BWXL)
+contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
+    extern __shared__ __align__(16) unsigned char bwx_smem[];
+    long long* roff = reinterpret_cast<long long*>(bwx_smem);                     // [nrows32] element offset of stack row kk
+    float* Wt = reinterpret_cast<float*>(bwx_smem + (size_t)nrows32 * 8);          // [32][nrows32]: W^T, zero beyond Fin*K / Fout
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int m0 = (blockIdx.x * 4 + wave) * 128;
+    const int Mq = a.Mp >> 2;
+    const bool wave_live = m0 < a.M;
+    bool ok[4];                                                                  // uniform: the 32 vertices of accumulator r lie inside the plane
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ok[r] = wave_live && m0 + 32 * r < a.Mp;
+    // the dy tile first (its latency runs under the LDS fill); unconditional loads on clamped addresses, masked afterwards
+    const float* dyb = a.dy + (size_t)b * a.Fout * a.Mp + (wave_live ? m0 : 0) + c;
+    const uint8_t* mkb = MASK ? a.mask + (size_t)b * a.Fout * Mq + (((wave_live ? m0 : 0) + c) >> 2) : nullptr;
+    float hold[16][4];
+    int bits[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int fo = 2 * j + h, foc = fo < a.Fout ? fo : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int dv = ok[r] ? 32 * r : 0;
+            hold[j][r] = __builtin_nontemporal_load(dyb + (size_t)foc * a.Mp + dv);
+            bits[j][r] = MASK ? (int)mkb[(size_t)foc * Mq + (dv >> 2)] : 15;
+        }
+    }
+    for (int idx = threadIdx.x; idx < nrows32 * 32; idx += 256) {
+        const int kk = idx >> 5, fo = idx & 31;
+        Wt[fo * nrows32 + kk] = (kk < a.FinK && fo < a.Fout) ? a.W[(size_t)kk * a.Fout + fo] : 0.f;
+    }
+    for (int kk = threadIdx.x; kk < nrows32; kk += 256) {
+        const int kc = kk < a.FinK ? kk : a.FinK - 1;
+        roff[kk] = (long long)(kc % a.K) * (long long)a.slab + (long long)(kc / a.K) * a.Mp;
+    }
+    __syncthreads();
+    if (!wave_live) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                            // ReluGrad: zero where the forward result was not positive
+            const bool on = ok[r] && 2 * j + h < a.Fout && ((bits[j][r] >> (c & 3)) & 1);
+            hold[j][r] = on ? hold[j][r] : 0.f;
+        }
+    float* gbase = a.gstack + (size_t)b * a.Fin * a.Mp + m0 + c;
+    const int ntiles = nrows32 >> 5;                 // whole tiles: the launcher sends Fin*K % 32 != 0 to the kernel above
+    f32x16 acc[4];
+    f32x16 zero16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zero16[q] = 0.f;
+    const float* wt0 = Wt + h * nrows32 + c;
+    const long long* ro0 = roff + 4 * h;
+    // One phase: (MM) the matrix instructions of accumulators R0, R0 + 1 of row tile t, interleaved with (ST) the stores of
+    // accumulators S0, S0 + 1 of row tile ts.  The A value and the row offset of step j + 1 are read from LDS during step j.
+    // ALL: the four accumulators lie inside the plane (not so only in the last vertex tile of a window, uniform per wave).
+    auto phase = [&](auto R0_, auto S0_, auto MM_, auto ST_, auto ALL_, int t, int ts) __attribute__((always_inline)) {
+        constexpr int R0 = decltype(R0_)::value, S0 = decltype(S0_)::value;
+        constexpr bool MM = decltype(MM_)::value, ST = decltype(ST_)::value, ALL = decltype(ALL_)::value;
+        const float* wt = wt0 + t * 32;
+        const long long* ro = ro0 + ts * 32;
+        float w = MM ? wt[0] : 0.f;
+        long long off = ST ? ro[0] : 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float wn = (MM && j < 15) ? wt[2 * (j + 1) * nrows32] : 0.f;
+            const long long offn = (ST && j < 15) ? ro[((j + 1) & 3) + 8 * ((j + 1) >> 2)] : 0;
+            if (MM) {
+                acc[R0] = mfma(w, hold[j][R0], j == 0 ? zero16 : acc[R0]);
+                acc[R0 + 1] = mfma(w, hold[j][R0 + 1], j == 0 ? zero16 : acc[R0 + 1]);
+            }
+            if (ST) {
+                float* dst = gbase + off;
+                if (ALL || ok[S0]) dst[32 * S0] = acc[S0][j];
+                if (ALL || ok[S0 + 1]) dst[32 * (S0 + 1)] = acc[S0 + 1][j];
+            }
+            w = wn;
+            off = offn;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    using Y = std::true_type;
+    using N = std::false_type;
+    auto run = [&](auto ALL_) __attribute__((always_inline)) {
+        phase(I0{}, I2{}, Y{}, N{}, ALL_, 0, 0);                 // accumulators 0, 1 of tile 0
+        for (int t = 0; t < ntiles - 1; ++t) {
+            phase(I2{}, I0{}, Y{}, Y{}, ALL_, t, t);             // 2, 3 of tile t      | stores of 0, 1 of tile t
+            phase(I0{}, I2{}, Y{}, Y{}, ALL_, t + 1, t);         // 0, 1 of tile t + 1  | stores of 2, 3 of tile t
+        }
+        phase(I2{}, I0{}, Y{}, Y{}, ALL_, ntiles - 1, ntiles - 1);
+        phase(I0{}, I2{}, N{}, Y{}, ALL_, 0, ntiles - 1);        // stores of 2, 3 of the last tile
+    };
+    if (ok[3]) run(Y{});
+    else run(N{});
+}
+#endif
+
 // --------------------------------------------------------------------------------------
 // bwd_w:  D[kk][o] = sum_{b,m} stack[kk][b,m] dy[o][b,m]
 // Both operands are read along their planes: lane (i, h) owns plane i of its tile and
@@ -689,6 +813,15 @@ static int launch_bwd_x(const float* dy, const uint8_t* mask, const float* W, fl
         return CHEBGCN_OK;
     }
     dim3 grid((M + 511) / 512, B, 1);
+#if CG_BWX_LDS
+    const int nrows32 = ((a.FinK + 31) / 32) * 32;
+    if (Fout <= 32 && a.FinK % 32 == 0 && (size_t)nrows32 * 136 <= 48 * 1024) {
+        if (mask) hipLaunchKernelGGL((contract_bwd_x_lds_kernel<true>), grid, dim3(256), (size_t)nrows32 * 136, stream, a, nrows32);
+        else hipLaunchKernelGGL((contract_bwd_x_lds_kernel<false>), grid, dim3(256), (size_t)nrows32 * 136, stream, a, nrows32);
+        CG_HIP(hipGetLastError());
+        return CHEBGCN_OK;
+    }
+#endif
     if (mask) {
         if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, true>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((contract_bwd_x_kernel<false, true>), grid, dim3(256), 0, stream, a);

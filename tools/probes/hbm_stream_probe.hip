@@ -61,6 +61,37 @@ __global__ void __launch_bounds__(256) copy_kernel(const f32x4* __restrict__ p, 
     }
 }
 
+// the pattern of contract_bwd_x's stores: a wave owns 128 vertices and writes `rows` planes (two per instruction)
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) wrows_kernel(float* __restrict__ p, int Mp, int rows, int tiles) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tiles) return;
+    const int b = blockIdx.y;
+    float* base = p + (size_t)b * rows * Mp + tile * 128 + 4 * c;
+    const f32x4 v = {1.f, 2.f, 3.f, (float)lane};
+    for (int r0 = 0; r0 < rows; r0 += 2 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4* q = reinterpret_cast<f32x4*>(base + (size_t)(r0 + 2 * u + h) * Mp);
+            if (NT) __builtin_nontemporal_store(v, q); else *q = v;
+        }
+    }
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(256) write_kernel(f32x4* __restrict__ q, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i + 3 * 256 < n16; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (NT) __builtin_nontemporal_store(v, q + i + u * 256); else q[i + u * 256] = v;
+        }
+    }
+}
+
 template <typename F>
 static float time_ms(F launch, int reps) {
     hipEvent_t a, b;
@@ -117,5 +148,18 @@ int main() {
         printf("copy  U=%d workgroups=%5d : %7.3f ms  %6.0f GB/s (read + write)\n", U, WGS, ms, 2.0 * bytes / ms / 1e6); \
     }
     COPY(4, cus * 8) COPY(8, cus * 4) COPY(8, cus * 8)
+#define WRITE(NT, WGS)                                                                                                \
+    {                                                                                                                 \
+        const float ms = time_ms([&] { hipLaunchKernelGGL((write_kernel<NT>), dim3(WGS), dim3(256), 0, 0, (f32x4*)q, n16); }, 20); \
+        printf("write nt=%d workgroups=%5d : %7.3f ms  %6.0f GB/s\n", (int)NT, WGS, ms, bytes / ms / 1e6);                \
+    }
+    WRITE(false, cus * 8) WRITE(true, cus * 8) WRITE(true, cus * 4) WRITE(true, cus * 16)
+#define WROWS(U, NT)                                                                                                  \
+    {                                                                                                                 \
+        const float ms = time_ms([&] { hipLaunchKernelGGL((wrows_kernel<U, NT>), dim3((tiles + 3) / 4, B), dim3(256), 0, 0, q, Mp, rows, tiles); }, 20); \
+        printf("wrows U=%d nt=%d (128 vertices x 160 planes per wave) : %7.3f ms  %6.0f GB/s\n", U, (int)NT, ms,          \
+               (double)tiles * 128 * rows * B * 4 / ms / 1e6);                                                       \
+    }
+    WROWS(8, false) WROWS(8, true) WROWS(16, true) WROWS(2, true)
     return 0;
 }
