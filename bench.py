@@ -392,6 +392,8 @@ def main():
     ap.add_argument('--instrumented-steps', type=int, default=10,
                     help='steps of the separate instrumented pass AFTER the timed regions (HIP events around every hot-kernel '
                          'launch, no second stream): the source of `roofline` and `kernels`; 0 disables it')
+    ap.add_argument('--step-graph', type=int, default=0,
+                    help='1: capture the training step as one HIP graph (cgcnn.enable_step_graph; single GPU only)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL)')
     ap.add_argument('--stub', action='store_true', help='launcher / reporting path with a stand-in CPU step (tests)')
     args = ap.parse_args()
@@ -432,6 +434,8 @@ def main():
                            dropout=0.5, batch_size=args.batch, learning_rate=0.001, decay_rate=0.9, momentum=0.9,
                            verbose=False)
     n_seen = 1
+    if args.step_graph and world == 1:
+        net.enable_step_graph(True)
     if world > 1:
         gdist.DataParallel(net)
         n_seen = ranks_seen(dist, dev)

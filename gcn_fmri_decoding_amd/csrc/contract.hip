@@ -447,18 +447,20 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
     for (int r = 0; r < 4; ++r) ok[r] = wave_live && m0 + 32 * r < a.Mp;
     // the dy tile first (its latency runs under the LDS fill); unconditional loads on clamped addresses, masked afterwards
     const float* dyb = a.dy + (size_t)b * a.Fout * a.Mp + (wave_live ? m0 : 0) + c;
-    const uint8_t* mkb = MASK ? a.mask + (size_t)b * a.Fout * Mq + (((wave_live ? m0 : 0) + c) >> 2) : nullptr;
+    // ReLU mask of row fo: one byte per four vertices, 32 bytes = 8 dwords for the 128 vertices of the tile.  Lane c
+    // fetches dword c & 7 of its row (one load per row); the bit of vertex 32 r + c sits in byte 8 r + (c >> 2), i.e. in the
+    // dword lane 2 r + (c >> 4) of the same half-wave holds: one ds_bpermute per accumulator instead of a byte load.
+    const uint8_t* mkb = MASK ? a.mask + (size_t)b * a.Fout * Mq + ((wave_live ? m0 : 0) >> 2) + 4 * (c & 7) : nullptr;
     float hold[16][4];
-    int bits[16][4];
+    int mword[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int fo = 2 * j + h, foc = fo < a.Fout ? fo : 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int dv = ok[r] ? 32 * r : 0;
-            hold[j][r] = __builtin_nontemporal_load(dyb + (size_t)foc * a.Mp + dv);
-            bits[j][r] = MASK ? (int)mkb[(size_t)foc * Mq + (dv >> 2)] : 15;
-        }
+        for (int r = 0; r < 4; ++r) hold[j][r] = __builtin_nontemporal_load(dyb + (size_t)foc * a.Mp + (ok[r] ? 32 * r : 0));
+        // (the row's 32 mask bytes exist for every r: planes are padded to 32 vertices and a tile is 4 x 32; beyond the
+        // plane the accumulator is dropped by ok[r])
+        mword[j] = MASK ? *reinterpret_cast<const int*>(mkb + (size_t)foc * Mq) : -1;
     }
     for (int idx = threadIdx.x; idx < nrows32 * 32; idx += 256) {
         const int kk = idx >> 5, fo = idx & 31;
@@ -470,11 +472,13 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
     }
     __syncthreads();
     if (!wave_live) return;
+    const int bit_sh = 8 * ((c >> 2) & 3) + (c & 3);
 #pragma unroll
     for (int j = 0; j < 16; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                                            // ReluGrad: zero where the forward result was not positive
-            const bool on = ok[r] && 2 * j + h < a.Fout && ((bits[j][r] >> (c & 3)) & 1);
+            const int word = MASK ? __builtin_amdgcn_ds_bpermute(4 * (2 * r + (c >> 4) + 32 * h), mword[j]) : -1;
+            const bool on = ok[r] && 2 * j + h < a.Fout && ((word >> bit_sh) & 1);
             hold[j][r] = on ? hold[j][r] : 0.f;
         }
     float* gbase = a.gstack + (size_t)b * a.Fin * a.Mp + m0 + c;

@@ -109,8 +109,9 @@ static float time_ms(F launch, int reps) {
     return ms / reps;
 }
 
-int main() {
-    const int Mp = 10496, rows = 160, B = 64, tiles = 82;
+int main(int argc, char** argv) {
+    const int Mp = 10496, rows = 160, tiles = 82;
+    const int B = argc > 1 ? atoi(argv[1]) : 64;     // windows: 64 = the stack of the bench shape (430 MB); 16 / 32 fit the 256 MB Infinity Cache
     const size_t bytes = (size_t)B * rows * Mp * 4;           // 430 MB: the stack of the bench shape
     float *p, *q, *out;
     hipMalloc(&p, bytes);
