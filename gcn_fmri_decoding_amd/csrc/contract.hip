@@ -870,16 +870,17 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
     const int gy = (a.ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
     dim3 grid(gx, gy, gz);
     const size_t lds = (size_t)(rt + 1) * 32 * BW_ROW * sizeof(float);
+#define CG_BWK contract_bwd_w_kernel
 #define CG_BW(N)                                                                                        \
     case N:                                                                                             \
         if (mask) {                                                                                     \
-            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_kernel<N, true>),   \
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(CG_BWK<N, true>),                  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-            hipLaunchKernelGGL((contract_bwd_w_kernel<N, true>), grid, dim3(256), lds, stream, a);      \
+            hipLaunchKernelGGL((CG_BWK<N, true>), grid, dim3(256), lds, stream, a);                     \
         } else {                                                                                        \
-            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_kernel<N, false>),  \
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(CG_BWK<N, false>),                 \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-            hipLaunchKernelGGL((contract_bwd_w_kernel<N, false>), grid, dim3(256), lds, stream, a);     \
+            hipLaunchKernelGGL((CG_BWK<N, false>), grid, dim3(256), lds, stream, a);                    \
         }                                                                                               \
         break
     switch (rt) {
@@ -887,6 +888,7 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
         default: return fail(CHEBGCN_EUNSUPPORTED, "contract_bwd_w: rt=%d", rt);
     }
 #undef CG_BW
+#undef CG_BWK
     CG_HIP(hipGetLastError());
     float* stage = (float*)workspace + (size_t)gx * gy * gz * rt * 16 * 64;
     hipLaunchKernelGGL(reduce_partials_stage1, dim3(rt * 16, gy * BW_SPLIT, gz), dim3(256), 0, stream,
