@@ -17,6 +17,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats.csv', '%s_bench_kernel_stats.csv'),
                  ('kbench.txt', '%s_kbench.txt'), ('kbench.json', '%s_kbench.json'),
                  ('kbench_config4.txt', '%s_kbench_config4_K25_F64.txt'), ('kbench_config5.txt', '%s_kbench_config5_bf16.txt'),
+                 ('hbm_stream_probe.txt', '%s_hbm_stream_probe.txt'), ('mfma_f32_probe.txt', '%s_mfma_f32_probe.txt'),
                  ('traffic_raw.json', '%s_traffic_raw.json'), ('kbench_two_planes.txt', '%s_kbench_two_plane_recurrence.txt'),
                  ('mfma.txt', '%s_contraction_mfma_counters.txt'), ('stamps4.txt', '%s_recurrence4_phase_stamps.txt'), ('mfma_counters_available.txt', '%s_mfma_counters_available.txt'),
                  ('config4_kernel_stats.csv', '%s_config4_kernel_stats.csv'), ('config5_kernel_stats.csv', '%s_config5_kernel_stats.csv'),
