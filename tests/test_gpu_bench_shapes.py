@@ -440,3 +440,76 @@ def test_contraction_bench_launch_b64(ops, dev):
     err = float((dbias[:, :M].double() - db_ref).abs().max() / db_ref.abs().max())
     assert err <= GREL, 'bias gradient: %.3e' % err
     assert float(dbias[:, M:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,M,Fin,K,Fout,bias_kind,relu', [
+    (256, 1050, 32, 5, 32, 'vertex', 1),      # Mp = 1056 = 8 * 128 + 32: one of four accumulators of the last tile inside the plane
+    (200, 1200, 15, 5, 32, 'filter', 1),      # Fin*K = 75: padded ring rounds forward, partial row tiles backward; 64 of 128 inside
+    (130, 2000, 32, 10, 24, 'none', 0),       # K = 10 (320 rows of W in LDS), Fout < 32, no ReLU (plain gradients); 96 of 128 inside
+])
+def test_contraction_big_launch_edges(ops, dev, B, M, Fin, K, Fout, bias_kind, relu):
+    """Big-launch contraction kernels (the ring forward, the two-phase bwd_x, bwd_w) where a window's last 128-vertex tile
+    sticks out of the plane, Fin*K is not a multiple of the ring round / row tile, Fout < 32, with and without the ReLU
+    mask -- against float64 products of the same operands (1e-5 / 2e-5 of max, pads poisoned with NaN)."""
+    import ctypes
+    from gcn_fmri_decoding_amd import _lib
+    lib = _lib.lib()
+    Mp = ops.plane_stride(M)
+    assert Mp % 128 != 0
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B + M)
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    stack[..., M:] = float('nan')
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * 0.1
+    kind = {'vertex': ops.BIAS_VERTEX, 'filter': ops.BIAS_FILTER, 'none': ops.BIAS_NONE}[bias_kind]
+    bias, bias_ref = None, 0.0
+    if bias_kind == 'vertex':
+        bias = torch.zeros((Fout, Mp), device=dev)
+        bias[:, :M] = torch.randn((Fout, M), generator=gen, device=dev) * 0.3
+        bias_ref = bias[:, :M].double()
+    elif bias_kind == 'filter':
+        bias = torch.randn((Fout,), generator=gen, device=dev) * 0.3
+        bias_ref = bias.double()[:, None]
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    out = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    mask = torch.zeros((B, Fout, Mp // 4), dtype=torch.uint8, device=dev) if relu else None
+    _lib.check(lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), kind, P(out), P(mask), B, M, Fin, K, Fout, 1, 0, relu, st), 'fwd')
+    S = stack[..., :M].permute(2, 0, 1, 3).reshape(Fin * K, B, M).double()          # rows fin*K + k
+    pre = torch.einsum('rbm,ro->bom', S, W.double()) + bias_ref
+    ref = pre.clamp(min=0) if relu else pre
+    err = float((out[..., :M].double() - ref).abs().max() / pre.abs().max())
+    assert err <= REL, 'contract_fwd: %.3e' % err
+
+    gout = torch.randn((B, Fout, Mp), generator=gen, device=dev)
+    gout[..., M:] = float('nan') if relu else 0.0        # (without a mask the pad columns of dy are the caller's zeros)
+    if relu:
+        bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, Fout, Mp)[..., :M].bool()
+        assert torch.equal(bits, out[..., :M] > 0), 'ReLU bit mask disagrees with the output'
+        dy = (gout[..., :M] * bits).double()
+    else:
+        dy = gout[..., :M].double()
+    n = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    dW = torch.full((Fin * K, Fout), float('nan'), device=dev)
+    if relu:
+        _lib.check(lib.chebgcn_contract_bwd_w_relu(P(stack), P(gout), P(mask), P(dW), P(ws), n, B, M, Fin, K, Fout, st), 'bwd_w')
+    else:
+        _lib.check(lib.chebgcn_contract_bwd_w(P(stack), P(gout), P(dW), P(ws), n, B, M, Fin, K, Fout, st), 'bwd_w')
+    dW_ref = torch.einsum('rbm,bom->ro', S, dy)
+    err = float((dW.double() - dW_ref).abs().max() / dW_ref.abs().max())
+    assert err <= GREL, 'contract_bwd_w: %.3e' % err
+    del S
+
+    gstack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    if relu:
+        _lib.check(lib.chebgcn_contract_bwd_x_relu(P(gout), P(mask), P(W), P(gstack), B, M, Fin, K, Fout, st), 'bwd_x')
+    else:
+        _lib.check(lib.chebgcn_contract_bwd_x(P(gout), P(W), P(gstack), B, M, Fin, K, Fout, st), 'bwd_x')
+    gs_ref = torch.einsum('ro,bom->rbm', W.double(), dy).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    err = float((gstack[..., :M].double() - gs_ref).abs().max() / gs_ref.abs().max())
+    assert err <= GREL, 'contract_bwd_x: %.3e' % err
+    # nothing was written beyond the planes: the next plane's first columns would be hit first
+    assert bool(torch.isfinite(gstack[..., :M]).all())
