@@ -408,6 +408,12 @@ def main():
     if args.stub:
         return stub_main(args, world, rank)
 
+    # stdout carries ONE line: the result.  Libraries write banners to file descriptor 1 (RCCL prints its version block
+    # when the first communicator comes up): everything but the result line goes to stderr from here on.
+    result_out = os.fdopen(os.dup(1), 'w')
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -545,7 +551,8 @@ def main():
             line['refshape'] = {'n360': refshape_leg(dev, 360, 100, 10), 'n1000': refshape_leg(dev, 1000, 100, 10)}
         if world == 1 and args.cpu_windows > 0:
             line['cpu_baseline'] = cpu_baseline(Ls[:1], cfg, args.cpu_windows)
-        print(json.dumps(line), flush=True)
+        result_out.write(json.dumps(line) + '\n')
+        result_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

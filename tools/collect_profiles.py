@@ -26,11 +26,15 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
                  ('northstar_recurrence_bwd_kernel_stats.csv', '%s_northstar_bwd_kernel_stats.csv'),
                  ('config4_recurrence_fwd_inplace_kernel_stats.csv', '%s_config4_recurrence_fwd_kernel_stats.csv'),
                  ('config4_recurrence_bwd_kernel_stats.csv', '%s_config4_recurrence_bwd_kernel_stats.csv'), ('refshape_n360_kernel_stats.csv', '%s_refshape_n360_kernel_stats.csv'),
-                 ('refshape_n360_line.json', '%s_refshape_n360_line.json')]:
+                 ('refshape_n360_line.json', '%s_refshape_n360_line.json')] + [
+        ('events_under_rocprof_%s_%s.txt' % (c, k), '%%s_events_under_rocprof_%s_%s.txt' % (c, k))
+        for c in ('northstar', 'config4') for k in ('recurrence_fwd_inplace', 'recurrence_fwd', 'recurrence_bwd')]:
     p = os.path.join(SRC, src)
     if os.path.exists(p):
         if src.endswith('.txt') or src == 'bench_line.json':
             lines = [l for l in open(p) if 'amdgpu.ids' not in l and l.strip() not in ('1', '6 6 6')]
+            if src == 'bench_line.json':
+                lines = [l for l in lines if l.startswith('{"metric"')]
             open(os.path.join(DST, dst % tag), 'w').writelines(lines)
         else:
             shutil.copy(p, os.path.join(DST, dst % tag))
@@ -38,8 +42,9 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
 raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
 names = {'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd',
          'cheb4_kernel<10240, 20, 6, 512, false,': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true,': 'recurrence_bwd_4planes',
-         'contract_fwd_kernel<1>': 'contract_fwd', 'contract_bwd_w_kernel<5, true>': 'contract_bwd_w',
-         'contract_bwd_x_kernel<true, true>': 'contract_bwd_x', 'bias_grad_relu_kernel<2>': 'bias_grad',
+         'contract_fwd_kernel<1>': 'contract_fwd', 'contract_fwd_ring_kernel': 'contract_fwd', 'contract_bwd_w_kernel<5, true>': 'contract_bwd_w',
+         'contract_bwd_x_kernel<true, true>': 'contract_bwd_x', 'contract_bwd_x_lds_kernel<true>': 'contract_bwd_x',
+         'contract_bwd_x_lds_kernel<false>': 'contract_bwd_x_unfolded', 'bias_grad_relu_kernel<2>': 'bias_grad',
          'contract_bwd_w_kernel<5, false>': 'contract_bwd_w_unfolded', 'contract_bwd_x_kernel<true, false>': 'contract_bwd_x_unfolded',
          'brelu_pool_bwd_kernel<2, 1>': 'brelu_pool_bwd_unfolded'}
 out = {'_note': 'HBM bytes per launch at the bench shape (B=64, Fin=Fout=32, K=5, M=10466), rocprofv3 --pmc FETCH_SIZE and '

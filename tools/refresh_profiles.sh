@@ -10,7 +10,7 @@ cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench_line.json 2> $out/bench.err
 python3 tools/kbench.py --json $out/kbench.json > $out/kbench.txt 2>&1
 python3 tools/kbench.py --planes 2 --B 64 256 --kernels recurrence_fwd recurrence_fwd_inplace recurrence_bwd > $out/kbench_two_planes.txt 2>&1
-python3 tools/kbench.py --B 64 256 --fin 64 --K 25 --kernels recurrence_fwd_inplace recurrence_bwd --iters 5 > $out/kbench_config4.txt 2>&1
+python3 tools/kbench.py --B 64 256 --fin 64 --K 25 --kernels recurrence_fwd_inplace recurrence_bwd --iters 30 > $out/kbench_config4.txt 2>&1
 python3 tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 --iters 10 > $out/kbench_config5.txt 2>&1
 bash tools/pmc_traffic.sh refresh > $out/traffic.log 2>&1
 cp gpurun_out/traffic_refresh/traffic_raw.json $out/ 2>/dev/null
@@ -22,7 +22,7 @@ find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv
 # configs[3] (K = 25, Fin = Fout = 64, batch 64): one program per recurrence entry, 30 launches each (the three warm-up launches of
 # kbench are in the average: with 5 launches, as in round 2, they skewed it by 10-15 %)
 for kern in recurrence_fwd_inplace recurrence_bwd; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4_$kern -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 30 --kernels $kern > $out/prof4_$kern.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4_$kern -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 30 --kernels $kern > $out/events_under_rocprof_config4_$kern.txt 2>&1
   find $out/prof4_$kern -name "*kernel_stats.csv" -exec cp {} $out/config4_${kern}_kernel_stats.csv \;
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4 -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 10 --kernels contract_fwd contract_bwd_w contract_bwd_x > $out/prof4.log 2>&1
@@ -32,7 +32,7 @@ find $out/prof5 -name "*kernel_stats.csv" -exec cp {} $out/config5_kernel_stats.
 # the north-star shape (K = 5, Fin = 32, batch 256): one program per entry, so that the in-place forward, the forward with the
 # copy of x and the adjoint each have their own average (the first two are the same kernel)
 for kern in recurrence_fwd_inplace recurrence_fwd recurrence_bwd; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/profn_$kern -o ns -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 256 --iters 100 --kernels $kern > $out/profn_$kern.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/profn_$kern -o ns -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 256 --iters 100 --kernels $kern > $out/events_under_rocprof_northstar_$kern.txt 2>&1
   find $out/profn_$kern -name "*kernel_stats.csv" -exec cp {} $out/northstar_${kern}_kernel_stats.csv \;
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profr -o rs -- python3 $GRAFT_REPO_ROOT/tools/refshape.py --nodes 360 > $out/profr.log 2>&1
