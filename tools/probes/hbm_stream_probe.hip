@@ -49,6 +49,31 @@ __global__ void __launch_bounds__(256) rows_kernel(const float* __restrict__ p, 
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
 }
 
+// the same with the stack's real layout [K][B][Fin][Mp]: row r = fin * K + k lies at k * slab + fin * Mp (slab = B * Fin * Mp
+// floats, + pad): consecutive rows of a wave are a whole slab apart -- 2^21 * 41 bytes at the bench shape
+template <int U>
+__global__ void __launch_bounds__(256) rowsk_kernel(const float* __restrict__ p, int Mp, int Fin, int K, size_t slab, int tiles, float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tiles) return;
+    const int b = blockIdx.y;
+    const float* base = p + (size_t)b * Fin * Mp + tile * 128 + 4 * c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int rows = Fin * K;
+    for (int r0 = 0; r0 < rows; r0 += 2 * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 2 * u + h;
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (size_t)(r % K) * slab + (size_t)(r / K) * Mp));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+
 template <int U>
 __global__ void __launch_bounds__(256) copy_kernel(const f32x4* __restrict__ p, f32x4* __restrict__ q, size_t n16) {
     const size_t stride = (size_t)gridDim.x * 256 * U;
@@ -143,6 +168,19 @@ int main(int argc, char** argv) {
     }
     ROWS(2, 0) ROWS(4, 0) ROWS(8, 0) ROWS(16, 0)
     ROWS(8, 6) ROWS(8, 4) ROWS(8, 3) ROWS(8, 2) ROWS(16, 3) ROWS(16, 2) ROWS(4, 3) ROWS(2, 3)
+#define ROWSK(U, PAD)                                                                                                 \
+    {                                                                                                                 \
+        const size_t slab = (size_t)B * 32 * Mp + PAD;                                                                \
+        if (5 * slab * 4 <= bytes + 5 * 4 * (size_t)PAD && B * 160 == B * rows) {                                      \
+            const float ms = time_ms([&] { hipLaunchKernelGGL((rowsk_kernel<U>), dim3((tiles + 3) / 4, B), dim3(256), 0, 0, p2, Mp, 32, 5, slab, tiles, out); }, 20); \
+            printf("rowsk U=%d slab pad %6d floats (stack layout [K][B][Fin][Mp], slab stride %zu B) : %7.3f ms  %6.0f GB/s\n", U, PAD, slab * 4, ms, \
+                   (double)tiles * 128 * rows * B * 4 / ms / 1e6);                                                   \
+        }                                                                                                             \
+    }
+    float* p2;
+    hipMalloc(&p2, bytes + 5 * 4 * 65536);
+    hipMemset(p2, 0, bytes + 5 * 4 * 65536);
+    ROWSK(8, 0) ROWSK(8, 64) ROWSK(8, 1024) ROWSK(8, 2080) ROWSK(8, 16416) ROWSK(4, 0) ROWSK(4, 2080)
 #define COPY(U, WGS)                                                                                                  \
     {                                                                                                                 \
         const float ms = time_ms([&] { hipLaunchKernelGGL((copy_kernel<U>), dim3(WGS), dim3(256), 0, 0, (const f32x4*)p, (f32x4*)q, n16); }, 20); \
