@@ -693,8 +693,13 @@ static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, h
     const int64_t nitems64 = (int64_t)ntm * B * (FoutP / G);
     CG_REQUIRE(nitems64 < (1ll << 31), "contract_fwd_bf16: too many tiles");
     const int nitems = (int)nitems64;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    static int cus = 0;                                  // cached: the attribute query is slow
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
     const dim3 grid(nitems < cus ? nitems : cus);       // one workgroup per CU (128 accumulator registers per lane)
 #define CG_BF16_LAUNCH(P, NW)                                                                                      \
     do {                                                                                                           \

@@ -73,7 +73,10 @@ int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr /*host [M+1]*
  * per active vertex fit the 160 KB of LDS, i.e. up to ~10200 active vertices, else 2), 2, or 4
  * (CHEBGCN_EUNSUPPORTED where 4 do not fit).  The
  * choice affects speed and the order of the terms inside a row sum (results agree to fp32
- * round-off). */
+ * round-off).  With 0, a graph that fits four planes keeps a two-plane image as well and a launch
+ * of fewer than four plane groups per CU (ceil(B*Fin/4) < 4 * CUs) runs on it: the same window can
+ * then differ in its last fp32 bits between batch sizes (training batch, evaluation batch, a
+ * data-parallel shard) and between GPUs with different CU counts; planes = 2 or 4 pins one image. */
 int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,
                                 const float* vals, int planes, chebgcn_graph** out);
 void chebgcn_graph_destroy(chebgcn_graph* g);
