@@ -225,12 +225,19 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
         if (vb) bv[u] = bias_row(u);
     }
     // ---- epilogue: bias, relu, pool, store ----------------------------------------------
+    float ms[4] = {0.f, 0.f, 0.f, 0.f};              // mean_out: sum over this lane's 16 filter rows (after bias + ReLU)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int fo = acc_row(j, h);
         float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
         fwd_epilogue_row(a, b, fo, v, n0, valid, c, vb, bv[j % RING]);
         if (vb && j + RING < 16) bv[j % RING] = bias_row(j + RING);
+        if (fo < a.Fout) { ms[0] += v[0]; ms[1] += v[1]; ms[2] += v[2]; ms[3] += v[3]; }
+    }
+    if (a.mean_out) {                                // + the 16 rows of the other half-wave, / Fout
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ms[r] = (ms[r] + __shfl_xor(ms[r], 32)) / (float)a.Fout;
+        if (h == 0 && valid) *reinterpret_cast<float4*>(a.mean_out + (size_t)b * a.Mp + n0) = make_float4(ms[0], ms[1], ms[2], ms[3]);
     }
 }
 #endif
@@ -307,6 +314,9 @@ struct BwdXArgs {
     const uint8_t* mask;         // MASK: dy = the gradient of the layer OUTPUT, gated by the ReLU mask of the forward
     int B, M, Mp, Fin, K, Fout, FinK;
     size_t slab;
+    // element strides of dy between windows and filters: Fout*Mp and Mp, or Mp and 0 where every filter takes the same plane
+    // (the gradient of a filter mean, chebgcn_contract_bwd_x_relu_mean)
+    size_t dy_bstride, dy_fstride;
 };
 
 // HOLD: dy tile (Fout <= 32 -> 16 float4 per lane) stays in registers across the row tiles.
@@ -325,7 +335,7 @@ contract_bwd_x_kernel(BwdXArgs a) {
     const bool valid = n0 < a.Mp;
     // every load below is unconditional on a clamped address and masked afterwards: a conditional load is a
     // branch with a full s_waitcnt behind it, i.e. one exposed memory round trip per row
-    const float* dyb = a.dy + (size_t)b * a.Fout * a.Mp + (valid ? n0 : 0);
+    const float* dyb = a.dy + (size_t)b * a.dy_bstride + (valid ? n0 : 0);
     const uint8_t* mkb = MASK ? a.mask + (size_t)b * a.Fout * (a.Mp >> 2) + (valid ? (n0 >> 2) : 0) : nullptr;
     const int Mq = a.Mp >> 2;
     auto gated = [&](float4 v, int bits) {       // ReluGrad: zero where the forward result was not positive
@@ -340,7 +350,7 @@ contract_bwd_x_kernel(BwdXArgs a) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int fo = 2 * j + h, foc = fo < a.Fout ? fo : 0;
-            hold[j] = ld_stream(dyb + (size_t)foc * a.Mp);
+            hold[j] = ld_stream(dyb + (size_t)foc * a.dy_fstride);
             bits[j] = MASK ? (int)mkb[(size_t)foc * Mq] : 15;
         }
 #pragma unroll
@@ -380,7 +390,7 @@ contract_bwd_x_kernel(BwdXArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     const int fo = 2 * (j0 + u) + h, foc = fo < a.Fout ? fo : 0;
                     av[u] = wrow[foc];
-                    bv[u] = *reinterpret_cast<const float4*>(dyb + (size_t)foc * a.Mp);
+                    bv[u] = *reinterpret_cast<const float4*>(dyb + (size_t)foc * a.dy_fstride);
                     bits[u] = MASK ? (int)mkb[(size_t)foc * Mq] : 15;
                 }
 #pragma unroll
@@ -446,7 +456,7 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) ok[r] = wave_live && m0 + 32 * r < a.Mp;
     // the dy tile first (its latency runs under the LDS fill); unconditional loads on clamped addresses, masked afterwards
-    const float* dyb = a.dy + (size_t)b * a.Fout * a.Mp + (wave_live ? m0 : 0) + c;
+    const float* dyb = a.dy + (size_t)b * a.dy_bstride + (wave_live ? m0 : 0) + c;
     // ReLU mask of row fo: one byte per four vertices, 32 bytes = 8 dwords for the 128 vertices of the tile.  Lane c
     // fetches dword c & 7 of its row (one load per row); the bit of vertex 32 r + c sits in byte 8 r + (c >> 2), i.e. in the
     // dword lane 2 r + (c >> 4) of the same half-wave holds: one ds_bpermute per accumulator instead of a byte load.
@@ -457,7 +467,7 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
     for (int j = 0; j < 16; ++j) {
         const int fo = 2 * j + h, foc = fo < a.Fout ? fo : 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hold[j][r] = __builtin_nontemporal_load(dyb + (size_t)foc * a.Mp + (ok[r] ? 32 * r : 0));
+        for (int r = 0; r < 4; ++r) hold[j][r] = __builtin_nontemporal_load(dyb + (size_t)foc * a.dy_fstride + (ok[r] ? 32 * r : 0));
         // (the row's 32 mask bytes exist for every r: planes are padded to 32 vertices and a tile is 4 x 32; beyond the
         // plane the accumulator is dropped by ok[r])
         mword[j] = MASK ? *reinterpret_cast<const int*>(mkb + (size_t)foc * Mq) : -1;
@@ -550,6 +560,7 @@ struct BwdWArgs {
     int nchunks_m;               // ceil(M / 64)
     int ntiles;                  // ceil(FinK / 32)
     size_t slab;
+    size_t dy_bstride, dy_fstride;   // see BwdXArgs
 };
 
 // One chunk = 64 consecutive vertices of one window.  Its operand rows -- RT*32 stack planes
@@ -601,7 +612,7 @@ contract_bwd_w_kernel(BwdWArgs a) {
         } else {
             int fo = fo0 + (row - RT * 32);
             if (fo >= a.Fout) fo = 0;
-            rsrc[u] = a.dy + (size_t)fo * a.Mp + 4 * rsw;
+            rsrc[u] = a.dy + (size_t)fo * a.dy_fstride + 4 * rsw;
         }
     }
     bool a_ok[RT];
@@ -623,7 +634,7 @@ contract_bwd_w_kernel(BwdWArgs a) {
             }
         }
         const ptrdiff_t mo = (m0 + 4 * rsw < a.Mp) ? m0 : -4 * rsw;   // beyond the plane: any valid address, masked below
-        const ptrdiff_t so = (ptrdiff_t)b * a.Fin * a.Mp + mo, dof = (ptrdiff_t)b * a.Fout * a.Mp + mo;
+        const ptrdiff_t so = (ptrdiff_t)b * a.Fin * a.Mp + mo, dof = (ptrdiff_t)b * (ptrdiff_t)a.dy_bstride + mo;
 #pragma unroll
         for (int u = 0; u < PER_WAVE; ++u) {
             const int n = wave + 4 * u;
@@ -798,12 +809,43 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
     return CHEBGCN_OK;
 }
 
+// whole ring rounds of row pairs; W and the row offsets of the padded rows in LDS (136 bytes per row)
+static int ring_rows(int FinK) { return ((FinK + 2 * RING - 1) / (2 * RING)) * (2 * RING); }
+
+extern "C" int chebgcn_contract_fwd_mean_supported(int B, int M, int Fin, int K, int Fout) {
+    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0 || Fout > 32 || B > 65535) return 0;
+    return !small_launch(B, M) && (size_t)ring_rows(Fin * K) * 136 <= 48 * 1024;
+}
+
+extern "C" int chebgcn_contract_fwd_mean(const float* stack, const float* W, const float* bias, int bias_kind, float* mean_out,
+                                         uint8_t* relu_mask, int B, int M, int Fin, int K, int Fout, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(stack && W && mean_out, "contract_fwd_mean: NULL argument");
+    CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || bias, "contract_fwd_mean: bias_kind set but bias is NULL");
+    CG_REQUIRE(bias_kind >= 0 && bias_kind <= 2, "contract_fwd_mean: bad kind");
+    if (!chebgcn_contract_fwd_mean_supported(B, M, Fin, K, Fout))
+        return fail(CHEBGCN_EUNSUPPORTED, "contract_fwd_mean: shape not served (chebgcn_contract_fwd_mean_supported)");
+    FwdArgs a;
+    a.stack = stack; a.W = W; a.bias = bias; a.out = nullptr; a.argmax = nullptr;
+    a.relu_mask = relu_mask; a.mean_out = mean_out;
+    a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
+    a.pool = 1; a.pool_kind = CHEBGCN_POOL_MAX; a.relu = 1; a.bias_kind = bias_kind;
+    a.Mo = M; a.Mpo = a.Mp;
+    a.slab = (size_t)B * Fin * a.Mp;
+    const int nrows_pad = ring_rows(a.FinK);
+    hipLaunchKernelGGL(contract_fwd_ring_kernel, dim3((M + 511) / 512, B, 1), dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
 static int launch_bwd_x(const float* dy, const uint8_t* mask, const float* W, float* gstack, int B, int M, int Fin, int K,
-                        int Fout, hipStream_t stream) {
+                        int Fout, hipStream_t stream, bool one_plane = false) {
     BwdXArgs a;
     a.dy = dy; a.W = W; a.gstack = gstack; a.mask = mask;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
     a.slab = (size_t)B * Fin * a.Mp;
+    a.dy_bstride = one_plane ? (size_t)a.Mp : (size_t)Fout * a.Mp;
+    a.dy_fstride = one_plane ? 0 : (size_t)a.Mp;
     if (small_launch(B, M)) {
         dim3 sgrid((M + 127) / 128, B, 1);
         if (mask) {
@@ -851,6 +893,13 @@ extern "C" int chebgcn_contract_bwd_x_relu(const float* dout, const uint8_t* rel
     return launch_bwd_x(dout, relu_mask, W, gstack, B, M, Fin, K, Fout, (hipStream_t)stream_);
 }
 
+extern "C" int chebgcn_contract_bwd_x_relu_mean(const float* gmean, const uint8_t* relu_mask, const float* W, float* gstack,
+                                                int B, int M, int Fin, int K, int Fout, chebgcn_stream stream_) {
+    CG_REQUIRE(gmean && relu_mask && W && gstack, "contract_bwd_x_relu_mean: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0 && B <= 65535, "contract_bwd_x_relu_mean: bad shape");
+    return launch_bwd_x(gmean, relu_mask, W, gstack, B, M, Fin, K, Fout, (hipStream_t)stream_, true);
+}
+
 extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K, int Fout) {
     if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
     const int ntiles = (Fin * K + 31) / 32, rt = bw_rt(ntiles);
@@ -859,10 +908,12 @@ extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K,
 }
 
 static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask, float* dW, void* workspace, int B, int M,
-                        int Fin, int K, int Fout, hipStream_t stream) {
+                        int Fin, int K, int Fout, hipStream_t stream, bool one_plane = false) {
     BwdWArgs a;
     a.stack = stack; a.dy = dy; a.partial = (float*)workspace; a.mask = mask;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
+    a.dy_bstride = one_plane ? (size_t)a.Mp : (size_t)Fout * a.Mp;
+    a.dy_fstride = one_plane ? 0 : (size_t)a.Mp;
     a.nchunks_m = (M + 63) / 64;
     a.ntiles = (a.FinK + 31) / 32;
     a.slab = (size_t)B * Fin * a.Mp;
@@ -897,6 +948,16 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
                        gy, rt, a.FinK, Fout);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_contract_bwd_w_relu_mean(const float* stack, const float* gmean, const uint8_t* relu_mask, float* dW,
+                                                void* workspace, size_t workspace_bytes, int B, int M, int Fin, int K,
+                                                int Fout, chebgcn_stream stream_) {
+    CG_REQUIRE(stack && gmean && relu_mask && dW && workspace, "contract_bwd_w_relu_mean: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w_relu_mean: bad shape");
+    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout),
+               "contract_bwd_w_relu_mean: workspace too small");
+    return launch_bwd_w(stack, gmean, relu_mask, dW, workspace, B, M, Fin, K, Fout, (hipStream_t)stream_, true);
 }
 
 extern "C" int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void* workspace,

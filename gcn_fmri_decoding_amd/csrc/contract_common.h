@@ -29,6 +29,9 @@ struct FwdArgs {
     // [B][Fout][Mp/4] -- all the gradient kernels need of the forward result (the ReluGrad of the
     // reference's autodiff folded into chebgcn_contract_bwd_*_relu)
     uint8_t* relu_mask = nullptr;
+    // mean over the filters of the (bias + ReLU) result, [B][Mp] (tf.reduce_mean(x, -1), models_gcn.py:673, fused into the
+    // last layer's epilogue: contract_fwd_ring_kernel only); `out` may then be NULL (the layer output itself is not stored)
+    float* mean_out = nullptr;
 };
 
 // Epilogue of one filter row for the four vertices n0..n0+3 held by lane c of a half-wave:
@@ -63,7 +66,7 @@ __device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo
     uint8_t* arow = a.argmax ? a.argmax + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo : nullptr;
     if (p == 1) {
         if (fo_ok && valid) {
-            *reinterpret_cast<float4*>(orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.out) *reinterpret_cast<float4*>(orow + n0) = make_float4(v[0], v[1], v[2], v[3]);
             if (a.relu_mask)
                 a.relu_mask[((size_t)b * a.Fout + fo) * (a.Mpo >> 2) + (n0 >> 2)] =
                     (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));

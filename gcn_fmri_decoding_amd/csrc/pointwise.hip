@@ -80,7 +80,8 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
 template <int BIAS>
 __global__ void __launch_bounds__(256)
 bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dy,
-                      float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F) {
+                      float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F,
+                      size_t d_bstride, size_t d_fstride) {      // element strides of dout: F*Mp and Mp, or Mp and 0 (one plane per window)
     __shared__ float4 psum[256];
     const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int Mq = Mp >> 2;
@@ -89,12 +90,12 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
     const bool live = q < Mq;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
-        const float* gp = dout + (size_t)f * Mp + 4 * q;
+        const float* gp = dout + (size_t)f * d_fstride + 4 * q;
         const uint8_t* mp = mask + (size_t)f * Mq + q;
 #pragma unroll 4
         for (int b = part; b < B; b += 4) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * F * Mp));
+            const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride));
             const int bits = mp[(size_t)b * F * Mq];
             const float4 d = make_float4((bits & 1) ? g.x : 0.f, (bits & 2) ? g.y : 0.f, (bits & 4) ? g.z : 0.f,
                                          (bits & 8) ? g.w : 0.f);
@@ -339,13 +340,13 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
         const dim3 grid(nblk, F);
         if (bias_kind == CHEBGCN_BIAS_FILTER) {
             hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
-                               B, M, Mp, F);
+                               B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);
         } else if (bias_kind == CHEBGCN_BIAS_VERTEX) {
             hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
-                               B, M, Mp, F);
+                               B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);
         } else {
             hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_NONE>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
-                               B, M, Mp, F);
+                               B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);
         }
     } else {
 #define CG_BRELU(BK, PARTS)                                                                                       \
@@ -368,6 +369,30 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
         hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
         CG_HIP(hipGetLastError());
     }
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* relu_mask, float* dbias, int bias_kind, int B, int M,
+                                           int F, void* workspace, size_t workspace_bytes, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(gmean && relu_mask && dbias, "bias_grad_relu_mean: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "bias_grad_relu_mean: bad shape");
+    CG_REQUIRE(bias_kind == CHEBGCN_BIAS_FILTER || bias_kind == CHEBGCN_BIAS_VERTEX, "bias_grad_relu_mean: bad bias kind");
+    const int Mp = plane_stride(M);
+    const int nblk = brelu_bwd_blocks(M, F, 1, 1, true, nullptr);
+    float* fpart = nullptr;
+    if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        CG_REQUIRE(workspace && workspace_bytes >= (size_t)F * nblk * sizeof(float),
+                   "bias_grad_relu_mean: the per-filter bias gradient needs a workspace of chebgcn_brelu_pool_bwd_workspace() bytes");
+        fpart = static_cast<float*>(workspace);
+        hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
+                           (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+        hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
+    } else {
+        hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
+                           (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+    }
+    CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
 

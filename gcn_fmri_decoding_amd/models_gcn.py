@@ -650,6 +650,9 @@ class cgcnn(base_model):
         # 'bf16x3' (bf16 matrix cores for wide layers); not a reference keyword -- set it on the instance.  It is
         # part of the checkpoint's architecture record: a model rebuilt from a checkpoint computes as it was trained
         self.contraction = 'f32'
+        # last conv layer + tf.reduce_mean(x, -1) (:673) in one kernel where the shape allows (ops.conv_mean_supported);
+        # False keeps the two separate (same values up to the order of the sum over the filters)
+        self.fuse_feature_mean = os.environ.get('CHEBGCN_FUSE_MEAN', '1') != '0'
         self.filter = getattr(self, filter)
         self.brelu = getattr(self, brelu)
         self.pool = getattr(self, pool)
@@ -827,12 +830,18 @@ class cgcnn(base_model):
             # training: the layer's gradients go straight into the flat (zeroed) gradient buffer
             direct = self.training_mode and W.grad is not None and b.grad is not None and torch.is_grad_enabled()
             done = (lambda layer=i + 1: self._dp.layer_done(layer)) if (direct and self._dp is not None) else None
+            # the last layer feeds tf.reduce_mean(x, -1) (:673) only: where the kernel can, it returns that mean and never
+            # stores its own output; its gradients read one plane per window
+            mean = bool(i + 1 == nl and self.fuse_feature_mean and
+                        ops.conv_mean_supported(B, g.M, x.shape[1], self.K[i], self.F[i], self.p[i], True, self.contraction))
             x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
                               BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out,
                               dW=W.grad if direct else None, dbias=b.grad if direct else None,
-                              precision=self.contraction, done=done)
+                              precision=self.contraction, done=done, mean=mean)
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
+        if mean:
+            return self._head(x[:, :M_last], dropout)
         return self._head(ops.FeatureMean.apply(x, M_last), dropout)
 
     def _head(self, x, dropout):

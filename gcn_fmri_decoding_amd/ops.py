@@ -327,6 +327,25 @@ class ChebConv(torch.autograd.Function):
         _lib.check(_launch('recurrence_fwd', 4.0 * M * Fin * K * B, 0.0, lambda: lib.chebgcn_recurrence_fwd(
             graph.handle, _p(x), _p(stack), B, Fin, K, _stream())), 'recurrence_fwd')
         Mo = M // pool
+        mean = bool(bufs is not None and bufs.mean)
+        if mean:
+            if not conv_mean_supported(B, M, Fin, K, Fout, pool, relu, getattr(bufs, 'precision', 'f32')):
+                raise ValueError('cheb_conv(mean=True): layer not served (ops.conv_mean_supported)')
+            wants_grad = any(ctx.needs_input_grad[:3])
+            mask = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device) if wants_grad else None
+            y = torch.empty((B, Mp), dtype=torch.float32, device=x.device)
+            b = bias.detach().contiguous() if bias is not None else None
+            _lib.check(_launch('contract_fwd', 4.0 * B * M * (Fin * K + 1), 2.0 * B * M * Fin * K * Fout,
+                               lambda: lib.chebgcn_contract_fwd_mean(_p(stack), _p(Wc), _p(b), bias_kind, _p(y), _p(mask), B, M,
+                                                                     Fin, K, Fout, _stream())), 'contract_fwd_mean')
+            ctx.save_for_backward(stack, Wc, None, mask)
+            ctx.fold, ctx.mean = True, True
+            ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
+            ctx.bias_shape = None if bias is None else tuple(bias.shape)
+            ctx.grad_bufs = (bufs.dW, bufs.dbias)
+            ctx.done = bufs.done
+            ctx.precision = 'f32'
+            return y
         if out is None:
             out = plane_empty(B, Fout, Mo, x.device)
         else:
@@ -349,7 +368,7 @@ class ChebConv(torch.autograd.Function):
             b = b.contiguous()
         contract_fwd_into(stack, Wc, b, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision)
         ctx.save_for_backward(stack, Wc, None if (pool == 1 and relu) else out, argmax)
-        ctx.fold = fold
+        ctx.fold, ctx.mean = fold, False
         ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
@@ -364,7 +383,9 @@ class ChebConv(torch.autograd.Function):
         dW_buf, dbias_buf = ctx.grad_bufs
         B, M, Fin, K, Fout, pool, pool_kind, relu, bias_kind = ctx.cfg
         g = ctx.graph
-        gout = gout.contiguous()
+        mean = ctx.mean
+        # mean: every filter's dy is gout / Fout, one plane per window (zero in the padding: the head reads [:, :M])
+        gout = (gout * (1.0 / Fout)).contiguous() if mean else gout.contiguous()
         dev = gout.device
         fold = ctx.fold
         dbias = None
@@ -385,6 +406,10 @@ class ChebConv(torch.autograd.Function):
                 # for) -- 3.88 against 3.93 ms per step at the bench shape; on the second stream it costs 4 %
                 def bias_job():
                     bws, nbws = _brelu_bwd_ws(B, M, Fout, 1, bias_kind, dev)
+                    if mean:
+                        _lib.check(_launch('bias_grad', B * M * (4.0 + Fout * 0.25), 0.0, lambda: lib.chebgcn_bias_grad_relu_mean(
+                            _p(gout), _p(mask), _p(dbias), bias_kind, B, M, Fout, _p(bws), nbws, _stream())), 'bias_grad_relu_mean')
+                        return
                     _lib.check(_launch('bias_grad', B * Fout * M * (4.0 + 0.25), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
                         _p(gout), None, _p(mask), None, _p(dbias), bias_kind, B, M, Fout, 1, pool_kind, 1, _p(bws), nbws,
                         _stream())), 'brelu_pool_bwd')
@@ -415,6 +440,9 @@ class ChebConv(torch.autograd.Function):
                 if passes:
                     call = lambda: lib.chebgcn_contract_bwd_w_bf16(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
                                                                    K, Fout, passes, _stream())
+                elif fold and mean:
+                    call = lambda: lib.chebgcn_contract_bwd_w_relu_mean(_p(stack), _p(dy), _p(mask), _p(dW), _p(ws), ws.numel(),
+                                                                        B, M, Fin, K, Fout, _stream())
                 elif fold:
                     call = lambda: lib.chebgcn_contract_bwd_w_relu(_p(stack), _p(dy), _p(mask), _p(dW), _p(ws), ws.numel(), B,
                                                                    M, Fin, K, Fout, _stream())
@@ -445,6 +473,10 @@ class ChebConv(torch.autograd.Function):
                 _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
                                    lambda: lib.chebgcn_contract_bwd_x_bf16(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
                                                                            passes, _p(wsx), nws, _stream())), what)
+            elif fold and mean:
+                _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + 1), 2.0 * B * M * Fin * K * Fout,
+                                   lambda: lib.chebgcn_contract_bwd_x_relu_mean(_p(dy), _p(mask), _p(Wc), _p(gstack), B, M, Fin,
+                                                                                K, Fout, _stream())), 'contract_bwd_x_relu_mean')
             elif fold:
                 _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
                                    lambda: lib.chebgcn_contract_bwd_x_relu(_p(dy), _p(mask), _p(Wc), _p(gstack), B, M, Fin, K,
@@ -475,21 +507,31 @@ class Buffers:
     does not accumulate: one use of a variable per step) in place of returning the gradients to
     autograd -- the model hands over views of its flat gradient buffer and saves an add per
     variable and step.  ``done``: called at the end of the layer's backward, once its gradient
-    kernels are enqueued (dist.DataParallel starts the layer's all-reduce from it)."""
-    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done')
+    kernels are enqueued (dist.DataParallel starts the layer's all-reduce from it).  ``mean``: the
+    layer is followed by ``tf.reduce_mean(x, -1)`` (models_gcn.py:673) and returns that mean, storage
+    [B, Mp], instead of its output (chebgcn_contract_fwd_mean; the gradients read one plane per window)."""
+    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean')
 
-    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None):
+    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False):
         self.stack, self.out, self.dW, self.dbias, self.precision, self.done = stack, out, dW, dbias, precision, done
+        self.mean = mean          # the layer returns the mean over its filters, [B, Mp] (see conv_mean_supported)
+
+
+def conv_mean_supported(B, M, Fin, K, Fout, pool, relu, precision='f32'):
+    """Can ``cheb_conv(..., mean=True)`` serve this layer?  (pool 1, ReLU, fp32 contraction, a shape of the ring kernel.)"""
+    return bool(fold_relu_grad and pool == 1 and relu and precision == 'f32'
+                and _lib.lib().chebgcn_contract_fwd_mean_supported(B, M, Fin, K, Fout))
 
 
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
-              dW=None, dbias=None, precision='f32', done=None):
+              dW=None, dbias=None, precision='f32', done=None, mean=False):
     """``precision``: arithmetic of the contraction and of its two gradients ('f32', 'bf16', 'bf16x3':
     chebgcn_contract_fwd_bf16 / _bwd_x_bf16 / _bwd_w_bf16 with 1 or 3 passes); storage, the recurrence, its adjoint
     and the bias / ReLU / pooling gradients stay fp32."""
     bufs = None
-    if stack is not None or out is not None or dW is not None or dbias is not None or precision != 'f32' or done is not None:
-        bufs = Buffers(stack, out, dW, dbias, precision, done)
+    if (stack is not None or out is not None or dW is not None or dbias is not None or precision != 'f32' or done is not None
+            or mean):
+        bufs = Buffers(stack, out, dW, dbias, precision, done, mean)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 

@@ -187,6 +187,31 @@ int chebgcn_contract_bwd_x_relu(const float* dout, const uint8_t* relu_mask, con
 int chebgcn_contract_bwd_x(const float* dy, const float* W, float* gstack, int B, int M,
                            int Fin, int K, int Fout, chebgcn_stream stream);
 
+/* ---- last conv layer + tf.reduce_mean(x, -1) (models_gcn.py:673) in one pass ----------------
+ * The mean over the filters of the layer's (bias + ReLU) result is all the head reads (models_gcn.py:671-674), so the
+ * last layer need not store its [B][Fout][Mp] output at all:
+ *   chebgcn_contract_fwd_mean: mean_out[b][m] = (1/Fout) sum_o relu(y[b][o][m] + bias), [B][Mp]; relu_mask as
+ *     chebgcn_contract_fwd writes it (may be NULL for inference).  pool = 1, ReLU.  Served where
+ *     chebgcn_contract_fwd_mean_supported() returns 1 (Fout <= 32, a big launch, Fin*K*136 bytes <= 48 KB);
+ *     CHEBGCN_EUNSUPPORTED otherwise (run chebgcn_contract_fwd + chebgcn_feature_mean_fwd).
+ *   backward: d(loss)/d(y[b][o][m]) = gmean[b][m] for EVERY filter o, gmean = d(loss)/d(mean) / Fout, [B][Mp] (zero in the
+ *     padding): the three gradients of a ReLU-folded layer read that one plane per window instead of a [B][Fout][Mp]
+ *     tensor -- the _mean forms of chebgcn_contract_bwd_w_relu / _bwd_x_relu and of the bias reduction
+ *     chebgcn_brelu_pool_bwd(dout, NULL, relu_mask, NULL, dbias, ...). */
+int chebgcn_contract_fwd_mean_supported(int B, int M, int Fin, int K, int Fout);
+int chebgcn_contract_fwd_mean(const float* stack, const float* W, const float* bias, int bias_kind,
+                              float* mean_out, uint8_t* relu_mask, int B, int M, int Fin, int K, int Fout,
+                              chebgcn_stream stream);
+int chebgcn_contract_bwd_w_relu_mean(const float* stack, const float* gmean, const uint8_t* relu_mask,
+                                     float* dW, void* workspace, size_t workspace_bytes, int B, int M,
+                                     int Fin, int K, int Fout, chebgcn_stream stream);
+int chebgcn_contract_bwd_x_relu_mean(const float* gmean, const uint8_t* relu_mask, const float* W,
+                                     float* gstack, int B, int M, int Fin, int K, int Fout,
+                                     chebgcn_stream stream);
+int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* relu_mask, float* dbias, int bias_kind,
+                                int B, int M, int F, void* workspace, size_t workspace_bytes,
+                                chebgcn_stream stream);
+
 /* ---- layout / staging -----------------------------------------------------------
  * perm_data: coarsening.perm_data_3d (lib_new/coarsening.py:244-265) fused with the
  * fp32 cast and batch gather of fit() (models_gcn.py:138-146):

@@ -513,3 +513,64 @@ def test_contraction_big_launch_edges(ops, dev, B, M, Fin, K, Fout, bias_kind, r
     assert err <= GREL, 'contract_bwd_x: %.3e' % err
     # nothing was written beyond the planes: the next plane's first columns would be hit first
     assert bool(torch.isfinite(gstack[..., :M]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,M,Fin,K,Fout,bias_kind', [(64, 10466, 32, 5, 32, 'vertex'), (256, 1050, 15, 5, 24, 'filter')])
+def test_last_layer_with_feature_mean(ops, dev, B, M, Fin, K, Fout, bias_kind):
+    """chebgcn_contract_fwd_mean and the three ``_mean`` gradients (the last conv layer fused with tf.reduce_mean(x, -1),
+    models_gcn.py:673) against float64: mean of relu(y + bias) over the filters; dW, dstack, dbias for dy[b][o][m] =
+    gmean[b][m] gated by the ReLU mask."""
+    import ctypes
+    from gcn_fmri_decoding_amd import _lib
+    lib = _lib.lib()
+    assert lib.chebgcn_contract_fwd_mean_supported(B, M, Fin, K, Fout) == 1
+    assert lib.chebgcn_contract_fwd_mean_supported(2, 380, Fin, K, Fout) == 0         # a small launch: not served
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B + M)
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    stack[..., M:] = float('nan')
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * 0.1
+    if bias_kind == 'vertex':
+        kind = ops.BIAS_VERTEX
+        bias = torch.zeros((Fout, Mp), device=dev)
+        bias[:, :M] = torch.randn((Fout, M), generator=gen, device=dev) * 0.3
+        bias_ref = bias[:, :M].double()
+    else:
+        kind = ops.BIAS_FILTER
+        bias = torch.randn((Fout,), generator=gen, device=dev) * 0.3
+        bias_ref = bias.double()[:, None]
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mean = torch.full((B, Mp), float('nan'), device=dev)
+    mask = torch.zeros((B, Fout, Mp // 4), dtype=torch.uint8, device=dev)
+    _lib.check(lib.chebgcn_contract_fwd_mean(P(stack), P(W), P(bias), kind, P(mean), P(mask), B, M, Fin, K, Fout, st), 'fwd_mean')
+    S = stack[..., :M].permute(2, 0, 1, 3).reshape(Fin * K, B, M).double()
+    pre = torch.einsum('rbm,ro->bom', S, W.double()) + bias_ref
+    ref = pre.clamp(min=0).mean(1)
+    assert float((mean[:, :M].double() - ref).abs().max() / pre.abs().max()) <= REL
+    bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, Fout, Mp)[..., :M].bool()
+    assert torch.equal(bits, pre > 0) or float(((bits != (pre > 0)) & (pre.abs() > 1e-5 * pre.abs().max())).sum()) == 0
+
+    gm = torch.zeros((B, Mp), device=dev)
+    gm[:, :M] = torch.randn((B, M), generator=gen, device=dev)
+    dy = (gm[:, None, :M] * bits).double()
+    n = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    dW = torch.full((Fin * K, Fout), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_w_relu_mean(P(stack), P(gm), P(mask), P(dW), P(ws), n, B, M, Fin, K, Fout, st), 'bwd_w_mean')
+    dW_ref = torch.einsum('rbm,bom->ro', S, dy)
+    assert float((dW.double() - dW_ref).abs().max() / dW_ref.abs().max()) <= GREL
+    del S
+    gstack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_x_relu_mean(P(gm), P(mask), P(W), P(gstack), B, M, Fin, K, Fout, st), 'bwd_x_mean')
+    gs_ref = torch.einsum('ro,bom->rbm', W.double(), dy).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    assert float((gstack[..., :M].double() - gs_ref).abs().max() / gs_ref.abs().max()) <= GREL
+    nb = lib.chebgcn_brelu_pool_bwd_workspace(B, M, Fout, 1, kind)
+    bws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    dbias = torch.full(tuple(bias.shape), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_bias_grad_relu_mean(P(gm), P(mask), P(dbias), kind, B, M, Fout, P(bws), nb, st), 'bias_mean')
+    db_ref = dy.sum(0) if bias_kind == 'vertex' else dy.sum((0, 2))
+    got = dbias[:, :M].double() if bias_kind == 'vertex' else dbias.double()
+    assert float((got - db_ref).abs().max() / db_ref.abs().max()) <= GREL
