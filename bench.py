@@ -374,7 +374,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=64, help='windows per GPU')
     ap.add_argument('--nodes', type=int, default=10000)
     ap.add_argument('--korder', type=int, default=5)
