@@ -2,6 +2,8 @@
 training step captured as one HIP graph against the eager step, and the full network at the shape the reference's
 own ``training.py`` builds (atlas-sized graph, K = 10 x 6, batch 128) against the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -214,3 +216,25 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
         twin.train_step(xs, ld)
     torch.cuda.synchronize()
     assert net._sg is not None and torch.equal(net._flat, twin._flat)
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_on_stdout():
+    """``python bench.py`` (kernel legs on: the dp_overhead leg brings up an RCCL communicator, which prints a version
+    banner to file descriptor 1): stdout must carry the result line and nothing else."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '3', '--repeats', '1',
+                        '--instrumented-steps', '2', '--cpu-windows', '0'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['n_ranks_seen'] == 1 and line['steps'] == 3
+    for key in ('roofline', 'kernels', 'northstar', 'config4', 'config5', 'dp_overhead', 'refshape'):        # (cpu_baseline: --cpu-windows 0 here)
+        assert key in line, key
+    assert line['roofline']['bound'] == 'hbm' and 0.2 < line['roofline']['frac'] < 1.0
