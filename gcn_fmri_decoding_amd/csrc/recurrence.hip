@@ -350,13 +350,16 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
         };
         auto finish_step = [&](int sdone, bool last) {
             CG_STAMP(4 * sdone + 0);
+            // adjoint: G_j of the finished step (added after the rotate) is requested as soon as THIS wave's gather is done,
+            // in front of the barrier: its latency runs under the wait for the slower waves and the rotate (0.652 -> 0.634 ms
+            // at batch 256, 0.176 -> 0.172 ms inside the step).  Requested earlier still, with the last levels of the gather
+            // (the wave's own operator requests are all out by then): 0.72 ms.
+            if (ADJ) fetch(src + (size_t)(K - 1 - sdone) * slab, grp);
             __syncthreads();                                    // every gather (and copy-out read) of this step is done
             CG_STAMP(4 * sdone + 1);
             // forward: only now, behind the barrier -- HBM loads queued while other waves still
             // gather would hold up their operator loads (the vector memory pipeline returns in order)
             if (!ADJ && last) fetch_next();
-            // adjoint: G_j of the finished step, added after the rotate
-            if (ADJ) fetch(src + (size_t)(K - 1 - sdone) * slab, grp);
             // ---- rotate: LDS <- T_k, registers <- T_{k-1} of the own rows -----------------
             {
                 Ent<P> prev[NJ];
