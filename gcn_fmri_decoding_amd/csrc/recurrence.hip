@@ -400,7 +400,7 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             }
                 };
         for (int step = 1; step < K; ++step) {
-            if (step > 1) finish_step(step - 1, false);
+            if (ADJ && step > 1) finish_step(step - 1, false);      // (forward: below, behind the first operator requests)
             const float f = ADJ ? (step == K - 1 ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
             // forward: slab step-1 is written out while this step gathers; an isolated vertex has
             // T_k = 0 for odd k and (-1)^(k/2) x for even k
@@ -476,6 +476,11 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
                 for (int q = 0; q < QMAX; ++q) request(jj, q);
             }
+            // forward: the operator records of the first two row groups are requested BEFORE the previous step is closed
+            // (barrier, rotate, barrier), their L2 latency runs under it: 0.576 -> 0.568 ms at batch 256, 0.127 -> 0.125 ms
+            // inside the step.  The adjoint, whose staging registers are live across that phase, spills 14 registers
+            // with it (0.61 -> 0.645 ms) and closes the step first.
+            if (!ADJ && step > 1) finish_step(step - 1, false);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 // the linear pieces of the previous slab go out with the last NQ levels, when the
