@@ -151,6 +151,7 @@ contract_fwd_kernel(FwdArgs a) {
 #ifndef CG_FWD_RING
 #define CG_FWD_RING 8
 #endif
+constexpr int FILL_U = 8;        // W -> LDS: loads in flight per thread
 #if CG_FWD_RING
 constexpr int RING = CG_FWD_RING;
 
@@ -162,9 +163,20 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
     extern __shared__ __align__(16) unsigned char ring_smem[];
     long long* roff = reinterpret_cast<long long*>(ring_smem);                    // [nrows_pad] element offset of row kk
     float* Ws = reinterpret_cast<float*>(ring_smem + (size_t)nrows_pad * 8);       // [nrows_pad][32]
-    for (int idx = threadIdx.x; idx < nrows_pad * 32; idx += 256) {
-        const int kk = idx >> 5, fo = idx & 31;
-        Ws[idx] = (kk < a.FinK && fo < a.Fout) ? a.W[(size_t)kk * a.Fout + fo] : 0.f;
+    // (eight loads in flight per thread: written as one load and one LDS store per iteration, hipcc waits for every load
+    // before its store -- 20 serial L2 round trips per workgroup at Fin*K = 160)
+    for (int i0 = threadIdx.x; i0 < nrows_pad * 32; i0 += 256 * FILL_U) {
+        float w[FILL_U];
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) {
+            const int idx = i0 + 256 * u, kk = idx >> 5, fo = idx & 31;
+            const bool live = kk < a.FinK && fo < a.Fout;
+            const float v = a.W[live ? (size_t)kk * a.Fout + fo : 0];       // unconditional load on a clamped address
+            w[u] = live ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u)
+            if (i0 + 256 * u < nrows_pad * 32) Ws[i0 + 256 * u] = w[u];
     }
     for (int kk = threadIdx.x; kk < nrows_pad; kk += 256) {
         const int kc = kk < a.FinK ? kk : a.FinK - 1;
@@ -472,9 +484,20 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
         // plane the accumulator is dropped by ok[r])
         mword[j] = MASK ? *reinterpret_cast<const int*>(mkb + (size_t)foc * Mq) : -1;
     }
-    for (int idx = threadIdx.x; idx < nrows32 * 32; idx += 256) {
-        const int kk = idx >> 5, fo = idx & 31;
-        Wt[fo * nrows32 + kk] = (kk < a.FinK && fo < a.Fout) ? a.W[(size_t)kk * a.Fout + fo] : 0.f;
+    for (int i0 = threadIdx.x; i0 < nrows32 * 32; i0 += 256 * FILL_U) {     // (eight loads in flight: see contract_fwd_ring_kernel)
+        float w[FILL_U];
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) {
+            const int idx = i0 + 256 * u, kk = idx >> 5, fo = idx & 31;
+            const bool live = kk < a.FinK && fo < a.Fout;
+            const float v = a.W[live ? (size_t)kk * a.Fout + fo : 0];
+            w[u] = live ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FILL_U; ++u) {
+            const int idx = i0 + 256 * u;
+            if (idx < nrows32 * 32) Wt[(idx & 31) * nrows32 + (idx >> 5)] = w[u];
+        }
     }
     for (int kk = threadIdx.x; kk < nrows32; kk += 256) {
         const int kc = kk < a.FinK ? kk : a.FinK - 1;
