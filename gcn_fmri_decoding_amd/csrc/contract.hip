@@ -733,7 +733,19 @@ reduce_partials_stage1(const float* __restrict__ partial, float* __restrict__ st
     const int y = blockIdx.y / BW_SPLIT, sp = blockIdx.y % BW_SPLIT, z = blockIdx.z;
     const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
     float s = 0.f;
-    for (int x = sp + BW_SPLIT * part; x < nx; x += 4 * BW_SPLIT) s += base[(size_t)x * per];
+    // eight partials in flight, added in the order they are indexed (as one load per iteration hipcc waits for each load
+    // before the add: 24 serial round trips per thread at 768 partials)
+    for (int x0 = sp + BW_SPLIT * part; x0 < nx; x0 += 8 * 4 * BW_SPLIT) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = x0 + u * 4 * BW_SPLIT;
+            v[u] = base[(size_t)(x < nx ? x : x0) * per];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (x0 + u * 4 * BW_SPLIT < nx) s += v[u];
+    }
     red[part][lane] = s;
     __syncthreads();
     if (part == 0)

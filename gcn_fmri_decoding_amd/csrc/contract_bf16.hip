@@ -594,7 +594,17 @@ bwb_reduce_stage1(const float* __restrict__ partial, float* __restrict__ stage, 
     const int y = blockIdx.y / BWB_SPLIT, sp = blockIdx.y % BWB_SPLIT, z = blockIdx.z;
     const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
     float s = 0.f;
-    for (int x = sp + BWB_SPLIT * part; x < nx; x += 4 * BWB_SPLIT) s += base[(size_t)x * per];
+    for (int x0 = sp + BWB_SPLIT * part; x0 < nx; x0 += 8 * 4 * BWB_SPLIT) {      // eight partials in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = x0 + u * 4 * BWB_SPLIT;
+            v[u] = base[(size_t)(x < nx ? x : x0) * per];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (x0 + u * 4 * BWB_SPLIT < nx) s += v[u];
+    }
     red[part][lane] = s;
     __syncthreads();
     if (part == 0)

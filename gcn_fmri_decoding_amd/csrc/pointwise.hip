@@ -226,7 +226,14 @@ feature_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int 
     if (m >= M) return;
     const float* p = x + (size_t)b * F * Mp + m;
     float s = 0.f;
-    for (int f = 0; f < F; ++f) s += p[(size_t)f * Mp];
+    for (int f0 = 0; f0 < F; f0 += 8) {               // eight planes in flight, added in filter order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(f0 + u < F ? f0 + u : f0) * Mp];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (f0 + u < F) s += v[u];
+    }
     y[(size_t)b * M + m] = s / (float)F;
 }
 
