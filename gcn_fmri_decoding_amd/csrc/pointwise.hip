@@ -179,18 +179,36 @@ __global__ void __launch_bounds__(256)
 perm_data_kernel(const float* __restrict__ x, const int32_t* __restrict__ perm,
                  const int32_t* __restrict__ sample, float* __restrict__ out, int N, int M, int Mp, int F) {
     extern __shared__ float tile[];                     // [F][65]
+    __shared__ int nodes[64];                           // source vertex of the block's 64 columns (N: none -> 0)
     const int s = blockIdx.y;
     const int i0 = blockIdx.x * 64;
     const size_t src = (size_t)(sample ? sample[s] : s) * N * F;
-    for (int e = threadIdx.x; e < 64 * F; e += 256) {
-        const int j = e / F, f = e - j * F;
-        const int i = i0 + j;
-        float v = 0.f;
-        if (i < M) {
-            const int node = perm ? perm[i] : i;
-            if (node < N) v = x[src + (size_t)node * F + f];
+    if (threadIdx.x < 64) {
+        const int i = i0 + threadIdx.x;
+        const int node = i < M ? (perm ? perm[i] : i) : N;
+        nodes[threadIdx.x] = node < N ? node : N;
+    }
+    __syncthreads();
+    // four gathers in flight per thread (one load, one LDS store per iteration compiles to a full wait per element,
+    // behind the index load it depends on)
+    for (int e0 = threadIdx.x; e0 < 64 * F; e0 += 4 * 256) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u, ec = e < 64 * F ? e : 0;
+            const int j = ec / F, f = ec - j * F;
+            const int node = nodes[j];
+            const float t = x[src + (size_t)(node < N ? node : 0) * F + f];        // unconditional load on a clamped address
+            v[u] = node < N ? t : 0.f;
         }
-        tile[f * 65 + j] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < 64 * F) {
+                const int j = e / F, f = e - j * F;
+                tile[f * 65 + j] = v[u];
+            }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * F; e += 256) {
