@@ -225,25 +225,47 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
         }
     }
     // last round; with a per-vertex bias, slot u takes the bias of accumulator row j = u as it falls free
-    const bool vb = a.bias_kind == CHEBGCN_BIAS_VERTEX;
+    // The bias loads are UNCONDITIONAL: behind a branch hipcc cannot count them and waits for every load in flight
+    // (s_waitcnt vmcnt(0)) before each of the last round's matrix blocks and at every row of the epilogue -- sixteen serial
+    // round trips at the end of every tile.  One form serves the three kinds: per vertex, the 16 bytes of the lane's four
+    // vertices in row fo; per filter, the 16 bytes around bias[fo] (four-byte aligned, inside the array: the launcher sends
+    // Fout < 4 to the kernel above) with the component picked afterwards; no bias: the first bytes of the stack, ignored.
+    const bool vb = a.bias_kind == CHEBGCN_BIAS_VERTEX, fbk = a.bias_kind == CHEBGCN_BIAS_FILTER;
+    const float* bsrc = (vb || fbk) ? a.bias : a.stack;
+    const size_t bpitch = vb ? (size_t)a.Mp : fbk ? 1 : 0;
+    const int blane = vb ? (valid ? n0 : 0) : 0;
+    auto bias_base = [&](int fo) { return fbk ? (fo < a.Fout - 4 ? fo : a.Fout - 4) : (fo < a.Fout ? fo : 0); };
     auto bias_row = [&](int j) __attribute__((always_inline)) -> float4 {
-        const int fo = acc_row(j, h);
-        const float* p = a.bias + (size_t)(fo < a.Fout ? fo : 0) * a.Mp + (valid ? n0 : 0);
-        return *reinterpret_cast<const float4*>(p);
+        const float* p = bsrc + (size_t)bias_base(acc_row(j, h)) * bpitch + blane;
+        typedef f32x4 f32x4_a4 __attribute__((aligned(4)));           // (a cached load: the bias is re-read by every window)
+        const f32x4 t = *reinterpret_cast<const f32x4_a4*>(p);
+        return make_float4(t.x, t.y, t.z, t.w);
     };
 #pragma unroll
     for (int u = 0; u < RING; ++u) {
         step(u);
-        if (vb) bv[u] = bias_row(u);
+        bv[u] = bias_row(u);
     }
+    FwdArgs ae = a;                                  // the row epilogue below runs without a bias of its own
+    ae.bias_kind = CHEBGCN_BIAS_NONE;
     // ---- epilogue: bias, relu, pool, store ----------------------------------------------
     float ms[4] = {0.f, 0.f, 0.f, 0.f};              // mean_out: sum over this lane's 16 filter rows (after bias + ReLU)
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int fo = acc_row(j, h);
         float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-        fwd_epilogue_row(a, b, fo, v, n0, valid, c, vb, bv[j % RING]);
-        if (vb && j + RING < 16) bv[j % RING] = bias_row(j + RING);
+        {
+            const float4 bb = bv[j % RING];
+            const int sel = fo - bias_base(fo);      // per filter: which of the four loaded values is bias[fo]
+            const float f = sel == 0 ? bb.x : sel == 1 ? bb.y : sel == 2 ? bb.z : bb.w;
+            const bool fo_ok = fo < a.Fout;
+            v[0] += vb ? bb.x : (fbk && fo_ok) ? f : 0.f;
+            v[1] += vb ? bb.y : (fbk && fo_ok) ? f : 0.f;
+            v[2] += vb ? bb.z : (fbk && fo_ok) ? f : 0.f;
+            v[3] += vb ? bb.w : (fbk && fo_ok) ? f : 0.f;
+        }
+        fwd_epilogue_row(ae, b, fo, v, n0, valid, c);
+        if (j + RING < 16) bv[j % RING] = bias_row(j + RING);
         if (fo < a.Fout) { ms[0] += v[0]; ms[1] += v[1]; ms[2] += v[2]; ms[3] += v[3]; }
     }
     if (a.mean_out) {                                // + the 16 rows of the other half-wave, / Fout
@@ -832,7 +854,7 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
 #if CG_FWD_RING
         // whole ring rounds of row pairs; W and the row offsets of the padded rows in LDS (136 bytes per row)
         const int nrows_pad = ((a.FinK + 2 * RING - 1) / (2 * RING)) * (2 * RING);
-        if ((size_t)nrows_pad * 136 <= 48 * 1024 && RING <= 8) {
+        if ((size_t)nrows_pad * 136 <= 48 * 1024 && RING <= 8 && (bias_kind != CHEBGCN_BIAS_FILTER || Fout >= 4)) {
             hipLaunchKernelGGL(contract_fwd_ring_kernel, grid, dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
             CG_HIP(hipGetLastError());
             return CHEBGCN_OK;
