@@ -18,6 +18,9 @@
 // r feeds accumulator r (vertex <-> MFMA column is a free permutation).  The A operand
 // (a 32 x 2 sliver of W) is 8 B per lane from L1/L2.
 #include "contract_common.h"
+#ifndef CG_DY_NT
+#define CG_DY_NT 0      // dy is read by three kernels of a layer's backward (bias, bwd_w, bwd_x): cached loads, 3.83 -> 3.795 ms per step
+#endif
 #include <type_traits>
 
 // Waves per SIMD the register allocation is held to (second __launch_bounds__ argument).  Left alone the
@@ -501,7 +504,8 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
     for (int j = 0; j < 16; ++j) {
         const int fo = 2 * j + h, foc = fo < a.Fout ? fo : 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hold[j][r] = __builtin_nontemporal_load(dyb + (size_t)foc * a.dy_fstride + (ok[r] ? 32 * r : 0));
+        for (int r = 0; r < 4; ++r) hold[j][r] = CG_DY_NT ? __builtin_nontemporal_load(dyb + (size_t)foc * a.dy_fstride + (ok[r] ? 32 * r : 0))
+                                                         : dyb[(size_t)foc * a.dy_fstride + (ok[r] ? 32 * r : 0)];
         // (the row's 32 mask bytes exist for every r: planes are padded to 32 vertices and a tile is 4 x 32; beyond the
         // plane the accumulator is dropped by ok[r])
         mword[j] = MASK ? *reinterpret_cast<const int*>(mkb + (size_t)foc * Mq) : -1;
@@ -684,7 +688,8 @@ contract_bwd_w_kernel(BwdWArgs a) {
         for (int u = 0; u < PER_WAVE; ++u) {
             const int n = wave + 4 * u;
             const float* src = rsrc[u] + (n < RT * 8 ? so : dof);
-            __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 2);   // aux 2 = nt: every chunk is read once
+            if (u >= 2 * RT && !CG_DY_NT) __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 0);   // dy rows: cached
+            else __builtin_amdgcn_global_load_lds(src, lds + (size_t)n * 4 * BW_ROW, 16, 0, 2);   // aux 2 = nt: every chunk is read once
         }
         __syncthreads();                                // DMA landed (the barrier's release waits vmcnt(0))
 

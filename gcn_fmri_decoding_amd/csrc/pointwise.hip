@@ -2,6 +2,9 @@
 // input staging (perm_data_3d gather + layout change), the feature mean in front of the
 // FC head, and the Adam update.  All accesses are coalesced along the vertex axis.
 #include "common.h"
+#ifndef CG_DY_NT
+#define CG_DY_NT 0      // see contract.hip
+#endif
 
 namespace chebgcn {
 
@@ -95,7 +98,8 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
 #pragma unroll 4
         for (int b = part; b < B; b += 4) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 g = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride));
+            const f32x4 g = CG_DY_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride))
+                                     : *reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride);
             const int bits = mp[(size_t)b * F * Mq];
             const float4 d = make_float4((bits & 1) ? g.x : 0.f, (bits & 2) ? g.y : 0.f, (bits & 4) ? g.z : 0.f,
                                          (bits & 8) ? g.w : 0.f);
