@@ -841,7 +841,7 @@ class cgcnn(base_model):
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
         if mean:
-            return self._head(x[:, :M_last], dropout)
+            return self._head(x, dropout)              # already the logical [B, M] view of the [B, Mp] means
         return self._head(ops.FeatureMean.apply(x, M_last), dropout)
 
     def _head(self, x, dropout):

@@ -251,6 +251,18 @@ def _workspace(nbytes, device):
     return ws
 
 
+_mean_grad_buffers = {}
+
+
+def _mean_grad_buffer(B, Mp, device):
+    """[B, Mp] scratch of the fused last layer's backward; columns beyond M stay zero (only [:, :M] is ever written)."""
+    key = (B, Mp, device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _mean_grad_buffers.get(key)
+    if buf is None:
+        buf = _mean_grad_buffers[key] = torch.zeros((B, Mp), dtype=torch.float32, device=device)
+    return buf
+
+
 def _brelu_bwd_ws(B, M, F, pool, bias_kind, device):
     """Scratch of chebgcn_brelu_pool_bwd: the per-workgroup partials of a per-filter (b1relu) bias gradient."""
     n = _lib.lib().chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, bias_kind)
@@ -345,7 +357,7 @@ class ChebConv(torch.autograd.Function):
             ctx.grad_bufs = (bufs.dW, bufs.dbias)
             ctx.done = bufs.done
             ctx.precision = 'f32'
-            return y
+            return y[:, :M]                   # the logical [B, M] mean (row stride Mp): its gradient arrives dense
         if out is None:
             out = plane_empty(B, Fout, Mo, x.device)
         else:
@@ -384,8 +396,14 @@ class ChebConv(torch.autograd.Function):
         B, M, Fin, K, Fout, pool, pool_kind, relu, bias_kind = ctx.cfg
         g = ctx.graph
         mean = ctx.mean
-        # mean: every filter's dy is gout / Fout, one plane per window (zero in the padding: the head reads [:, :M])
-        gout = (gout * (1.0 / Fout)).contiguous() if mean else gout.contiguous()
+        if mean:
+            # every filter's dy is gout / Fout, one plane [B][Mp] per window, zero in the padding: scaled into a buffer whose
+            # padding was zeroed once (one kernel per step instead of autograd's zero-fill + copy of a sliced output)
+            gm = _mean_grad_buffer(B, ctx.graph.Mp, gout.device)
+            torch.mul(gout, 1.0 / Fout, out=gm[:, :M])
+            gout = gm
+        else:
+            gout = gout.contiguous()
         dev = gout.device
         fold = ctx.fold
         dbias = None
