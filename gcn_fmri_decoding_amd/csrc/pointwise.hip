@@ -80,15 +80,18 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
 // contraction gradients gate dout themselves (contract_bwd_*_relu) and nothing but dbias is written.
 // thread = four consecutive vertices (one mask byte, one 16-byte load per window) of filter f and
 // one of four interleaved subsets of the batch; fixed-order LDS sum of the four subsets.
-template <int BIAS>
+// NP = 4 subsets of the batch x 64 quads per workgroup, or (small graphs: an atlas-sized layer would give the chip 64 workgroups
+// that each walk the batch in 8 serial rounds) 16 subsets x 16 quads.
+template <int BIAS, int NP = 4>
 __global__ void __launch_bounds__(256)
 bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dy,
                       float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F,
                       size_t d_bstride, size_t d_fstride) {      // element strides of dout: F*Mp and Mp, or Mp and 0 (one plane per window)
     __shared__ float4 psum[256];
-    const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
+    constexpr int QL = 256 / NP;                        // quads per workgroup
+    const int ql = threadIdx.x % QL, part = threadIdx.x / QL;
     const int Mq = Mp >> 2;
-    const int q = blockIdx.x * 64 + ql;
+    const int q = blockIdx.x * QL + ql;
     const int f = blockIdx.y;
     const bool live = q < Mq;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -96,7 +99,7 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
         const float* gp = dout + (size_t)f * d_fstride + 4 * q;
         const uint8_t* mp = mask + (size_t)f * Mq + q;
 #pragma unroll 4
-        for (int b = part; b < B; b += 4) {
+        for (int b = part; b < B; b += NP) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 g = CG_DY_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride))
                                      : *reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride);
@@ -118,15 +121,15 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
     if (part == 0) {
         float4 t = psum[ql];
 #pragma unroll
-        for (int p = 1; p < 4; ++p) {
-            const float4 o = psum[p * 64 + ql];
+        for (int p = 1; p < NP; ++p) {
+            const float4 o = psum[p * QL + ql];
             t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
         }
         if (BIAS == CHEBGCN_BIAS_VERTEX) {
             if (live) *reinterpret_cast<float4*>(dbias + (size_t)f * Mp + 4 * q) = t;
         } else {
             float s = (t.x + t.y) + (t.z + t.w);
-            for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+            for (int d = QL / 2; d > 0; d >>= 1) s += __shfl_xor(s, d);      // the QL lanes of part 0 (QL <= 64: one wave)
             if (ql == 0) fpart[(size_t)f * gridDim.x + blockIdx.x] = s;
         }
     }
@@ -329,8 +332,10 @@ extern "C" int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bia
 static int brelu_bwd_blocks(int M, int F, int pool, int relu, bool have_mask, int* parts_out) {
     const int Mp = plane_stride(M);
     if (pool == 1 && relu && have_mask) {
-        if (parts_out) *parts_out = 0;
-        return (Mp / 4 + 63) / 64;
+        // bias_grad_relu_kernel: 64 quads x 4 batch subsets per workgroup, or 16 x 16 where that leaves the chip short of work
+        const bool fine = ((Mp / 4 + 63) / 64) * F < 512;
+        if (parts_out) *parts_out = fine ? 16 : 4;
+        return fine ? (Mp / 4 + 15) / 16 : (Mp / 4 + 63) / 64;
     }
     // enough workgroups for the chip: small graphs split the batch over 4 or 8 thread groups
     const int parts = ((M + 255) / 256) * F >= 1024 ? 1 : ((M + 63) / 64) * F >= 1024 ? 4 : 8;
@@ -367,16 +372,19 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
     }
     if (pool == 1 && relu && argmax) {                  // ReLU mask of contract_fwd: vertices in fours, dy optional
         const dim3 grid(nblk, F);
-        if (bias_kind == CHEBGCN_BIAS_FILTER) {
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
-                               B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);
-        } else if (bias_kind == CHEBGCN_BIAS_VERTEX) {
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
-                               B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);
-        } else {
-            hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_NONE>, grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart,
-                               B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);
-        }
+#define CG_BGR(BK)                                                                                                         \
+    do {                                                                                                                   \
+        if (parts == 16)                                                                                                   \
+            hipLaunchKernelGGL((bias_grad_relu_kernel<BK, 16>), grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart, B, M, \
+                               Mp, F, (size_t)F * Mp, (size_t)Mp);                                                         \
+        else                                                                                                               \
+            hipLaunchKernelGGL((bias_grad_relu_kernel<BK, 4>), grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart, B, M,  \
+                               Mp, F, (size_t)F * Mp, (size_t)Mp);                                                         \
+    } while (0)
+        if (bias_kind == CHEBGCN_BIAS_FILTER) CG_BGR(CHEBGCN_BIAS_FILTER);
+        else if (bias_kind == CHEBGCN_BIAS_VERTEX) CG_BGR(CHEBGCN_BIAS_VERTEX);
+        else CG_BGR(CHEBGCN_BIAS_NONE);
+#undef CG_BGR
     } else {
 #define CG_BRELU(BK, PARTS)                                                                                       \
     hipLaunchKernelGGL((brelu_pool_bwd_kernel<BK, PARTS>), dim3(nblk, F), dim3(256), 0, stream, dout, out, argmax, dy, \
@@ -408,18 +416,27 @@ extern "C" int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* re
     CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "bias_grad_relu_mean: bad shape");
     CG_REQUIRE(bias_kind == CHEBGCN_BIAS_FILTER || bias_kind == CHEBGCN_BIAS_VERTEX, "bias_grad_relu_mean: bad bias kind");
     const int Mp = plane_stride(M);
-    const int nblk = brelu_bwd_blocks(M, F, 1, 1, true, nullptr);
+    int parts = 0;
+    const int nblk = brelu_bwd_blocks(M, F, 1, 1, true, &parts);
     float* fpart = nullptr;
     if (bias_kind == CHEBGCN_BIAS_FILTER) {
         CG_REQUIRE(workspace && workspace_bytes >= (size_t)F * nblk * sizeof(float),
                    "bias_grad_relu_mean: the per-filter bias gradient needs a workspace of chebgcn_brelu_pool_bwd_workspace() bytes");
         fpart = static_cast<float*>(workspace);
-        hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER>, dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
-                           (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+        if (parts == 16)
+            hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER, 16>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
+                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+        else
+            hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER, 4>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
+                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
         hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
     } else {
-        hipLaunchKernelGGL(bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX>, dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
-                           (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+        if (parts == 16)
+            hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX, 16>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
+                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+        else
+            hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX, 4>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
+                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
     }
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
