@@ -304,26 +304,45 @@ contract_fwd_splitk_kernel(FwdArgs a) {
         for (int j = 0; j < 16; ++j) acc[r][j] = 0.f;
     const float* base = a.stack + (size_t)b * a.Fin * a.Mp + (valid ? n0 : 0);
     const int npairs = (a.FinK + 1) >> 1;
-    const int fo = c;
-    for (int i0 = wave; i0 < npairs; i0 += 4 * FWD_UNROLL) {
-        float4 bv[FWD_UNROLL];
-        float av[FWD_UNROLL];
+    const int fo = c < a.Fout ? c : a.Fout - 1;
+    const float wz = c < a.Fout ? 1.f : 0.f;
+    // A ring of FWD_UNROLL operand registers refilled as it is consumed (as in contract_fwd_ring_kernel): this wave's pairs
+    // are wave, wave + 4, ...; every load is unconditional on a clamped address (a pair beyond Fin*K re-reads the last
+    // plane against a zero weight), so hipcc counts the loads in flight instead of waiting for all of them.
+    float4 bv[FWD_UNROLL];
+    float av[FWD_UNROLL], az[FWD_UNROLL];              // the weight as loaded, and 1 / 0 (applied at the use: no wait at the issue)
+    auto issue = [&](int u, int i) __attribute__((always_inline)) {
+        const int kk = 2 * i + h;
+        const bool live = kk < a.FinK;
+        const int kkc = live ? kk : a.FinK - 1;
+        const int fc = kkc / a.K, kc = kkc - fc * a.K;
+        bv[u] = ld_stream(base + (size_t)kc * a.slab + (size_t)fc * a.Mp);
+        av[u] = a.W[(size_t)kkc * a.Fout + fo];
+        az[u] = live ? wz : 0.f;
+    };
+    const int nmine = npairs > wave ? (npairs - wave + 3) >> 2 : 0;            // pairs of this wave
+    const int nring = (nmine + FWD_UNROLL - 1) / FWD_UNROLL * FWD_UNROLL;      // whole ring rounds (the padding multiplies by zero)
+#pragma unroll
+    for (int u = 0; u < FWD_UNROLL; ++u) issue(u, wave + 4 * u);
+    for (int r0 = FWD_UNROLL; r0 < nring; r0 += FWD_UNROLL) {      // (the refill is unconditional inside a round: countable)
 #pragma unroll
         for (int u = 0; u < FWD_UNROLL; ++u) {
-            const int kk = 2 * (i0 + 4 * u) + h;
-            const bool live = kk < a.FinK;
-            const int kkc = live ? kk : a.FinK - 1;         // dead iterations re-read the last plane against a zero weight
-            const int fc = kkc / a.K, kc = kkc - fc * a.K;
-            const float* p = base + (size_t)kc * a.slab + (size_t)fc * a.Mp;
-            bv[u] = valid ? ld_stream(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-            av[u] = (live && fo < a.Fout) ? a.W[(size_t)kk * a.Fout + fo] : 0.f;
+            const float w = av[u] * az[u];
+            acc[0] = mfma(w, bv[u].x, acc[0]);
+            acc[1] = mfma(w, bv[u].y, acc[1]);
+            acc[2] = mfma(w, bv[u].z, acc[2]);
+            acc[3] = mfma(w, bv[u].w, acc[3]);
+            issue(u, wave + 4 * (r0 + u));
         }
+    }
+    if (nring > 0) {                                               // last round: nothing to refill
 #pragma unroll
         for (int u = 0; u < FWD_UNROLL; ++u) {
-            acc[0] = mfma(av[u], bv[u].x, acc[0]);
-            acc[1] = mfma(av[u], bv[u].y, acc[1]);
-            acc[2] = mfma(av[u], bv[u].z, acc[2]);
-            acc[3] = mfma(av[u], bv[u].w, acc[3]);
+            const float w = av[u] * az[u];
+            acc[0] = mfma(w, bv[u].x, acc[0]);
+            acc[1] = mfma(w, bv[u].y, acc[1]);
+            acc[2] = mfma(w, bv[u].z, acc[2]);
+            acc[3] = mfma(w, bv[u].w, acc[3]);
         }
     }
 #pragma unroll
