@@ -297,6 +297,15 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
         }
     };
 
+    // operator ring (see the gather below).  Small graphs (NJ <= 2: every row group of a wave fits the ring) request their
+    // records ONCE per workgroup and keep them for every step of every plane group: the ring is never refilled there,
+    // and an atlas-sized layer (N = 360: 376 rows, K = 10) otherwise pays one exposed L2 round trip in each of its nine steps.
+    constexpr int RING = 2 * QMAX;
+    constexpr int QO = (QMAX + 1) / 2;       // id records (two quads each) per group in the ring
+    constexpr int ORING = 2 * QO;
+    uint4 ro[ORING];
+    float4 rv[RING];
+    bool ring_resident = false;
     int grp = blockIdx.x;
     const size_t in_base = ADJ ? (size_t)(K - 1) * slab : 0;
     __syncthreads();
@@ -415,11 +424,6 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
             // slot n % RING and is requested RING quads (two groups) before it is gathered -- one
             // group of lead does not cover the L2 latency.  Requests are unconditional, so the
             // compiler can count the loads in flight (s_waitcnt vmcnt(N), N > 0).
-            constexpr int RING = 2 * QMAX;
-            constexpr int QO = (QMAX + 1) / 2;       // id records (two quads each) per group in the ring
-            constexpr int ORING = 2 * QO;
-            uint4 ro[ORING];
-            float4 rv[RING];
             auto group_info = [&](int j, int& qoff, int& len) {
                 // {quad offset, length} of group j*nwaves + wave, from lane j of the wave's table
                 qoff = __builtin_amdgcn_readlane(gtab.x, j);
@@ -468,13 +472,16 @@ cheb_onchip_kernel(EllView e, const float* __restrict__ src, float* __restrict__
 #pragma unroll
                     for (int p = 0; p < P; ++p) acc[p] = fmaf(comp(v, i), t[i].x[p], acc[p]);
             };
+            if (NJ > 2 || !ring_resident) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                if (jj >= NJ) break;
+                for (int jj = 0; jj < 2; ++jj) {
+                    if (jj >= NJ) break;
 #pragma unroll
-                for (int o = 0; o < QO; ++o) request_ids(jj, o);
+                    for (int o = 0; o < QO; ++o) request_ids(jj, o);
 #pragma unroll
-                for (int q = 0; q < QMAX; ++q) request(jj, q);
+                    for (int q = 0; q < QMAX; ++q) request(jj, q);
+                }
+                ring_resident = true;
             }
             // forward: the operator records of the first two row groups are requested BEFORE the previous step is closed
             // (barrier, rotate, barrier), their L2 latency runs under it: 0.576 -> 0.568 ms at batch 256, 0.127 -> 0.125 ms
