@@ -1,7 +1,8 @@
 """Timing of the first FC layer's three skinny GEMMs (64 x 10466 x 512, fp32) in the formulations torch / hipBLASLt offer."""
 import torch, time
 dev = torch.device('cuda:0')
-B, M, O = 64, 10466, 512
+import sys
+B, M, O = (int(sys.argv[1]), int(sys.argv[2]), 512) if len(sys.argv) > 2 else (64, 10466, 512)
 x = torch.randn(B, M, device=dev); W = torch.randn(M, O, device=dev) * 0.01; dy = torch.randn(B, O, device=dev)
 Wt = W.t().contiguous(); xt = x.t().contiguous(); dyt = dy.t().contiguous()
 def t(fn, n=50):
