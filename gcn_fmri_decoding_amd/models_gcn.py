@@ -782,9 +782,13 @@ class cgcnn(base_model):
             # training step: the layer writes its gradients straight into the flat gradient buffer (like the
             # conv layers do) -- no accumulate-into-.grad add per variable, no zeroing of the buffer
             dp, names = self._dp, (self._var_name('weights'), self._var_name('bias'))
-            x = _LinearInto.apply(x, W, b, W.grad, b.grad, (lambda: dp.head_grads_done(names)) if dp is not None else None)
-        else:
-            x = torch.addmm(b, x, W)
+            return _LinearInto.apply(x, W, b, W.grad, b.grad,
+                                     (lambda: dp.head_grads_done(names)) if dp is not None else None, relu)
+        if not (torch.is_grad_enabled() and (x.requires_grad or W.requires_grad or b.requires_grad)):
+            y = ops.fc_forward(x, W, b, relu) if x.is_cuda else None
+            if y is not None:
+                return y
+        x = torch.addmm(b, x, W)
         return torch.relu(x) if relu else x
 
     # ------------------------------------------------------------------ network
@@ -862,22 +866,29 @@ class _LinearInto(torch.autograd.Function):
     through ``done`` (dist.DataParallel.head_grads_done: the head's all-reduce starts from it)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, gW, gb, done):
-        ctx.save_for_backward(x, W)
+    def forward(ctx, x, W, b, gW, gb, done, relu):
+        y = ops.fc_forward(x, W.detach(), b.detach(), relu) if x.is_cuda else None
+        if y is None:
+            y = torch.addmm(b.detach(), x, W.detach())
+            if relu:
+                y = torch.relu_(y)
+        ctx.save_for_backward(x, W, y if relu else None)
         ctx.bufs = (gW, gb, done)
-        return torch.addmm(b.detach(), x, W.detach())
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, W = ctx.saved_tensors
+        x, W, y = ctx.saved_tensors
         gW, gb, done = ctx.bufs
         g = g.contiguous()
+        if y is not None:
+            g = torch.ops.aten.threshold_backward(g, y, 0.0)
         torch.mm(x.t(), g, out=gW)
         torch.sum(g, 0, out=gb)
         dx = g @ W.t() if ctx.needs_input_grad[0] else None
         if done is not None:
             done()
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 def get_best_checkpoint(best_checkpoint_dir, select_maximum_value=True):

@@ -612,6 +612,24 @@ class FeatureMean(torch.autograd.Function):
         return dx, None
 
 
+def fc_forward(x, W, b, relu):
+    """``act(x @ W + b)`` of the head's FC layers (models_gcn.py:650-656) by the library's small-product kernel, or None
+    where the product is outside its range (large or odd inner size: the caller uses the vendor GEMM).  x may be a
+    [B, M] view of a [B, Mp] buffer."""
+    if not (x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and x.dim() == 2 and W.is_contiguous()
+            and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0):
+        return None
+    B, I = x.shape
+    O = W.shape[1]
+    L = _lib.lib()
+    if not L.chebgcn_fc_fwd_supported(B, I, O):
+        return None
+    y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    _lib.check(L.chebgcn_fc_fwd(_p(x), x.stride(0), _p(W), _p(b) if b is not None else None, _p(y), B, I, O,
+                                1 if relu else 0, _stream()), 'fc_fwd')
+    return y
+
+
 def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
     """In-place TF-form Adam on flat fp32 buffers (models_gcn.py:296).  ``lr_t``: a Python float, or a one-element
     fp32 DEVICE tensor read when the kernel runs (chebgcn_adam_step_dev: the form a captured step graph replays)."""

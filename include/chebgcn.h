@@ -229,6 +229,16 @@ int chebgcn_from_plane(const float* x_plane, float* out_bmf, int B, int M, int F
 int chebgcn_feature_mean_fwd(const float* x, float* y, int B, int M, int F, chebgcn_stream stream);
 int chebgcn_feature_mean_bwd(const float* dy, float* dx, int B, int M, int F, chebgcn_stream stream);
 
+/* ---- head: fully connected layer on atlas-sized inputs (models_gcn.py:650-656) ----
+ *   y[b][o] = act( sum_i x[b][i] * W[i][o] + bias[o] ),  act = ReLU if relu else identity
+ * x: [B] rows of I floats, row stride ldx floats (a [B, M] view of a [B, Mp] buffer is fine; ldx % 4 == 0, x 16-byte
+ * aligned); W: [I][O] dense; bias: [O] or NULL; y: [B][O] dense.  Eight waves split the reduction in a fixed order.
+ * Supported: I % 4 == 0, I <= 4096, B*O <= 2^20 (chebgcn_fc_fwd_supported); CHEBGCN_EUNSUPPORTED otherwise -- the caller
+ * keeps such products (the benchmark graph's 64 x 10466 x 512) on the vendor GEMM. */
+int chebgcn_fc_fwd_supported(int B, int I, int O);
+int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int B, int I, int O,
+                   int relu, chebgcn_stream stream);
+
 /* ---- optimizer: tf.train.AdamOptimizer step (models_gcn.py:296, TF form) ---------
  * g' = grad_scale * g + l2 * p (per-segment l2 handled by the caller passing
  * segments);  m += (1-b1)(g'-m);  v += (1-b2)(g'^2-v);  p -= lr_t * m / (sqrt(v)+eps)

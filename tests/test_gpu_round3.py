@@ -238,3 +238,38 @@ def test_bench_prints_one_json_line_on_stdout():
     for key in ('roofline', 'kernels', 'northstar', 'config4', 'config5', 'dp_overhead', 'refshape'):        # (cpu_baseline: --cpu-windows 0 here)
         assert key in line, key
     assert line['roofline']['bound'] == 'hbm' and 0.2 < line['roofline']['frac'] < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,I,O,ld', [(128, 512, 256, 512), (128, 360, 512, 384), (64, 256, 22, 256), (50, 1000, 512, 1024),
+                                      (3, 8, 1, 8), (128, 4096, 64, 4096), (33, 36, 33, 40)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_fc_forward_small_products(B, I, O, ld, relu):
+    """Head FC layer (reference models_gcn.py:650-656) by the library kernel against float64; x as a view of a wider
+    buffer, ragged batch / output sizes, inner sizes that are not a multiple of the wave split."""
+    from gcn_fmri_decoding_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B * 7 + I + O)
+    buf = torch.randn(B, ld, generator=g).to(dev)
+    x = buf[:, :I]
+    W = (torch.randn(I, O, generator=g) * 0.1).to(dev)
+    b = torch.randn(O, generator=g).to(dev)
+    y = ops.fc_forward(x, W, b, relu)
+    assert y is not None and y.shape == (B, O)
+    ref = x.double() @ W.double() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = (x.double().abs() @ W.double().abs()).max().item()
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * scale          # fp32 accumulation over I terms
+    y2 = ops.fc_forward(x, W, b, relu)
+    assert torch.equal(y, y2)                                             # fixed summation order
+    assert ops.fc_forward(x, W, None, relu) is not None
+
+
+@pytest.mark.gpu
+def test_fc_forward_declines_what_it_does_not_cover():
+    from gcn_fmri_decoding_amd import ops
+    dev = torch.device('cuda:0')
+    assert ops.fc_forward(torch.zeros(64, 10466, device=dev), torch.zeros(10466, 512, device=dev), None, True) is None
+    assert ops.fc_forward(torch.zeros(8, 30, device=dev), torch.zeros(30, 4, device=dev), None, True) is None
+    assert ops.fc_forward(torch.zeros(8, 33, device=dev)[:, 1:], torch.zeros(32, 4, device=dev), None, True) is None
