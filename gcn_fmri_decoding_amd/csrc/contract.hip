@@ -33,6 +33,9 @@
 #ifndef CG_LB_BWX
 #define CG_LB_BWX 1
 #endif
+#ifndef CG_LB_BWXS
+#define CG_LB_BWXS 2      // small launches: two workgroups per CU (three, 168 registers: N=360 34 us against 30)
+#endif
 // s_setprio around a wave's block of MFMAs: without it the waves of a SIMD that are ready together share the
 // matrix pipe round-robin, finish together and then all wait for memory together (a convoy: matrix time and
 // memory time add up instead of overlapping)
@@ -379,7 +382,7 @@ struct BwdXArgs {
 // SPLIT (small launches, see contract_fwd_splitk_kernel): the four waves of a workgroup share one 128-vertex tile and take
 // every fourth tile of 32 output rows each -- no reduction involved, the dy tile is loaded by each of them.
 template <bool HOLD, bool MASK, bool SPLIT = false>
-__global__ void __launch_bounds__(256, CG_LB_BWX)
+__global__ void __launch_bounds__(256, SPLIT ? CG_LB_BWXS : CG_LB_BWX)
 contract_bwd_x_kernel(BwdXArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
