@@ -60,6 +60,7 @@ SIGNATURES = {
     'chebgcn_feature_mean_bwd': (_i, [_p, _p, _i, _i, _i, _p]),
     'chebgcn_fc_fwd_supported': (_i, [_i, _i, _i]),
     'chebgcn_fc_fwd': (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'chebgcn_fc_bwd': (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     'chebgcn_adam_step': (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
     'chebgcn_adam_step_dev': (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _p]),
     'chebgcn_metis_one_level_f32': (_i, [_i64, _p, _p, _p, _p, _p, _i64, _p]),

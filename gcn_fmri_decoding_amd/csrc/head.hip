@@ -64,6 +64,127 @@ fc_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restric
     }
 }
 
+// dW[i][o] = sum_b x[b][i] * gm[b][o],  db[o] = sum_b gm[b][o],  gm = g gated by y > 0 (ReluGrad) where y is given.
+// One workgroup per 32 x 32 tile of dW; the eight waves split the batch in chunks of eight windows and are summed in wave
+// order.  The workgroups of the first row tile also reduce db (per lane over its windows, then half-waves and waves in order).
+__global__ void __launch_bounds__(FC_WAVES * 64)
+fc_bwd_w_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ g, const float* __restrict__ y,
+                float* __restrict__ dW, float* __restrict__ db, int B, int I, int O) {
+    __shared__ float part[FC_WAVES][32][33];
+    __shared__ float bpart[FC_WAVES][2][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const int icol = min(i0 + c, I - 1), ocol = min(o0 + c, O - 1);
+    const int nchunks = (B + 7) >> 3;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    float bsum = 0.f;
+    constexpr int U = 2;
+    for (int q0 = 0; wave + FC_WAVES * q0 < nchunks; q0 += U) {
+        float av[U][4], gv[U][4], yv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = 8 * (wave + FC_WAVES * (q0 + u)) + 4 * h + j;
+                const int bc = b < B ? b : 0;
+                av[u][j] = x[(size_t)bc * ldx + icol];
+                gv[u][j] = g[(size_t)bc * O + ocol];
+                yv[u][j] = y ? y[(size_t)bc * O + ocol] : 1.f;
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = 8 * (wave + FC_WAVES * (q0 + u)) + 4 * h + j;
+                const bool ok = b < B;
+                const float gm = (ok && yv[u][j] > 0.f) ? gv[u][j] : 0.f;
+                bsum += gm;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? av[u][j] : 0.f, gm, acc, 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) part[wave][acc_row(j, h)][c] = acc[j];
+    bpart[wave][h][c] = bsum;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32; e += FC_WAVES * 64) {
+        const int r = e >> 5, cc = e & 31;
+        float s = part[0][r][cc];
+#pragma unroll
+        for (int w = 1; w < FC_WAVES; ++w) s += part[w][r][cc];
+        if (i0 + r < I && o0 + cc < O) dW[(size_t)(i0 + r) * O + o0 + cc] = s;
+    }
+    if (db && blockIdx.y == 0 && threadIdx.x < 32 && o0 + threadIdx.x < O) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < FC_WAVES; ++w) s += bpart[w][0][threadIdx.x] + bpart[w][1][threadIdx.x];
+        db[o0 + threadIdx.x] = s;
+    }
+}
+
+// dx[b][i] = sum_o gm[b][o] * W[i][o]: 32 x 32 tiles of dx, the eight waves split the outputs in chunks of eight.
+template <bool VEC>
+__global__ void __launch_bounds__(FC_WAVES * 64)
+fc_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ W,
+                float* __restrict__ dx, long long lddx, int B, int I, int O) {
+    __shared__ float part[FC_WAVES][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int brow = min(b0 + c, B - 1), irow = min(i0 + c, I - 1);
+    const float* gr = g + (size_t)brow * O;
+    const float* yr = y ? y + (size_t)brow * O : nullptr;
+    const float* wr = W + (size_t)irow * O;
+    const int nchunks = (O + 7) >> 3;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    constexpr int U = 4;
+    for (int q0 = 0; wave + FC_WAVES * q0 < nchunks; q0 += U) {
+        f32x4 gv[U], yv[U], wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = 8 * (wave + FC_WAVES * (q0 + u)) + 4 * h;
+            if (VEC) {
+                const int kc = k < O ? k : 0;
+                gv[u] = *reinterpret_cast<const f32x4*>(gr + kc);
+                wv[u] = *reinterpret_cast<const f32x4*>(wr + kc);
+                if (yr) yv[u] = *reinterpret_cast<const f32x4*>(yr + kc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kc = k + j < O ? k + j : 0;
+                    gv[u][j] = gr[kc];
+                    wv[u][j] = wr[kc];
+                    if (yr) yv[u][j] = yr[kc];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = 8 * (wave + FC_WAVES * (q0 + u)) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = k + j < O;
+                const float gm = (ok && (!yr || yv[u][j] > 0.f)) ? gv[u][j] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gm, ok ? wv[u][j] : 0.f, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) part[wave][acc_row(j, h)][c] = acc[j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32; e += FC_WAVES * 64) {
+        const int r = e >> 5, cc = e & 31;
+        float s = part[0][r][cc];
+#pragma unroll
+        for (int w = 1; w < FC_WAVES; ++w) s += part[w][r][cc];
+        if (b0 + r < B && i0 + cc < I) dx[(size_t)(b0 + r) * lddx + i0 + cc] = s;
+    }
+}
+
 }  // namespace chebgcn
 
 using namespace chebgcn;
@@ -80,6 +201,27 @@ extern "C" int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const
         return CHEBGCN_EUNSUPPORTED;
     dim3 grid((O + 31) / 32, (B + 31) / 32);
     hipLaunchKernelGGL(fc_fwd_kernel, grid, dim3(FC_WAVES * 64), 0, stream, x, (long long)ldx, W, bias, y, B, I, O, relu);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const float* g, const float* y, float* dW,
+                              float* db, float* dx, int64_t lddx, int B, int I, int O, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(x && W && g && B > 0 && I > 0 && O > 0 && ldx >= I && (!dx || lddx >= I), "fc_bwd: bad argument");
+    if (!chebgcn_fc_fwd_supported(B, I, O)) return CHEBGCN_EUNSUPPORTED;
+    if (dW) {
+        dim3 grid((O + 31) / 32, (I + 31) / 32);
+        hipLaunchKernelGGL(fc_bwd_w_kernel, grid, dim3(FC_WAVES * 64), 0, stream, x, (long long)ldx, g, y, dW, db, B, I, O);
+    }
+    if (dx) {
+        dim3 grid((I + 31) / 32, (B + 31) / 32);
+        const bool vec = (O & 3) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)W & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0);
+        if (vec)
+            hipLaunchKernelGGL(fc_bwd_x_kernel<true>, grid, dim3(FC_WAVES * 64), 0, stream, g, y, W, dx, (long long)lddx, B, I, O);
+        else
+            hipLaunchKernelGGL(fc_bwd_x_kernel<false>, grid, dim3(FC_WAVES * 64), 0, stream, g, y, W, dx, (long long)lddx, B, I, O);
+    }
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

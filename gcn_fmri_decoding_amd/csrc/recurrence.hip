@@ -79,11 +79,11 @@ __host__ __device__ constexpr int lds_capacity(int nj, int nthr, int planes) {
 }
 
 // In-kernel phase stamps (CG_X & 64, tools/xbuild.sh): lane 0 of every wave of workgroup
-// g_dbg_block records the cycle counter at phase boundaries of its SECOND plane group.
+// g_dbg_block records the cycle counter at phase boundaries of its SECOND plane group (its only one on small launches).
 __device__ long long g_dbg[16 * 64];
 #define CG_STAMP(id)                                                                          \
     do {                                                                                      \
-        if ((CG_X & 64) && (id) < 64 && lane == 0 && blockIdx.x == 37 && grp == blockIdx.x + (int)gridDim.x) \
+        if ((CG_X & 64) && (id) < 64 && lane == 0 && blockIdx.x == 37 && grp == blockIdx.x + (ngrp > (int)gridDim.x ? (int)gridDim.x : 0)) \
             g_dbg[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();                \
     } while (0)
 
@@ -637,7 +637,11 @@ static int dispatch_onchip(const chebgcn_graph* g, const Ell& ell, const float* 
         return nj * nthr >= rows && nq * nthr >= Mq && ell.lds_entries <= lds_capacity(nj, nthr, P);
     };
 #define CG_TRY(NJ, NQ, NTHR) if (fits(NJ, NQ, NTHR)) return launch_onchip<P, NJ, NQ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
-    CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
+    CG_TRY(1, 1, 256);
+#ifdef CG_TRY384
+    CG_TRY(1, 1, 384);
+#endif
+    CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
     if constexpr (P == 4) {
         // beyond 2048 rows: the dedicated kernel of recurrence4.hip
         return dispatch_onchip4<ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);

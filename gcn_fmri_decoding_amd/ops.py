@@ -630,6 +630,22 @@ def fc_forward(x, W, b, relu):
     return y
 
 
+def fc_backward(x, W, g, y, dW, db, need_dx):
+    """The three gradients of ``act(x @ W + b)`` (ReluGrad on ``y`` where given) by the library kernels: dW and db are
+    WRITTEN into the given buffers, dx is returned (None unless ``need_dx``).  False where fc_forward would decline."""
+    B, I = x.shape
+    O = W.shape[1]
+    L = _lib.lib()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and W.is_contiguous() and g.is_contiguous()
+            and dW.is_contiguous() and db.is_contiguous() and (y is None or y.is_contiguous())
+            and L.chebgcn_fc_fwd_supported(B, I, O)):
+        return False
+    dx = torch.empty((B, I), dtype=torch.float32, device=x.device) if need_dx else None
+    _lib.check(L.chebgcn_fc_bwd(_p(x), x.stride(0), _p(W), _p(g), _p(y) if y is not None else None, _p(dW), _p(db),
+                                _p(dx) if dx is not None else None, I, B, I, O, _stream()), 'fc_bwd')
+    return dx if need_dx else True
+
+
 def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
     """In-place TF-form Adam on flat fp32 buffers (models_gcn.py:296).  ``lr_t``: a Python float, or a one-element
     fp32 DEVICE tensor read when the kernel runs (chebgcn_adam_step_dev: the form a captured step graph replays)."""

@@ -238,6 +238,12 @@ int chebgcn_feature_mean_bwd(const float* dy, float* dx, int B, int M, int F, ch
 int chebgcn_fc_fwd_supported(int B, int I, int O);
 int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int B, int I, int O,
                    int relu, chebgcn_stream stream);
+/* The layer's three gradients (TF autodiff of :650-656): with gm = g where y > 0, else 0 (ReluGrad; gm = g if y is NULL)
+ *   dW[i][o] = sum_b x[b][i] gm[b][o],   db[o] = sum_b gm[b][o],   dx[b][i] = sum_o gm[b][o] W[i][o]
+ * g, y: [B][O] dense; dW: [I][O]; db: [O] or NULL; dx: [B] rows of stride lddx, or NULL (first layer of a model whose input
+ * needs no gradient); dW NULL skips dW and db.  Same range as chebgcn_fc_fwd; every sum in a fixed order. */
+int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const float* g, const float* y, float* dW, float* db,
+                   float* dx, int64_t lddx, int B, int I, int O, chebgcn_stream stream);
 
 /* ---- optimizer: tf.train.AdamOptimizer step (models_gcn.py:296, TF form) ---------
  * g' = grad_scale * g + l2 * p (per-segment l2 handled by the caller passing

@@ -273,3 +273,34 @@ def test_fc_forward_declines_what_it_does_not_cover():
     assert ops.fc_forward(torch.zeros(64, 10466, device=dev), torch.zeros(10466, 512, device=dev), None, True) is None
     assert ops.fc_forward(torch.zeros(8, 30, device=dev), torch.zeros(30, 4, device=dev), None, True) is None
     assert ops.fc_forward(torch.zeros(8, 33, device=dev)[:, 1:], torch.zeros(32, 4, device=dev), None, True) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,I,O,ld', [(128, 512, 256, 512), (128, 360, 512, 384), (64, 256, 22, 256), (50, 1000, 512, 1024),
+                                      (3, 8, 1, 8), (33, 36, 33, 40)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_fc_backward_small_products(B, I, O, ld, relu):
+    """Gradients of the head FC layer (TF autodiff of reference models_gcn.py:650-656, ReluGrad included) by the library
+    kernels against float64."""
+    from gcn_fmri_decoding_amd import ops
+    dev = torch.device('cuda:0')
+    gen = torch.Generator().manual_seed(B * 11 + I + O)
+    buf = torch.randn(B, ld, generator=gen).to(dev)
+    x = buf[:, :I]
+    W = (torch.randn(I, O, generator=gen) * 0.1).to(dev)
+    b = torch.randn(O, generator=gen).to(dev)
+    g = torch.randn(B, O, generator=gen).to(dev)
+    y = ops.fc_forward(x, W, b, relu) if relu else None
+    dW = torch.full((I, O), float('nan'), device=dev)
+    db = torch.full((O,), float('nan'), device=dev)
+    dx = ops.fc_backward(x, W, g, y, dW, db, True)
+    assert dx is not False and dx.shape == (B, I)
+    gm = g.double() * (y > 0).double() if relu else g.double()
+    for got, ref, scale in ((dW, x.double().t() @ gm, (x.double().abs().t() @ gm.abs()).max().item()),
+                            (db, gm.sum(0), gm.abs().sum(0).max().item()),
+                            (dx, gm @ W.double().t(), (gm.abs() @ W.double().abs().t()).max().item())):
+        assert (got.double() - ref).abs().max().item() <= 2e-6 * max(scale, 1e-30)
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    dx2 = ops.fc_backward(x, W, g, y, dW2, db2, True)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2) and torch.equal(dx, dx2)      # fixed summation order
+    assert ops.fc_backward(x, W, g, y, dW2, db2, False) is True and torch.equal(dW, dW2)
