@@ -637,11 +637,7 @@ static int dispatch_onchip(const chebgcn_graph* g, const Ell& ell, const float* 
         return nj * nthr >= rows && nq * nthr >= Mq && ell.lds_entries <= lds_capacity(nj, nthr, P);
     };
 #define CG_TRY(NJ, NQ, NTHR) if (fits(NJ, NQ, NTHR)) return launch_onchip<P, NJ, NQ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
-    CG_TRY(1, 1, 256);
-#ifdef CG_TRY384
-    CG_TRY(1, 1, 384);
-#endif
-    CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
+    CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
     if constexpr (P == 4) {
         // beyond 2048 rows: the dedicated kernel of recurrence4.hip
         return dispatch_onchip4<ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
