@@ -44,7 +44,7 @@ names = {'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd', 'cheb_onc
          'cheb4_kernel<10240, 20, 6, 512, false,': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true,': 'recurrence_bwd_4planes',
          'contract_fwd_kernel<1>': 'contract_fwd', 'contract_fwd_ring_kernel': 'contract_fwd', 'contract_bwd_w_kernel<5, true>': 'contract_bwd_w',
          'contract_bwd_x_kernel<true, true>': 'contract_bwd_x', 'contract_bwd_x_lds_kernel<true>': 'contract_bwd_x',
-         'contract_bwd_x_lds_kernel<false>': 'contract_bwd_x_unfolded', 'bias_grad_relu_kernel<2>': 'bias_grad',
+         'contract_bwd_x_lds_kernel<false>': 'contract_bwd_x_unfolded', 'bias_grad_relu_kernel<2': 'bias_grad',
          'contract_bwd_w_kernel<5, false>': 'contract_bwd_w_unfolded', 'contract_bwd_x_kernel<true, false>': 'contract_bwd_x_unfolded',
          'brelu_pool_bwd_kernel<2, 1>': 'brelu_pool_bwd_unfolded'}
 out = {'_note': 'HBM bytes per launch at the bench shape (B=64, Fin=Fout=32, K=5, M=10466), rocprofv3 --pmc FETCH_SIZE and '
