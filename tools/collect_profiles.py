@@ -6,6 +6,7 @@ named per round, and derives profiles/traffic.json (HBM bytes per launch and ker
 """
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -32,7 +33,8 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
     p = os.path.join(SRC, src)
     if os.path.exists(p):
         if src.endswith('.txt') or src == 'bench_line.json':
-            lines = [l for l in open(p) if 'amdgpu.ids' not in l and l.strip() not in ('1', '6 6 6')]
+            lines = [l for l in open(p) if 'amdgpu.ids' not in l and l.strip() not in ('1', '6 6 6')
+                     and not re.match(r'[WEI]\d{8} ', l)]            # rocprofv3's own log lines
             if src == 'bench_line.json':
                 lines = [l for l in lines if l.startswith('{"metric"')]
             open(os.path.join(DST, dst % tag), 'w').writelines(lines)

@@ -37,7 +37,7 @@ for kern in recurrence_fwd_inplace recurrence_fwd recurrence_bwd; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profr -o rs -- python3 $GRAFT_REPO_ROOT/tools/refshape.py --nodes 360 > $out/profr.log 2>&1
 find $out/profr -name "*kernel_stats.csv" -exec cp {} $out/refshape_n360_kernel_stats.csv \;
-tail -1 $out/profr.log > $out/refshape_n360_line.json
+grep "^{\"shape\"" $out/profr.log | tail -1 > $out/refshape_n360_line.json
 # what the memory system and the fp32 matrix pipe give with nothing else going on (EXPERIMENTS.md 3b)
 for b in 8 16 32 64; do $GRAFT_REPO_ROOT/tools/probes/hbm_stream_probe $b; done > $out/hbm_stream_probe.txt 2>&1
 $GRAFT_REPO_ROOT/tools/probes/mfma_f32_probe > $out/mfma_f32_probe.txt 2>&1
