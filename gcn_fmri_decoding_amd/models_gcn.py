@@ -883,10 +883,10 @@ class _LinearInto(torch.autograd.Function):
         g = g.contiguous()
         if g.is_cuda:
             r = ops.fc_backward(x, W, g, y, gW, gb, ctx.needs_input_grad[0])
-            if r is not False:
+            if r is not None:
                 if done is not None:
                     done()
-                return (r if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
+                return r[0], None, None, None, None, None, None
         if y is not None:
             g = torch.ops.aten.threshold_backward(g, y, 0.0)
         torch.mm(x.t(), g, out=gW)

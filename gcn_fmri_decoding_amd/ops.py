@@ -632,18 +632,19 @@ def fc_forward(x, W, b, relu):
 
 def fc_backward(x, W, g, y, dW, db, need_dx):
     """The three gradients of ``act(x @ W + b)`` (ReluGrad on ``y`` where given) by the library kernels: dW and db are
-    WRITTEN into the given buffers, dx is returned (None unless ``need_dx``).  False where fc_forward would decline."""
+    WRITTEN into the given buffers.  Returns ``(dx,)`` (``(None,)`` unless ``need_dx``), or None where fc_forward would
+    decline and nothing was launched."""
     B, I = x.shape
     O = W.shape[1]
     L = _lib.lib()
     if not (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and W.is_contiguous() and g.is_contiguous()
             and dW.is_contiguous() and db.is_contiguous() and (y is None or y.is_contiguous())
             and L.chebgcn_fc_fwd_supported(B, I, O)):
-        return False
+        return None
     dx = torch.empty((B, I), dtype=torch.float32, device=x.device) if need_dx else None
-    _lib.check(L.chebgcn_fc_bwd(_p(x), x.stride(0), _p(W), _p(g), _p(y) if y is not None else None, _p(dW), _p(db),
-                                _p(dx) if dx is not None else None, I, B, I, O, _stream()), 'fc_bwd')
-    return dx if need_dx else True
+    _lib.check(L.chebgcn_fc_bwd(_p(x), x.stride(0), _p(W), _p(g), _p(y), _p(dW), _p(db), _p(dx), I, B, I, O, _stream()),
+               'fc_bwd')
+    return (dx,)
 
 
 def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):

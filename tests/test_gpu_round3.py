@@ -293,14 +293,17 @@ def test_fc_backward_small_products(B, I, O, ld, relu):
     y = ops.fc_forward(x, W, b, relu) if relu else None
     dW = torch.full((I, O), float('nan'), device=dev)
     db = torch.full((O,), float('nan'), device=dev)
-    dx = ops.fc_backward(x, W, g, y, dW, db, True)
-    assert dx is not False and dx.shape == (B, I)
+    (dx,) = ops.fc_backward(x, W, g, y, dW, db, True)
+    assert dx.shape == (B, I)
     gm = g.double() * (y > 0).double() if relu else g.double()
     for got, ref, scale in ((dW, x.double().t() @ gm, (x.double().abs().t() @ gm.abs()).max().item()),
                             (db, gm.sum(0), gm.abs().sum(0).max().item()),
                             (dx, gm @ W.double().t(), (gm.abs() @ W.double().abs().t()).max().item())):
         assert (got.double() - ref).abs().max().item() <= 2e-6 * max(scale, 1e-30)
     dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
-    dx2 = ops.fc_backward(x, W, g, y, dW2, db2, True)
+    (dx2,) = ops.fc_backward(x, W, g, y, dW2, db2, True)
     assert torch.equal(dW, dW2) and torch.equal(db, db2) and torch.equal(dx, dx2)      # fixed summation order
-    assert ops.fc_backward(x, W, g, y, dW2, db2, False) is True and torch.equal(dW, dW2)
+    assert ops.fc_backward(x, W, g, y, dW2, db2, False) == (None,) and torch.equal(dW, dW2)
+    big = torch.zeros(4, 10466, device=dev)
+    assert ops.fc_backward(big, torch.zeros(10466, 8, device=dev), torch.zeros(4, 8, device=dev), None,
+                           torch.zeros(10466, 8, device=dev), torch.zeros(8, device=dev), True) is None
