@@ -242,8 +242,10 @@ def perm_data(x, perm, sample=None, out=None):
 _workspaces = {}
 
 
-def _workspace(nbytes, device):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, tag=''):
+    """Scratch of a library call, kept per device, stream and use: launches on one stream are ordered, so the buffer of the
+    previous call of the same kind is free by the time the next one runs."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
@@ -297,7 +299,7 @@ def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout
                    'contract_fwd')
         return
     nws = lib.chebgcn_contract_fwd_bf16_workspace(Fin, K, Fout)
-    ws = torch.empty(nws, dtype=torch.uint8, device=stack.device)
+    ws = _workspace(nws, stack.device, 'fwd_bf16')
     _lib.check(_launch('contract_fwd_' + precision, nbytes, flops,
                        lambda: lib.chebgcn_contract_fwd_bf16(_p(stack), _p(W), _p(bias), bias_kind, _p(out), _p(argmax), B, M,
                                                              Fin, K, Fout, pool, pool_kind, int(relu), PRECISIONS[precision],
@@ -486,7 +488,7 @@ class ChebConv(torch.autograd.Function):
             passes = PRECISIONS[ctx.precision]
             if passes:
                 nws = lib.chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout)
-                wsx = torch.empty(nws, dtype=torch.uint8, device=dev)     # its own: bwd_w may be running beside it
+                wsx = _workspace(nws, dev, 'bwd_x_bf16')                  # its own: bwd_w may be running beside it
                 what = 'contract_bwd_x_' + ctx.precision
                 _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
                                    lambda: lib.chebgcn_contract_bwd_x_bf16(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
