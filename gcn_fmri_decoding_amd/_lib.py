@@ -59,7 +59,8 @@ SIGNATURES = {
     'chebgcn_feature_mean_fwd': (_i, [_p, _p, _i, _i, _i, _p]),
     'chebgcn_feature_mean_bwd': (_i, [_p, _p, _i, _i, _i, _p]),
     'chebgcn_fc_fwd_supported': (_i, [_i, _i, _i]),
-    'chebgcn_fc_fwd': (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'chebgcn_fc_fwd_workspace': (C.c_size_t, [_i, _i, _i]),
+    'chebgcn_fc_fwd': (_i, [_p, _i64, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _p]),
     'chebgcn_fc_bwd': (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     'chebgcn_adam_step': (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
     'chebgcn_adam_step_dev': (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _p]),

@@ -14,9 +14,11 @@ namespace chebgcn {
 constexpr int FC_WAVES = 8;
 constexpr int FC_U = 8;        // chunks of eight input features a wave keeps in flight
 
+// gridDim.z > 1: the reduction is also split across workgroups (chunks [z*cps, (z+1)*cps) of eight input features); the
+// partial tiles go to part_out[z][b][o] and fc_fwd_reduce_kernel adds them in order.
 __global__ void __launch_bounds__(FC_WAVES * 64)
 fc_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ W, const float* __restrict__ bias,
-              float* __restrict__ y, int B, int I, int O, int relu) {
+              float* __restrict__ y, float* __restrict__ part_out, int B, int I, int O, int relu, int cps) {
     __shared__ float part[FC_WAVES][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -25,28 +27,31 @@ fc_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restric
     const float* xr = x + (size_t)brow * ldx;
     const float* wc = W + ocol;
     const int nchunks = (I + 7) >> 3;
+    const int q_lo = blockIdx.z * cps, q_hi = min(q_lo + cps, nchunks);
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    // chunk q of this wave covers input features 8*(wave + FC_WAVES*q) + 4*h .. + 3 for this half-wave
-    for (int q0 = 0; wave + FC_WAVES * q0 < nchunks; q0 += FC_U) {
+    // chunk q covers input features 8*q + 4*h .. + 3 for this half-wave; this wave takes q_lo + wave, + FC_WAVES, ...
+    for (int q0 = q_lo + wave; q0 < q_hi; q0 += FC_WAVES * FC_U) {
         f32x4 av[FC_U];
         float bv[FC_U][4];
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
-            const int k = 8 * (wave + FC_WAVES * (q0 + u)) + 4 * h;
-            const int kc = k < I ? k : 0;               // I is a multiple of four: a group of four is inside or outside
-            av[u] = *reinterpret_cast<const f32x4*>(xr + kc);
+            const int q = q0 + FC_WAVES * u;
+            const int k = (q < q_hi ? 8 * q : 0) + 4 * h;       // beyond the range: any readable address, multiplied by zero
+            av[u] = *reinterpret_cast<const f32x4*>(xr + (k + 3 < ldx ? k : 0));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[u][j] = wc[(size_t)(kc + j) * O];
+            for (int j = 0; j < 4; ++j) bv[u][j] = wc[(size_t)(k + j < I ? k + j : 0) * O];
         }
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
-            const int k = 8 * (wave + FC_WAVES * (q0 + u)) + 4 * h;
-            const bool ok = k < I;
+            const int q = q0 + FC_WAVES * u;
+            const int k = 8 * q + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = q < q_hi && k + j < I;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? av[u][j] : 0.f, ok ? bv[u][j] : 0.f, acc, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -58,10 +63,32 @@ fc_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restric
 #pragma unroll
         for (int w = 1; w < FC_WAVES; ++w) s += part[w][r][cc];
         if (b0 + r < B && o0 + cc < O) {
-            s += bias ? bias[o0 + cc] : 0.f;
-            y[(size_t)(b0 + r) * O + o0 + cc] = relu ? fmaxf(s, 0.f) : s;
+            if (part_out) {
+                part_out[((size_t)blockIdx.z * B + b0 + r) * O + o0 + cc] = s;
+            } else {
+                s += bias ? bias[o0 + cc] : 0.f;
+                y[(size_t)(b0 + r) * O + o0 + cc] = relu ? fmaxf(s, 0.f) : s;
+            }
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+fc_fwd_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y, int BO, int O,
+                     int S, int relu) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= BO) return;
+    float v[16];
+    float s = 0.f;
+    for (int z0 = 0; z0 < S; z0 += 16) {                 // sixteen loads in flight, added in split order
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part[(size_t)min(z0 + u, S - 1) * BO + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (z0 + u < S) s += v[u];
+    }
+    s += bias ? bias[e % O] : 0.f;
+    y[e] = relu ? fmaxf(s, 0.f) : s;
 }
 
 // dW[i][o] = sum_b x[b][i] * gm[b][o],  db[o] = sum_b gm[b][o],  gm = g gated by y > 0 (ReluGrad) where y is given.
@@ -189,18 +216,40 @@ fc_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ y, const 
 
 using namespace chebgcn;
 
-extern "C" int chebgcn_fc_fwd_supported(int B, int I, int O) {
-    return B > 0 && I > 0 && O > 0 && (I & 3) == 0 && I <= 4096 && (long long)B * O <= (1 << 20);
+// splits of the reduction across workgroups: enough workgroups for two per CU, at least 64 chunks (512 input features) each
+static int fc_splits(int B, int I, int O) {
+    const int tiles = ((O + 31) / 32) * ((B + 31) / 32);
+    int s = 512 / tiles;
+    const int by_len = (I + 511) / 512;
+    if (s > by_len) s = by_len;
+    return s < 1 ? 1 : s;
 }
 
-extern "C" int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int B, int I,
-                              int O, int relu, chebgcn_stream stream_) {
+extern "C" int chebgcn_fc_fwd_supported(int B, int I, int O) {
+    return B > 0 && I > 0 && O > 0 && I <= (1 << 20) && (long long)B * O <= (1 << 20);
+}
+
+extern "C" size_t chebgcn_fc_fwd_workspace(int B, int I, int O) {
+    if (!chebgcn_fc_fwd_supported(B, I, O)) return 0;
+    const int S = fc_splits(B, I, O);
+    return S > 1 ? (size_t)S * B * O * sizeof(float) : 0;
+}
+
+extern "C" int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bias, float* y, void* workspace,
+                              size_t workspace_bytes, int B, int I, int O, int relu, chebgcn_stream stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     CG_REQUIRE(x && W && y && B > 0 && I > 0 && O > 0 && ldx >= I, "fc_fwd: bad argument");
     if (!chebgcn_fc_fwd_supported(B, I, O) || (ldx & 3) || ((uintptr_t)x & 15))
         return CHEBGCN_EUNSUPPORTED;
-    dim3 grid((O + 31) / 32, (B + 31) / 32);
-    hipLaunchKernelGGL(fc_fwd_kernel, grid, dim3(FC_WAVES * 64), 0, stream, x, (long long)ldx, W, bias, y, B, I, O, relu);
+    const int S = fc_splits(B, I, O);
+    const int nchunks = (I + 7) / 8, cps = (nchunks + S - 1) / S;
+    CG_REQUIRE(S == 1 || (workspace && workspace_bytes >= chebgcn_fc_fwd_workspace(B, I, O)), "fc_fwd: workspace too small");
+    dim3 grid((O + 31) / 32, (B + 31) / 32, S);
+    hipLaunchKernelGGL(fc_fwd_kernel, grid, dim3(FC_WAVES * 64), 0, stream, x, (long long)ldx, W, bias, y,
+                       S > 1 ? (float*)workspace : nullptr, B, I, O, relu, cps);
+    if (S > 1)
+        hipLaunchKernelGGL(fc_fwd_reduce_kernel, dim3((B * O + 255) / 256), dim3(256), 0, stream, (const float*)workspace, bias,
+                           y, B * O, O, S, relu);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -614,6 +614,10 @@ class FeatureMean(torch.autograd.Function):
         return dx, None
 
 
+FC_BWD_MAX_INNER = 4096      # beyond: the gradients stay on the vendor GEMMs (tools/probes/fc_small_probe.py)
+FC_FWD_MAX_INNER = int(os.environ.get('CHEBGCN_FC_FWD_MAX_INNER', 1 << 20))     # A/B knob for bench runs
+
+
 def fc_forward(x, W, b, relu):
     """``act(x @ W + b)`` of the head's FC layers (models_gcn.py:650-656) by the library's small-product kernel, or None
     where the product is outside its range (large or odd inner size: the caller uses the vendor GEMM).  x may be a
@@ -624,11 +628,13 @@ def fc_forward(x, W, b, relu):
     B, I = x.shape
     O = W.shape[1]
     L = _lib.lib()
-    if not L.chebgcn_fc_fwd_supported(B, I, O):
+    if I > FC_FWD_MAX_INNER or not L.chebgcn_fc_fwd_supported(B, I, O):
         return None
     y = torch.empty((B, O), dtype=torch.float32, device=x.device)
-    _lib.check(L.chebgcn_fc_fwd(_p(x), x.stride(0), _p(W), _p(b) if b is not None else None, _p(y), B, I, O,
-                                1 if relu else 0, _stream()), 'fc_fwd')
+    nws = L.chebgcn_fc_fwd_workspace(B, I, O)
+    ws = _workspace(nws, x.device, 'fc_fwd') if nws else None
+    _lib.check(L.chebgcn_fc_fwd(_p(x), x.stride(0), _p(W), _p(b), _p(y), _p(ws), nws, B, I, O, 1 if relu else 0, _stream()),
+               'fc_fwd')
     return y
 
 
@@ -641,7 +647,7 @@ def fc_backward(x, W, g, y, dW, db, need_dx):
     L = _lib.lib()
     if not (x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1 and W.is_contiguous() and g.is_contiguous()
             and dW.is_contiguous() and db.is_contiguous() and (y is None or y.is_contiguous())
-            and L.chebgcn_fc_fwd_supported(B, I, O)):
+            and I <= FC_BWD_MAX_INNER and L.chebgcn_fc_fwd_supported(B, I, O)):
         return None
     dx = torch.empty((B, I), dtype=torch.float32, device=x.device) if need_dx else None
     _lib.check(L.chebgcn_fc_bwd(_p(x), x.stride(0), _p(W), _p(g), _p(y), _p(dW), _p(db), _p(dx), I, B, I, O, _stream()),

@@ -229,15 +229,17 @@ int chebgcn_from_plane(const float* x_plane, float* out_bmf, int B, int M, int F
 int chebgcn_feature_mean_fwd(const float* x, float* y, int B, int M, int F, chebgcn_stream stream);
 int chebgcn_feature_mean_bwd(const float* dy, float* dx, int B, int M, int F, chebgcn_stream stream);
 
-/* ---- head: fully connected layer on atlas-sized inputs (models_gcn.py:650-656) ----
+/* ---- head: fully connected layer (models_gcn.py:650-656) -------------------------
  *   y[b][o] = act( sum_i x[b][i] * W[i][o] + bias[o] ),  act = ReLU if relu else identity
  * x: [B] rows of I floats, row stride ldx floats (a [B, M] view of a [B, Mp] buffer is fine; ldx % 4 == 0, x 16-byte
- * aligned); W: [I][O] dense; bias: [O] or NULL; y: [B][O] dense.  Eight waves split the reduction in a fixed order.
- * Supported: I % 4 == 0, I <= 4096, B*O <= 2^20 (chebgcn_fc_fwd_supported); CHEBGCN_EUNSUPPORTED otherwise -- the caller
- * keeps such products (the benchmark graph's 64 x 10466 x 512) on the vendor GEMM. */
+ * aligned, else CHEBGCN_EUNSUPPORTED); W: [I][O] dense; bias: [O] or NULL; y: [B][O] dense.  32 x 32 tiles of y, eight waves
+ * split the reduction; long reductions are also split across workgroups (partials in `workspace`,
+ * chebgcn_fc_fwd_workspace bytes, 0 for short ones) and added in a fixed order by a second launch.
+ * chebgcn_fc_fwd_supported: B*O <= 2^20, I <= 2^20. */
 int chebgcn_fc_fwd_supported(int B, int I, int O);
-int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bias, float* y, int B, int I, int O,
-                   int relu, chebgcn_stream stream);
+size_t chebgcn_fc_fwd_workspace(int B, int I, int O);
+int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bias, float* y, void* workspace,
+                   size_t workspace_bytes, int B, int I, int O, int relu, chebgcn_stream stream);
 /* The layer's three gradients (TF autodiff of :650-656): with gm = g where y > 0, else 0 (ReluGrad; gm = g if y is NULL)
  *   dW[i][o] = sum_b x[b][i] gm[b][o],   db[o] = sum_b gm[b][o],   dx[b][i] = sum_o gm[b][o] W[i][o]
  * g, y: [B][O] dense; dW: [I][O]; db: [O] or NULL; dx: [B] rows of stride lddx, or NULL (first layer of a model whose input

@@ -242,7 +242,8 @@ def test_bench_prints_one_json_line_on_stdout():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,I,O,ld', [(128, 512, 256, 512), (128, 360, 512, 384), (64, 256, 22, 256), (50, 1000, 512, 1024),
-                                      (3, 8, 1, 8), (128, 4096, 64, 4096), (33, 36, 33, 40)])
+                                      (3, 8, 1, 8), (128, 4096, 64, 4096), (33, 36, 33, 40), (8, 30, 4, 32), (5, 1, 3, 4),
+                                      (64, 10466, 512, 10496), (16, 2051, 40, 2052)])
 @pytest.mark.parametrize('relu', [False, True])
 def test_fc_forward_small_products(B, I, O, ld, relu):
     """Head FC layer (reference models_gcn.py:650-656) by the library kernel against float64; x as a view of a wider
@@ -251,6 +252,7 @@ def test_fc_forward_small_products(B, I, O, ld, relu):
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(B * 7 + I + O)
     buf = torch.randn(B, ld, generator=g).to(dev)
+    buf[:, I:] = float('nan')                      # what lies beyond the logical row never reaches the result
     x = buf[:, :I]
     W = (torch.randn(I, O, generator=g) * 0.1).to(dev)
     b = torch.randn(O, generator=g).to(dev)
@@ -270,9 +272,9 @@ def test_fc_forward_small_products(B, I, O, ld, relu):
 def test_fc_forward_declines_what_it_does_not_cover():
     from gcn_fmri_decoding_amd import ops
     dev = torch.device('cuda:0')
-    assert ops.fc_forward(torch.zeros(64, 10466, device=dev), torch.zeros(10466, 512, device=dev), None, True) is None
-    assert ops.fc_forward(torch.zeros(8, 30, device=dev), torch.zeros(30, 4, device=dev), None, True) is None
-    assert ops.fc_forward(torch.zeros(8, 33, device=dev)[:, 1:], torch.zeros(32, 4, device=dev), None, True) is None
+    assert ops.fc_forward(torch.zeros(8, 30, device=dev), torch.zeros(30, 4, device=dev), None, True) is None       # row stride
+    assert ops.fc_forward(torch.zeros(8, 33, device=dev)[:, 1:], torch.zeros(32, 4, device=dev), None, True) is None  # alignment
+    assert ops.fc_forward(torch.zeros(2 ** 11, 8, device=dev), torch.zeros(8, 2 ** 10, device=dev), None, True) is None
 
 
 @pytest.mark.gpu
