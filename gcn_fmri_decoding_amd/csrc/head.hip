@@ -12,9 +12,10 @@
 namespace chebgcn {
 
 constexpr int FC_WAVES = 8;
-constexpr int FC_U = 8;        // chunks of eight input features a wave keeps in flight
+constexpr int FC_CHUNK = 32;   // input features per chunk of the forward's reduction
+constexpr int FC_U = 2;        // chunks a wave keeps in flight
 
-// gridDim.z > 1: the reduction is also split across workgroups (chunks [z*cps, (z+1)*cps) of eight input features); the
+// gridDim.z > 1: the reduction is also split across workgroups (chunks [z*cps, (z+1)*cps) of FC_CHUNK input features); the
 // partial tiles go to part_out[z][b][o] and fc_fwd_reduce_kernel adds them in order.
 __global__ void __launch_bounds__(FC_WAVES * 64)
 fc_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ W, const float* __restrict__ bias,
@@ -22,36 +23,44 @@ fc_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restric
     __shared__ float part[FC_WAVES][32][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int o0 = bx * 32, b0 = by * 32;
     const int brow = min(b0 + c, B - 1), ocol = min(o0 + c, O - 1);
     const float* xr = x + (size_t)brow * ldx;
     const float* wc = W + ocol;
-    const int nchunks = (I + 7) >> 3;
-    const int q_lo = blockIdx.z * cps, q_hi = min(q_lo + cps, nchunks);
+    const int nchunks = (I + FC_CHUNK - 1) / FC_CHUNK;
+    const int q_lo = bz * cps, q_hi = min(q_lo + cps, nchunks);
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    // chunk q covers input features 8*q + 4*h .. + 3 for this half-wave; this wave takes q_lo + wave, + FC_WAVES, ...
+    // chunk q covers input features 32*q .. 32*q + 31: this half-wave takes 16 of them, i.e. every lane reads one whole
+    // 64-byte sector of its OWN row of x in four 16-byte requests (with 16 bytes per lane and sector the L1 fills were four
+    // times the bytes used: 64 x 10466 x 512 23.4 -> 19.4 us); this wave takes chunks q_lo + wave, + FC_WAVES, ...
     for (int q0 = q_lo + wave; q0 < q_hi; q0 += FC_WAVES * FC_U) {
-        f32x4 av[FC_U];
-        float bv[FC_U][4];
+        f32x4 av[FC_U][4];
+        float bv[FC_U][4][4];
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
             const int q = q0 + FC_WAVES * u;
-            const int k = (q < q_hi ? 8 * q : 0) + 4 * h;       // beyond the range: any readable address, multiplied by zero
-            av[u] = *reinterpret_cast<const f32x4*>(xr + (k + 3 < ldx ? k : 0));
+            const int k = (q < q_hi ? FC_CHUNK * q : 0) + 16 * h;    // beyond the range: any readable address, multiplied by zero
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[u][j] = wc[(size_t)(k + j < I ? k + j : 0) * O];
+            for (int t = 0; t < 4; ++t) {
+                av[u][t] = *reinterpret_cast<const f32x4*>(xr + (k + 4 * t + 3 < ldx ? k + 4 * t : 0));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[u][t][j] = wc[(size_t)(k + 4 * t + j < I ? k + 4 * t + j : 0) * O];
+            }
         }
 #pragma unroll
         for (int u = 0; u < FC_U; ++u) {
             const int q = q0 + FC_WAVES * u;
-            const int k = 8 * q + 4 * h;
+            const int k = FC_CHUNK * q + 16 * h;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = q < q_hi && k + j < I;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? av[u][j] : 0.f, ok ? bv[u][j] : 0.f, acc, 0, 0, 0);
-            }
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = q < q_hi && k + 4 * t + j < I;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? av[u][t][j] : 0.f, ok ? bv[u][t][j] : 0.f, acc, 0, 0, 0);
+                }
         }
     }
 #pragma unroll
@@ -64,7 +73,7 @@ fc_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restric
         for (int w = 1; w < FC_WAVES; ++w) s += part[w][r][cc];
         if (b0 + r < B && o0 + cc < O) {
             if (part_out) {
-                part_out[((size_t)blockIdx.z * B + b0 + r) * O + o0 + cc] = s;
+                part_out[((size_t)bz * B + b0 + r) * O + o0 + cc] = s;
             } else {
                 s += bias ? bias[o0 + cc] : 0.f;
                 y[(size_t)(b0 + r) * O + o0 + cc] = relu ? fmaxf(s, 0.f) : s;
@@ -242,7 +251,7 @@ extern "C" int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const
     if (!chebgcn_fc_fwd_supported(B, I, O) || (ldx & 3) || ((uintptr_t)x & 15))
         return CHEBGCN_EUNSUPPORTED;
     const int S = fc_splits(B, I, O);
-    const int nchunks = (I + 7) / 8, cps = (nchunks + S - 1) / S;
+    const int nchunks = (I + FC_CHUNK - 1) / FC_CHUNK, cps = (nchunks + S - 1) / S;
     CG_REQUIRE(S == 1 || (workspace && workspace_bytes >= chebgcn_fc_fwd_workspace(B, I, O)), "fc_fwd: workspace too small");
     dim3 grid((O + 31) / 32, (B + 31) / 32, S);
     hipLaunchKernelGGL(fc_fwd_kernel, grid, dim3(FC_WAVES * 64), 0, stream, x, (long long)ldx, W, bias, y,
