@@ -68,6 +68,15 @@ def test_argument_validation_without_gpu():
     assert lib.chebgcn_contract_bwd_w_bf16_workspace(0, 1, 1, 1, 1) == 0
     assert lib.chebgcn_contract_bwd_w_bf16(None, None, None, None, 0, 1, 1, 1, 1, 1, 1, None) == -1
     assert b'contract_bwd_w_bf16' in lib.chebgcn_last_error()
+    # the head's FC layer: range, split arithmetic and argument checks
+    assert lib.chebgcn_fc_fwd_supported(128, 512, 256) == 1 and lib.chebgcn_fc_fwd_supported(64, 10466, 512) == 1
+    assert lib.chebgcn_fc_fwd_supported(2 ** 11, 8, 2 ** 10) == 0 and lib.chebgcn_fc_fwd_supported(0, 8, 8) == 0
+    assert lib.chebgcn_fc_fwd_workspace(128, 512, 256) == 0                      # short reduction: one launch, no partials
+    assert lib.chebgcn_fc_fwd_workspace(64, 10466, 512) == 16 * 64 * 512 * 4     # 32 tiles -> 16 splits of the 10466 features
+    assert lib.chebgcn_fc_fwd(None, 8, None, None, None, None, 0, 1, 8, 1, 0, None) == -1
+    assert b'fc_fwd' in lib.chebgcn_last_error()
+    assert lib.chebgcn_fc_bwd(None, 8, None, None, None, None, None, None, 8, 1, 8, 1, None) == -1
+    assert b'fc_bwd' in lib.chebgcn_last_error()
     with pytest.raises(_lib.ChebgcnError):
         _lib.check(-1, 'x')
 
