@@ -26,6 +26,7 @@ _f = C.c_float
 SIGNATURES = {
     'chebgcn_version': (_i, []),
     'chebgcn_last_error': (C.c_char_p, []),
+    'chebgcn_last_dispatch': (C.c_char_p, []),
     'chebgcn_plane_stride': (_i, [_i]),
     'chebgcn_graph_create': (_i, [_i, _i64, _p, _p, _p, C.POINTER(_p)]),
     'chebgcn_graph_create_planes': (_i, [_i, _i64, _p, _p, _p, _i, C.POINTER(_p)]),
@@ -95,10 +96,22 @@ def lib():
     return _lib
 
 
+# When a list: every checked launching call appends (what, chebgcn_last_dispatch()) -- the kernel templates the
+# dispatchers chose for that call.  Tests assert the instantiation they claim to reach with it; None = off.
+dispatch_log = None
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().chebgcn_last_error()
         raise ChebgcnError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+    if dispatch_log is not None:
+        dispatch_log.append((what, lib().chebgcn_last_dispatch().decode()))
+
+
+def last_dispatch():
+    """Kernel templates the calling thread's last launching entry point enqueued (chebgcn_last_dispatch)."""
+    return lib().chebgcn_last_dispatch().decode()
 
 
 def plane_stride(M):

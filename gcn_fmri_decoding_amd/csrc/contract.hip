@@ -519,7 +519,10 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
     // ReLU mask of row fo: one byte per four vertices, 32 bytes = 8 dwords for the 128 vertices of the tile.  Lane c
     // fetches dword c & 7 of its row (one load per row); the bit of vertex 32 r + c sits in byte 8 r + (c >> 2), i.e. in the
     // dword lane 2 r + (c >> 4) of the same half-wave holds: one ds_bpermute per accumulator instead of a byte load.
-    const uint8_t* mkb = MASK ? a.mask + (size_t)b * a.Fout * Mq + ((wave_live ? m0 : 0) >> 2) + 4 * (c & 7) : nullptr;
+    // A mask row is Mp / 4 bytes (planes are padded to 32 vertices, not to the 128 of a tile): in the last tile of a window the
+    // dwords beyond the row alias dword 0 (their accumulators are dropped by ok[r]); nothing is read past the allocation.
+    const int mdw = (wave_live && m0 + 16 * (c & 7) < a.Mp) ? (c & 7) : 0;
+    const uint8_t* mkb = MASK ? a.mask + (size_t)b * a.Fout * Mq + ((wave_live ? m0 : 0) >> 2) + 4 * mdw : nullptr;
     float hold[16][4];
     int mword[16];
 #pragma unroll
@@ -528,8 +531,6 @@ contract_bwd_x_lds_kernel(BwdXArgs a, int nrows32) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) hold[j][r] = CG_DY_NT ? __builtin_nontemporal_load(dyb + (size_t)foc * a.dy_fstride + (ok[r] ? 32 * r : 0))
                                                          : dyb[(size_t)foc * a.dy_fstride + (ok[r] ? 32 * r : 0)];
-        // (the row's 32 mask bytes exist for every r: planes are padded to 32 vertices and a tile is 4 x 32; beyond the
-        // plane the accumulator is dropped by ok[r])
         mword[j] = MASK ? *reinterpret_cast<const int*>(mkb + (size_t)foc * Mq) : -1;
     }
     for (int i0 = threadIdx.x; i0 < nrows32 * 32; i0 += 256 * FILL_U) {     // (eight loads in flight: see contract_fwd_ring_kernel)
@@ -905,9 +906,11 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
     const int gx = (M + 511) / 512;
     if (Fout > 32) {
         dim3 grid(gx, B, (Fout + 63) / 64);
+        note_dispatch("contract_fwd_kernel<2>");
         hipLaunchKernelGGL(contract_fwd_kernel<2>, grid, dim3(256), 0, stream, a);
     } else if (small_launch(B, M)) {
         dim3 grid((M + 127) / 128, B, 1);
+        note_dispatch("contract_fwd_splitk_kernel");
         hipLaunchKernelGGL(contract_fwd_splitk_kernel, grid, dim3(256), 0, stream, a);
     } else {
         dim3 grid(gx, B, 1);
@@ -915,11 +918,13 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
         // whole ring rounds of row pairs; W and the row offsets of the padded rows in LDS (136 bytes per row)
         const int nrows_pad = ((a.FinK + 2 * RING - 1) / (2 * RING)) * (2 * RING);
         if ((size_t)nrows_pad * 136 <= 48 * 1024 && RING <= 8 && (bias_kind != CHEBGCN_BIAS_FILTER || Fout >= 4)) {
+            note_dispatch("contract_fwd_ring_kernel");
             hipLaunchKernelGGL(contract_fwd_ring_kernel, grid, dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
             CG_HIP(hipGetLastError());
             return CHEBGCN_OK;
         }
 #endif
+        note_dispatch("contract_fwd_kernel<1>");
         hipLaunchKernelGGL(contract_fwd_kernel<1>, grid, dim3(256), 0, stream, a);
     }
     CG_HIP(hipGetLastError());
@@ -930,7 +935,9 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
 static int ring_rows(int FinK) { return ((FinK + 2 * RING - 1) / (2 * RING)) * (2 * RING); }
 
 extern "C" int chebgcn_contract_fwd_mean_supported(int B, int M, int Fin, int K, int Fout) {
-    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0 || Fout > 32 || B > 65535) return 0;
+    // Fout < 4: the ring kernel's 16-byte load around a per-filter bias would start in front of the array (chebgcn_contract_fwd
+    // sends such layers to contract_fwd_kernel<1>); not served here whatever the bias kind
+    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout < 4 || Fout > 32 || B > 65535) return 0;
     return !small_launch(B, M) && (size_t)ring_rows(Fin * K) * 136 <= 48 * 1024;
 }
 
@@ -950,6 +957,7 @@ extern "C" int chebgcn_contract_fwd_mean(const float* stack, const float* W, con
     a.Mo = M; a.Mpo = a.Mp;
     a.slab = (size_t)B * Fin * a.Mp;
     const int nrows_pad = ring_rows(a.FinK);
+    note_dispatch("contract_fwd_ring_kernel<mean>");
     hipLaunchKernelGGL(contract_fwd_ring_kernel, dim3((M + 511) / 512, B, 1), dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
@@ -965,12 +973,17 @@ static int launch_bwd_x(const float* dy, const uint8_t* mask, const float* W, fl
     a.dy_fstride = one_plane ? 0 : (size_t)a.Mp;
     if (small_launch(B, M)) {
         dim3 sgrid((M + 127) / 128, B, 1);
+#define CG_BX(H, MK, SP, G)                                                                     \
+    do {                                                                                        \
+        note_dispatch("contract_bwd_x_kernel<" #H "," #MK "," #SP ">");                          \
+        hipLaunchKernelGGL((contract_bwd_x_kernel<H, MK, SP>), G, dim3(256), 0, stream, a);      \
+    } while (0)
         if (mask) {
-            if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, true, true>), sgrid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((contract_bwd_x_kernel<false, true, true>), sgrid, dim3(256), 0, stream, a);
+            if (Fout <= 32) CG_BX(true, true, true, sgrid);
+            else CG_BX(false, true, true, sgrid);
         } else {
-            if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, false, true>), sgrid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((contract_bwd_x_kernel<false, false, true>), sgrid, dim3(256), 0, stream, a);
+            if (Fout <= 32) CG_BX(true, false, true, sgrid);
+            else CG_BX(false, false, true, sgrid);
         }
         CG_HIP(hipGetLastError());
         return CHEBGCN_OK;
@@ -979,6 +992,7 @@ static int launch_bwd_x(const float* dy, const uint8_t* mask, const float* W, fl
 #if CG_BWX_LDS
     const int nrows32 = ((a.FinK + 31) / 32) * 32;
     if (Fout <= 32 && a.FinK % 32 == 0 && (size_t)nrows32 * 136 <= 48 * 1024) {
+        note_dispatch(mask ? "contract_bwd_x_lds_kernel<true>" : "contract_bwd_x_lds_kernel<false>");
         if (mask) hipLaunchKernelGGL((contract_bwd_x_lds_kernel<true>), grid, dim3(256), (size_t)nrows32 * 136, stream, a, nrows32);
         else hipLaunchKernelGGL((contract_bwd_x_lds_kernel<false>), grid, dim3(256), (size_t)nrows32 * 136, stream, a, nrows32);
         CG_HIP(hipGetLastError());
@@ -986,12 +1000,13 @@ static int launch_bwd_x(const float* dy, const uint8_t* mask, const float* W, fl
     }
 #endif
     if (mask) {
-        if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((contract_bwd_x_kernel<false, true>), grid, dim3(256), 0, stream, a);
+        if (Fout <= 32) CG_BX(true, true, false, grid);
+        else CG_BX(false, true, false, grid);
     } else {
-        if (Fout <= 32) hipLaunchKernelGGL((contract_bwd_x_kernel<true, false>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((contract_bwd_x_kernel<false, false>), grid, dim3(256), 0, stream, a);
+        if (Fout <= 32) CG_BX(true, false, false, grid);
+        else CG_BX(false, false, false, grid);
     }
+#undef CG_BX
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
@@ -1041,6 +1056,7 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
 #define CG_BWK contract_bwd_w_kernel
 #define CG_BW(N)                                                                                        \
     case N:                                                                                             \
+        note_dispatch(mask ? "contract_bwd_w_kernel<" #N ",true>" : "contract_bwd_w_kernel<" #N ",false>"); \
         if (mask) {                                                                                     \
             CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(CG_BWK<N, true>),                  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
@@ -1059,12 +1075,15 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
 #undef CG_BWK
     CG_HIP(hipGetLastError());
     if (gx <= 256) {
+        note_dispatch_more("reduce_partials_small");
         hipLaunchKernelGGL(reduce_partials_small, dim3(rt * 16, gy, gz), dim3(256), 0, stream, (const float*)workspace, dW, gx, gy, rt,
                            a.FinK, Fout);
         CG_HIP(hipGetLastError());
         return CHEBGCN_OK;
     }
     float* stage = (float*)workspace + (size_t)gx * gy * gz * rt * 16 * 64;
+    note_dispatch_more("reduce_partials_stage1");
+    note_dispatch_more("reduce_partials_stage2");
     hipLaunchKernelGGL(reduce_partials_stage1, dim3(rt * 16, gy * BW_SPLIT, gz), dim3(256), 0, stream,
                        (const float*)workspace, stage, gx, gy, rt);
     hipLaunchKernelGGL(reduce_partials_stage2, dim3(rt * 16, gy, gz), dim3(64), 0, stream, (const float*)stage, dW,

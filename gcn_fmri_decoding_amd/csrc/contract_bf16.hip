@@ -700,6 +700,7 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
     a.Mo = M / pool; a.Mpo = plane_stride(a.Mo);
     a.slab = (size_t)B * Fin * a.Mp;
     const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + 255) / 256 * 256;
+    note_dispatch("pack_w_bf16_kernel");
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
                        a.FinK, Fout, nks, FoutP, passes == 3 ? 2 : 1, 0);
     CG_HIP(hipGetLastError());
@@ -726,6 +727,7 @@ static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, h
 #define CG_BF16_LAUNCH(P, NW)                                                                                      \
     do {                                                                                                           \
         constexpr int lds = Bf16Cfg<P, NW>::NSTAGE * Bf16Cfg<P, NW>::STAGE;                                        \
+        note_dispatch_more("contract_fwd_bf16_kernel<" #P "," #NW ">");                                            \
         CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_fwd_bf16_kernel<P, NW>),                 \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                              \
         hipLaunchKernelGGL((contract_fwd_bf16_kernel<P, NW>), grid, dim3(NW * 64), lds, stream, a,                 \
@@ -776,6 +778,7 @@ extern "C" int chebgcn_contract_bwd_x_bf16(const float* dy, const float* W, floa
     a.out_K = K;
     const int nw = bwd_x_bf16_waves(a.Fout), G = 64 * nw;
     const int nks = bf16_ksteps(a.FinK), FoutP = (a.Fout + G - 1) / G * G;
+    note_dispatch("pack_w_bf16_kernel<transposed>");
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
                        a.FinK, a.Fout, nks, FoutP, passes == 3 ? 2 : 1, Fout);
     CG_HIP(hipGetLastError());
@@ -809,6 +812,7 @@ extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, 
         const size_t ldsw = (size_t)BWW_NBUF * BWW_BUF;
         const long long total = (long long)B * a.nchunks_m;
         CG_REQUIRE(total < (1ll << 31), "contract_bwd_w_bf16: too many chunks");
+        note_dispatch(passes == 3 ? "contract_bwd_w_bf16_wide_kernel<3>" : "contract_bwd_w_bf16_wide_kernel<1>");
         if (passes == 3) {
             CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_wide_kernel<3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
@@ -822,6 +826,7 @@ extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, 
     const size_t lds = (size_t)(p.rt + p.ct) * 32 * BWB_ROW * sizeof(float);
 #define CG_BWB(R, C, P)                                                                                   \
     if (p.rt == R && p.ct == C && passes == P) {                                                          \
+        note_dispatch("contract_bwd_w_bf16_kernel<" #R "," #C "," #P ">");                                \
         CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_kernel<R, C, P>),    \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
         hipLaunchKernelGGL((contract_bwd_w_bf16_kernel<R, C, P>), grid, dim3(256), lds, stream, a);       \
@@ -833,6 +838,8 @@ extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, 
     CG_HIP(hipGetLastError());
     const int rows = p.rt * p.ct * 16;
     float* stage = (float*)workspace + (size_t)p.gx * p.gy * p.gz * p.per;
+    note_dispatch_more("bwb_reduce_stage1");
+    note_dispatch_more("bwb_reduce_stage2");
     hipLaunchKernelGGL(bwb_reduce_stage1, dim3(rows, p.gy * BWB_SPLIT, p.gz), dim3(256), 0, stream,
                        (const float*)workspace, stage, p.gx, p.gy, rows);
     hipLaunchKernelGGL(bwb_reduce_stage2, dim3(rows, p.gy, p.gz), dim3(64), 0, stream, (const float*)stage, dW, p.gy,

@@ -24,6 +24,29 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace {
+struct DispatchRecord {
+    const char* name[6];
+    int n;
+    char joined[512];
+};
+DispatchRecord& dispatch_record() {
+    static thread_local DispatchRecord r = {{nullptr}, 0, {0}};
+    return r;
+}
+}  // namespace
+
+void note_dispatch(const char* name) {
+    DispatchRecord& r = dispatch_record();
+    r.name[0] = name;
+    r.n = 1;
+}
+
+void note_dispatch_more(const char* name) {
+    DispatchRecord& r = dispatch_record();
+    if (r.n < 6) r.name[r.n++] = name;
+}
+
 template <typename T>
 static int upload(T** dst, const std::vector<T>& src) {
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
@@ -291,6 +314,17 @@ using namespace chebgcn;
 
 extern "C" int chebgcn_version(void) { return CHEBGCN_VERSION; }
 extern "C" const char* chebgcn_last_error(void) { return err_buf(); }
+extern "C" const char* chebgcn_last_dispatch(void) {
+    DispatchRecord& r = dispatch_record();
+    size_t at = 0;
+    r.joined[0] = 0;
+    for (int i = 0; i < r.n; ++i) {
+        const int w = snprintf(r.joined + at, sizeof(r.joined) - at, "%s%s", i ? " + " : "", r.name[i]);
+        if (w < 0 || (size_t)w >= sizeof(r.joined) - at) break;
+        at += (size_t)w;
+    }
+    return r.joined;
+}
 extern "C" int chebgcn_plane_stride(int M) { return plane_stride(M); }
 
 extern "C" int chebgcn_graph_create(int M, int64_t nnz, const int32_t* rowptr, const int32_t* colidx,

@@ -254,6 +254,8 @@ extern "C" int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const
     const int nchunks = (I + FC_CHUNK - 1) / FC_CHUNK, cps = (nchunks + S - 1) / S;
     CG_REQUIRE(S == 1 || (workspace && workspace_bytes >= chebgcn_fc_fwd_workspace(B, I, O)), "fc_fwd: workspace too small");
     dim3 grid((O + 31) / 32, (B + 31) / 32, S);
+    note_dispatch(S > 1 ? "fc_fwd_kernel<split>" : "fc_fwd_kernel");
+    if (S > 1) note_dispatch_more("fc_fwd_reduce_kernel");
     hipLaunchKernelGGL(fc_fwd_kernel, grid, dim3(FC_WAVES * 64), 0, stream, x, (long long)ldx, W, bias, y,
                        S > 1 ? (float*)workspace : nullptr, B, I, O, relu, cps);
     if (S > 1)
@@ -268,6 +270,7 @@ extern "C" int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const
     hipStream_t stream = (hipStream_t)stream_;
     CG_REQUIRE(x && W && g && B > 0 && I > 0 && O > 0 && ldx >= I && (!dx || lddx >= I), "fc_bwd: bad argument");
     if (!chebgcn_fc_fwd_supported(B, I, O)) return CHEBGCN_EUNSUPPORTED;
+    note_dispatch(dW ? "fc_bwd_w_kernel" : "");
     if (dW) {
         dim3 grid((O + 31) / 32, (I + 31) / 32);
         hipLaunchKernelGGL(fc_bwd_w_kernel, grid, dim3(FC_WAVES * 64), 0, stream, x, (long long)ldx, g, y, dW, db, B, I, O);
@@ -275,6 +278,7 @@ extern "C" int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const
     if (dx) {
         dim3 grid((I + 31) / 32, (B + 31) / 32);
         const bool vec = (O & 3) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)W & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0);
+        note_dispatch_more(vec ? "fc_bwd_x_kernel<true>" : "fc_bwd_x_kernel<false>");
         if (vec)
             hipLaunchKernelGGL(fc_bwd_x_kernel<true>, grid, dim3(FC_WAVES * 64), 0, stream, g, y, W, dx, (long long)lddx, B, I, O);
         else

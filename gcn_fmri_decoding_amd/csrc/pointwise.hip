@@ -322,6 +322,7 @@ extern "C" int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bia
                "brelu_pool_fwd: average pooling keeps a ReLU mask only for pool <= 8");
     const int Mp = plane_stride(M), Mo = M / pool, Mpo = plane_stride(Mo);
     dim3 grid((Mpo + 255) / 256, F, B);
+    note_dispatch("brelu_pool_fwd_kernel");
     hipLaunchKernelGGL(brelu_pool_fwd_kernel, grid, dim3(256), 0, stream, x, bias, out, argmax, M, Mp, F, pool,
                        pool_kind, relu, bias_kind, Mo, Mpo);
     CG_HIP(hipGetLastError());
@@ -374,6 +375,7 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
         const dim3 grid(nblk, F);
 #define CG_BGR(BK)                                                                                                         \
     do {                                                                                                                   \
+        note_dispatch(parts == 16 ? "bias_grad_relu_kernel<" #BK ",16>" : "bias_grad_relu_kernel<" #BK ",4>");             \
         if (parts == 16)                                                                                                   \
             hipLaunchKernelGGL((bias_grad_relu_kernel<BK, 16>), grid, dim3(256), 0, stream, dout, argmax, dy, dbias, fpart, B, M, \
                                Mp, F, (size_t)F * Mp, (size_t)Mp);                                                         \
@@ -386,9 +388,12 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
         else CG_BGR(CHEBGCN_BIAS_NONE);
 #undef CG_BGR
     } else {
-#define CG_BRELU(BK, PARTS)                                                                                       \
-    hipLaunchKernelGGL((brelu_pool_bwd_kernel<BK, PARTS>), dim3(nblk, F), dim3(256), 0, stream, dout, out, argmax, dy, \
-                       dbias, fpart, B, M, Mp, F, pool, pool_kind, relu, Mpo)
+#define CG_BRELU(BK, PARTS)                                                                                           \
+    do {                                                                                                              \
+        note_dispatch("brelu_pool_bwd_kernel<" #BK "," #PARTS ">");                                                   \
+        hipLaunchKernelGGL((brelu_pool_bwd_kernel<BK, PARTS>), dim3(nblk, F), dim3(256), 0, stream, dout, out, argmax, dy, \
+                           dbias, fpart, B, M, Mp, F, pool, pool_kind, relu, Mpo);                                    \
+    } while (0)
 #define CG_BRELU_P(BK)                                                        \
     do {                                                                      \
         if (parts == 1) CG_BRELU(BK, 1);                                      \
@@ -403,6 +408,7 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
     }
     CG_HIP(hipGetLastError());
     if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        note_dispatch_more("bias_filter_reduce_kernel");
         hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
         CG_HIP(hipGetLastError());
     }
@@ -423,6 +429,8 @@ extern "C" int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* re
         CG_REQUIRE(workspace && workspace_bytes >= (size_t)F * nblk * sizeof(float),
                    "bias_grad_relu_mean: the per-filter bias gradient needs a workspace of chebgcn_brelu_pool_bwd_workspace() bytes");
         fpart = static_cast<float*>(workspace);
+        note_dispatch(parts == 16 ? "bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER,16><mean>" : "bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER,4><mean>");
+        note_dispatch_more("bias_filter_reduce_kernel");
         if (parts == 16)
             hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER, 16>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
                                (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
@@ -431,6 +439,7 @@ extern "C" int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* re
                                (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
         hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
     } else {
+        note_dispatch(parts == 16 ? "bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,16><mean>" : "bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4><mean>");
         if (parts == 16)
             hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX, 16>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
                                (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);

@@ -32,6 +32,8 @@
 //     each piece issued right after a group's operator loads so that later waits on those
 //     loads never cover the stores;
 //   * workgroups of one XCD start staggered so that they are in different phases.
+#include <string>
+
 #include "common.h"
 
 namespace chebgcn {
@@ -611,6 +613,9 @@ static int launch_onchip(const chebgcn_graph* g, const Ell& ell, const float* sr
                        (size_t)lds_id_levels(NJ, NTHR, P) * (NTHR >> 6) * 2 * 1024;
     static_assert(NQ <= NJ, "a linear piece is issued per group at most");
     auto kern = cheb_onchip_kernel<P, NJ, NQ, NTHR, ADJ>;
+    static const std::string name = "cheb_onchip_kernel<" + std::to_string(P) + "," + std::to_string(NJ) + "," + std::to_string(NQ) +
+                                    "," + std::to_string(NTHR) + "," + (ADJ ? "true" : "false") + ">";
+    note_dispatch(name.c_str());
     int per_cu = (int)((160 * 1024) / lds);
     per_cu = per_cu < 1 ? 1 : per_cu;
     if (per_cu > 2048 / NTHR) per_cu = 2048 / NTHR;
@@ -654,6 +659,7 @@ static int dispatch_onchip(const chebgcn_graph* g, const Ell& ell, const float* 
 static int step_global(const chebgcn_graph* g, const Ell& ell, const float* src, const float* sub,
                        const float* add, float* out, int nplanes, float f, hipStream_t stream) {
     dim3 grid((g->M + 255) / 256, nplanes);
+    note_dispatch("cheb_step_global_kernel");
     hipLaunchKernelGGL(cheb_step_global_kernel, grid, dim3(256), 0, stream, ell.rowptr, ell.col32,
                        ell.cval, src, sub, add, out, g->M, g->Mp, f);
     CG_HIP(hipGetLastError());

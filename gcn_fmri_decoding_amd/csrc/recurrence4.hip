@@ -28,6 +28,8 @@
 //     the barrier that ended the last gather, so its HBM latency hides under the last rotate.
 #include <type_traits>
 
+#include <string>
+
 #include "common.h"
 
 namespace chebgcn {
@@ -941,13 +943,18 @@ int launch4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst
     if (grid > ngrp) grid = ngrp;
     const size_t slab = (size_t)nplanes * g->Mp;
     bool launched = false;
+    static const std::string stem = "cheb4_kernel<" + std::to_string(ENT) + "," + std::to_string(NJ) + "," + std::to_string(NQ) + "," +
+                                    std::to_string(NT4) + "," + (ADJ ? "true" : "false");
+    static const std::string name_iso = stem + ",true>", name_plain = stem + ",false>";
     if constexpr (!ADJ) {                            // (the adjoint keeps the round-2 scheme: see `xi` in the kernel)
         if (ell.iso_max512 <= NISO) {
+            note_dispatch(name_iso.c_str());
             hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, NT4, ADJ, true>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M,
                                g->Mp, nplanes, K, slab, copy_t0 | (g_stagger << 20));
             launched = true;
         }
     }
+    if (!launched) note_dispatch(name_plain.c_str());
     if (!launched)
         hipLaunchKernelGGL((cheb4_kernel<ENT, NJ, NQ, NT4, ADJ, false>), dim3(grid), dim3(NT4), 0, stream, view(ell), src, dst, g->M,
                            g->Mp, nplanes, K, slab, copy_t0 | (g_stagger << 20));

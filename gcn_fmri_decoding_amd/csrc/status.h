@@ -12,6 +12,11 @@ namespace chebgcn {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 
+// thread-local record behind chebgcn_last_dispatch(): the kernel templates the calling thread's last launching entry point
+// enqueued.  Names must have static storage (string literals, or one string built once per template instantiation).
+void note_dispatch(const char* name);         // first kernel of a call: starts a new record
+void note_dispatch_more(const char* name);    // further kernels of the same call
+
 }  // namespace chebgcn
 
 #define CG_REQUIRE(cond, ...)                                           \

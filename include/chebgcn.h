@@ -52,6 +52,11 @@ typedef void* chebgcn_stream;
 
 int chebgcn_version(void);
 const char* chebgcn_last_error(void);
+/* Names of the kernel templates the calling thread's last launching entry point enqueued, in launch order, joined by
+ * " + " (e.g. "contract_bwd_w_kernel<5,true> + reduce_partials_stage1 + reduce_partials_stage2"); "" before the first
+ * launch.  The dispatchers below choose instantiations by shape and by the device's CU count: this is how a test (or a
+ * profile) names the one a given call reached.  The pointer stays valid until the thread's next call of this function. */
+const char* chebgcn_last_dispatch(void);
 
 /* Padded plane length for M vertices (multiple of 32 floats = 128 B). */
 int chebgcn_plane_stride(int M);
@@ -192,7 +197,7 @@ int chebgcn_contract_bwd_x(const float* dy, const float* W, float* gstack, int B
  * last layer need not store its [B][Fout][Mp] output at all:
  *   chebgcn_contract_fwd_mean: mean_out[b][m] = (1/Fout) sum_o relu(y[b][o][m] + bias), [B][Mp]; relu_mask as
  *     chebgcn_contract_fwd writes it (may be NULL for inference).  pool = 1, ReLU.  Served where
- *     chebgcn_contract_fwd_mean_supported() returns 1 (Fout <= 32, a big launch, Fin*K*136 bytes <= 48 KB);
+ *     chebgcn_contract_fwd_mean_supported() returns 1 (4 <= Fout <= 32, a big launch, Fin*K*136 bytes <= 48 KB);
  *     CHEBGCN_EUNSUPPORTED otherwise (run chebgcn_contract_fwd + chebgcn_feature_mean_fwd).
  *   backward: d(loss)/d(y[b][o][m]) = gmean[b][m] for EVERY filter o, gmean = d(loss)/d(mean) / Fout, [B][Mp] (zero in the
  *     padding): the three gradients of a ReLU-folded layer read that one plane per window instead of a [B][Fout][Mp]

@@ -71,3 +71,18 @@ def assert_adam_params_close(got, ref, v_ref, step, ill, key, rel=2e-5, lr=1e-3,
         worst = d[well].max() if quantile >= 1.0 else np.quantile(d[well], quantile)
         assert worst <= rel * scale, 'step %d %s: rel err %.3e' % (step, key, worst / scale)
     assert d.max() <= 1.1 * lr * (step + 1), 'step %d %s: max diff %.3e' % (step, key, d.max())
+
+
+def record_measured(test, **values):
+    """Measured parity errors of a GPU test, appended as one JSON line to gpurun_out/parity_measured.jsonl (scratch on the
+    GPU box; the round's copy is committed as profiles/rNN_parity_measured.jsonl).  A passing test prints nothing under
+    ``pytest -q``: this is where the margins to the asserted bounds can be read afterwards."""
+    import json
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_measured.jsonl'), 'a') as f:
+            f.write(json.dumps(dict(test=test, **{k: (float(v) if isinstance(v, (int, float, np.floating)) else v)
+                                                  for k, v in values.items()})) + '\n')
+    except OSError:
+        pass

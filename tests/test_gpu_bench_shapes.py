@@ -3,20 +3,26 @@ configs[1] and configs[3] on the full-size graph (M = 10466) -- against the CPU 
 through the C ABI.  Needs an MI355X: ``-m gpu``.
 
 The layer tests of test_gpu_parity.py run on the N = 212 fixture graphs, where the
-dispatchers pick other template instantiations (Fin*K <= 75 there).  Here every case names
-the kernels it reaches:
+dispatchers pick other template instantiations (Fin*K <= 75 there).  The single-layer cases
+here run batches of 1..3 windows through autograd: on the 256 CUs of an MI355X those are SMALL
+launches (contract.hip ``small_launch``: ceil(M/512) * B < 2 * CUs), i.e. the split kernels.
+Each case asserts the templates it reaches through ``chebgcn_last_dispatch()``
+(``_lib.dispatch_log``); the big-launch arms (ring / LDS / config 4 / config 5 at batch >= 25)
+have their value tests in test_gpu_dispatch.py.
 
 =====================================  =========================================================
-case                                   instantiations (contract.hip / pointwise.hip / recurrence.hip)
+case                                   templates (asserted)
 =====================================  =========================================================
-layer 32 -> 32, K=5, b2relu (config 2) contract_fwd<1> over 21 column blocks, bwd_x<HOLD>,
-                                       bwd_w<RT=5>, brelu_pool_bwd<VERTEX, PARTS=1>, on-chip
-                                       recurrence forward + adjoint at the bench shape
-layer 15 -> 32 (first layer)           bwd_w<RT=3>, no dx
-layer 64 -> 64, K=25 (config 4)        contract_fwd<2>, bwd_x<!HOLD>, bwd_w<RT=5> with gy = 10
-RT sweep on the N=212 graph            bwd_w<RT=1..5> and gy = 2, value comparison
-PARTS sweep                            brelu_pool_bwd PARTS = 1 / 4 / 8 for all three bias kinds
+layer 32 -> 32, K=5, b2relu, B=3       contract_fwd_splitk_kernel, contract_bwd_x_kernel<true,true,true>,
+                                       contract_bwd_w_kernel<5,true> + reduce_partials_small,
+                                       bias_grad_relu_kernel<VERTEX,4>, cheb_onchip_kernel<2,14,4,768,*>
+layer 15 -> 32 (first layer), B=2      contract_bwd_w_kernel<3,true>, no dx
+layer 64 -> 64, K=25 (config 4), B=1   contract_fwd_kernel<2>, contract_bwd_x_kernel<false,true,true>,
+                                       contract_bwd_w_kernel<5,true> with gy = 10
+RT sweep on the N=212 graph            contract_bwd_w_kernel<RT,true> for RT = 1..5 and gy = 2 / 10
+PARTS sweep                            brelu_pool_bwd_kernel<BIAS, 1 / 4 / 8> for all three bias kinds
 6-layer configs[1] net, B = 2          everything above in sequence: logits, loss, 3 Adam steps
+contraction launches at batch 64/256   ring forward, two-phase bwd_x, bwd_w on 768 workgroups (float64 products)
 =====================================  =========================================================
 
 Tolerance: max|hip - ref| <= 1e-5 * max|ref| forward (north star: 1e-5 relative fp32);
@@ -78,8 +84,23 @@ def from_storage(st, M):
     return st[:, :, :M].permute(0, 2, 1).cpu().numpy()
 
 
-def run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3):
-    """One conv layer forward + backward, HIP against oracle.  Returns the error dict."""
+def run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3, expect=None):
+    """One conv layer forward + backward, HIP against oracle.  Returns the error dict.  ``expect``: entry point ->
+    kernel templates (prefix) the dispatchers must have chosen for it (chebgcn_last_dispatch)."""
+    from gcn_fmri_decoding_amd import _lib
+    _lib.dispatch_log = log = []
+    try:
+        errs = _run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx, wscale)
+        torch.cuda.synchronize()
+    finally:
+        _lib.dispatch_log = None
+    for what, name in (expect or {}).items():
+        seen = [n for w, n in log if w == what]
+        assert seen and all(n.startswith(name) for n in seen), (what, seen, name)
+    return errs
+
+
+def _run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3):
     M = L.shape[0]
     g = ops.graph_for(L, dev)
     rs = np.random.RandomState(seed)
@@ -142,19 +163,26 @@ def run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=Tr
 
 def test_config2_layer_32_32_k5(ops, dev, bench_graph):
     """Layers 2-6 of configs[1]: Fin = Fout = 32, K = 5, b2relu, no pooling."""
-    errs = run_layer(ops, dev, bench_graph, B=3, Fin=32, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=1)
+    errs = run_layer(ops, dev, bench_graph, B=3, Fin=32, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=1, expect={
+        'contract_fwd': 'contract_fwd_splitk_kernel', 'contract_bwd_x_relu': 'contract_bwd_x_kernel<true,true,true>',
+        'contract_bwd_w': 'contract_bwd_w_kernel<5,true>', 'brelu_pool_bwd': 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>',
+        'recurrence_fwd': 'cheb_onchip_kernel<2,14,4,768,false>', 'recurrence_bwd': 'cheb_onchip_kernel<2,14,4,768,true>'})
     print('config2 layer errors', errs)
 
 
 def test_config2_first_layer_15_32_k5(ops, dev, bench_graph):
     """Layer 1 of configs[1]: block_dura = 15 input features, no gradient wrt the input."""
-    run_layer(ops, dev, bench_graph, B=2, Fin=15, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=2, need_dx=False)
+    run_layer(ops, dev, bench_graph, B=2, Fin=15, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=2, need_dx=False,
+              expect={'contract_fwd': 'contract_fwd_splitk_kernel', 'contract_bwd_w': 'contract_bwd_w_kernel<3,true>'})
 
 
 def test_config4_layer_64_64_k25(ops, dev, bench_graph):
     """configs[3]: K = 25, Fin = Fout = 64 -- Fin*K = 1600 (50 row tiles -> gy = 10 in bwd_w),
-    Fout = 64 (two filter tiles in contract_fwd, dy streamed instead of held in bwd_x)."""
-    run_layer(ops, dev, bench_graph, B=1, Fin=64, Fout=64, K=25, p=1, pool_kind=0, bias=2, seed=3)
+    Fout = 64 (two filter tiles in contract_fwd, dy streamed instead of held in bwd_x); one window = a small launch
+    (the big-launch arms of this shape: test_gpu_dispatch.py ``config4_b25``)."""
+    run_layer(ops, dev, bench_graph, B=1, Fin=64, Fout=64, K=25, p=1, pool_kind=0, bias=2, seed=3, expect={
+        'contract_fwd': 'contract_fwd_kernel<2>', 'contract_bwd_x_relu': 'contract_bwd_x_kernel<false,true,true>',
+        'contract_bwd_w': 'contract_bwd_w_kernel<5,true>'})
 
 
 def test_pooled_layer_full_size(ops, dev, bench_graph):
@@ -177,7 +205,8 @@ def test_bwd_w_row_tile_sweep(ops, dev, Fin, K, rt, gy):
     """contract_bwd_w_kernel<RT> for RT = 1..5 and several row-tile groups (gy > 1)."""
     ntiles = (Fin * K + 31) // 32
     assert min(ntiles, 5) == rt and (ntiles + rt - 1) // rt == gy      # the dispatcher's arithmetic (contract.hip bw_rt)
-    run_layer(ops, dev, levels()[0], B=2, Fin=Fin, Fout=40, K=K, p=1, pool_kind=0, bias=2, seed=Fin + K)
+    run_layer(ops, dev, levels()[0], B=2, Fin=Fin, Fout=40, K=K, p=1, pool_kind=0, bias=2, seed=Fin + K,
+              expect={'contract_bwd_w': 'contract_bwd_w_kernel<%d,true>' % rt})
 
 
 @pytest.mark.parametrize('lvl,F,parts', [(0, 256, 4), (0, 24, 8), (2, 33, 8)])
@@ -189,13 +218,19 @@ def test_brelu_pool_bwd_parts_small_graph(ops, dev, lvl, F, parts, bias):
     M = L.shape[0]
     got = 1 if ((M + 255) // 256) * F >= 1024 else 4 if ((M + 63) // 64) * F >= 1024 else 8
     assert got == parts                                                # the dispatcher's arithmetic (pointwise.hip)
-    run_layer(ops, dev, L, B=5, Fin=2, Fout=F, K=2, p=2, pool_kind=0, bias=bias, seed=F + bias)
+    kind = ['CHEBGCN_BIAS_NONE', 'CHEBGCN_BIAS_FILTER', 'CHEBGCN_BIAS_VERTEX'][bias]
+    run_layer(ops, dev, L, B=5, Fin=2, Fout=F, K=2, p=2, pool_kind=0, bias=bias, seed=F + bias,
+              expect={'brelu_pool_bwd': 'brelu_pool_bwd_kernel<%s,%d>' % (kind, parts)})
 
 
 @pytest.mark.parametrize('bias,p,pool_kind', [(0, 1, 0), (1, 1, 0), (2, 2, 0), (2, 2, 1)])     # M = 10466 = 2 * 5233
 def test_brelu_pool_bwd_parts1_full_size(ops, dev, bench_graph, bias, p, pool_kind):
     """PARTS = 1 (41 * 32 >= 1024 blocks) for the bias kinds / pooling forms not covered above."""
-    run_layer(ops, dev, bench_graph, B=2, Fin=3, Fout=32, K=2, p=p, pool_kind=pool_kind, bias=bias, seed=10 * bias + p)
+    kind = ['CHEBGCN_BIAS_NONE', 'CHEBGCN_BIAS_FILTER', 'CHEBGCN_BIAS_VERTEX'][bias]
+    # (pool 1 with ReLU takes the bit-mask kernel instead; without ReLU -- bias 0 -- and with pooling: PARTS = 1)
+    name = 'bias_grad_relu_kernel<%s,4>' % kind if (p == 1 and bias != 0) else 'brelu_pool_bwd_kernel<%s,1>' % kind
+    run_layer(ops, dev, bench_graph, B=2, Fin=3, Fout=32, K=2, p=p, pool_kind=pool_kind, bias=bias, seed=10 * bias + p,
+              expect={'brelu_pool_bwd': name})
 
 
 # ---------------------------------------------------------------------------------------
@@ -387,8 +422,8 @@ def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K):
 
 def test_contraction_bench_launch_b64(ops, dev):
     """The contraction launches of the bench step at their real size (batch 64, M = 10466, Fin = Fout = 32,
-    K = 5: contract_fwd<1> with the ReLU bit mask, contract_bwd_w_kernel<5, true> on 768 workgroups + the
-    two reduce kernels, contract_bwd_x_kernel<true, true>, bias_grad_relu_kernel) against float64 matrix
+    K = 5: contract_fwd_ring_kernel with the ReLU bit mask, contract_bwd_w_kernel<5,true> on 768 workgroups,
+    contract_bwd_x_lds_kernel<true>, bias_grad_relu_kernel) against float64 matrix
     products of the same operands computed on the device (1e-5 / 2e-5 of max, pads poisoned)."""
     import ctypes
     from gcn_fmri_decoding_amd import _lib

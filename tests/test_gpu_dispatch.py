@@ -1,0 +1,393 @@
+"""Every arm of the library's dispatchers, reached by a VALUE test that names it.  Needs an MI355X: ``-m gpu``.
+
+The dispatchers of libchebgcn.so choose kernel templates by shape and by the device's CU count
+(contract.hip ``small_launch`` / ring / LDS conditions, ``bw_rt``, recurrence.hip ``dispatch_onchip``, ``pick_ell``,
+pointwise.hip ``brelu_bwd_blocks``).  ``chebgcn_last_dispatch()`` reports which templates the last launching call
+enqueued; each case below asserts that name -- a change of a dispatch condition that silently moves a test onto
+another kernel fails here -- and then compares the results with float64 products of the same operands computed on the
+device (pads poisoned with NaN), or with the CPU oracle.  All numbers assume the 256 CUs of an MI355X.
+
+=============================================  ===============================================================
+case (M = 10466 unless stated)                 kernel templates asserted
+=============================================  ===============================================================
+bench step, B=64, 32->32, K=5                  contract_fwd_ring_kernel, contract_bwd_x_lds_kernel<true|false>,
+                                               contract_bwd_w_kernel<5,true|false> (768 workgroups, in-kernel reduce)
+config 4 big launch, B=25, 64->64, K=25        contract_fwd_kernel<2>, contract_bwd_x_kernel<false,*,false>,
+                                               contract_bwd_w_kernel<5,*> with gy = 10
+config 5 in fp32, B=64, 60->256, K=5           contract_fwd_kernel<2> (4 filter blocks), contract_bwd_x_kernel<false,*,false>,
+                                               contract_bwd_w_kernel<5,*> gy = 2, gz = 8   (the reference leg of rel_err_vs_f32)
+W beyond 48 KB, B=25, 32->32, K=25             contract_fwd_kernel<1>, contract_bwd_x_kernel<true,*,false>
+small launch, B=3, 32->32, K=5                 contract_fwd_splitk_kernel, contract_bwd_x_kernel<true,*,true>
+small launch, B=3, 64->64, K=25                contract_fwd_kernel<2>, contract_bwd_x_kernel<false,*,true>
+recurrence, B*Fin = 8192 / 2048 / 960 planes   cheb4_kernel<10240,20,6,512,*>, cheb_onchip_kernel<2,14,4,768,*>
+configs[1] network at batch 64                 the set of templates of one training step, fused feature mean on and off
+=============================================  ===============================================================
+
+Tolerance: ``max|hip - ref| <= 1e-5 max|ref|`` forward, 2e-5 gradients (north star: 1e-5 relative fp32), per tensor;
+the network test states its own.  Measured errors go to gpurun_out/parity_measured.jsonl (conftest.record_measured).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_adam_params_close, record_measured
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+GREL = 2e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    assert torch.cuda.get_device_properties(0).multi_processor_count == 256, 'the dispatch arms asserted here assume 256 CUs'
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gcn_fmri_decoding_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from gcn_fmri_decoding_amd import _lib
+    return _lib.lib()
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rel_err(got, ref, scale=None):
+    scale = ref.abs().max() if scale is None else scale
+    return float((got.double() - ref).abs().max() / scale)
+
+
+CASES = {
+    # name: (B, M, Fin, K, Fout, forward, bwd_x stem, bwd_w RT, bwd_w reduce)
+    'bench_b64': (64, 10466, 32, 5, 32, 'contract_fwd_ring_kernel', 'contract_bwd_x_lds_kernel<%s>', 5, 'big'),
+    'config4_b25': (25, 10466, 64, 25, 64, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,false>', 5, 'big'),
+    'config5_f32_b64': (64, 10466, 60, 5, 256, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,false>', 5, 'big'),
+    'wide_w_b25': (25, 10466, 32, 25, 32, 'contract_fwd_kernel<1>', 'contract_bwd_x_kernel<true,%s,false>', 5, 'big'),
+    'small_b3': (3, 10466, 32, 5, 32, 'contract_fwd_splitk_kernel', 'contract_bwd_x_kernel<true,%s,true>', 5, 'small'),
+    'small_config4_b3': (3, 10466, 64, 25, 64, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,true>', 5, 'small'),
+    'first_layer_b64': (64, 10466, 15, 5, 32, 'contract_fwd_ring_kernel', 'contract_bwd_x_kernel<true,%s,false>', 3, 'big'),
+}
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_contraction_arm_vs_float64(ops, dev, lib, case):
+    """Forward (per-vertex bias, ReLU, bit mask), both gradients with the ReluGrad folded in (``_relu`` entry points) and
+    without (plain entry points on the gated gradient): dispatcher arm asserted, values against float64 products
+    (models_gcn.py:611-617 and its autodiff :297-303)."""
+    from gcn_fmri_decoding_amd import _lib
+    B, M, Fin, K, Fout, fwd_name, bwx_stem, rt, red = CASES[case]
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(sum(map(ord, case)))
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    stack[..., M:] = float('nan')
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * (0.5 / np.sqrt(Fin * K))
+    bias = torch.zeros((Fout, Mp), device=dev)
+    bias[:, :M] = torch.randn((Fout, M), generator=gen, device=dev) * 0.3
+    st = stream()
+    got = {}
+
+    out = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    mask = torch.zeros((B, Fout, Mp // 4), dtype=torch.uint8, device=dev)
+    _lib.check(lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), ops.BIAS_VERTEX, P(out), P(mask), B, M, Fin, K, Fout, 1, 0, 1, st), 'fwd')
+    assert _lib.last_dispatch() == fwd_name
+    S = stack[..., :M].permute(2, 0, 1, 3).reshape(Fin * K, B, M).double()          # rows fin*K + k
+    pre = torch.einsum('rbm,ro->bom', S, W.double()) + bias[:, :M].double()
+    got['fwd'] = rel_err(out[..., :M], pre.clamp(min=0), pre.abs().max())
+    assert got['fwd'] <= REL, 'contract_fwd (%s): %.3e' % (fwd_name, got['fwd'])
+    bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, Fout, Mp)[..., :M].bool()
+    assert torch.equal(bits, out[..., :M] > 0), 'ReLU bit mask disagrees with the output'
+    del pre
+
+    gout = torch.randn((B, Fout, Mp), generator=gen, device=dev)
+    gated = gout.clone()
+    gated[..., :M] *= bits
+    gated[..., M:] = 0.0                      # plain entry points: the pad columns of dy are the caller's zeros
+    gout[..., M:] = float('nan')
+    dy = gated[..., :M].double()
+    n = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    dW_ref = torch.einsum('rbm,bom->ro', S, dy)
+    del S
+    ntiles = (Fin * K + 31) // 32
+    assert min(ntiles, 5) == rt
+    dWs = {}
+    for folded in (True, False):
+        dW = torch.full((Fin * K, Fout), float('nan'), device=dev)
+        if folded:
+            _lib.check(lib.chebgcn_contract_bwd_w_relu(P(stack), P(gout), P(mask), P(dW), P(ws), n, B, M, Fin, K, Fout, st), 'bwd_w_relu')
+        else:
+            _lib.check(lib.chebgcn_contract_bwd_w(P(stack), P(gated), P(dW), P(ws), n, B, M, Fin, K, Fout, st), 'bwd_w')
+        name = _lib.last_dispatch()
+        assert name.startswith('contract_bwd_w_kernel<%d,%s>' % (rt, 'true' if folded else 'false')), name
+        assert name.endswith(BWD_W_TAIL[red]), name
+        key = 'bwd_w_relu' if folded else 'bwd_w'
+        got[key] = rel_err(dW, dW_ref)
+        assert got[key] <= GREL, '%s (%s): %.3e' % (key, name, got[key])
+        dWs[folded] = dW
+    assert torch.equal(dWs[True], dWs[False]), 'folded and plain dW differ'            # the same products in the same order
+
+    gs_ref = torch.einsum('ro,bom->rbm', W.double(), dy).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    gss = {}
+    for folded in (True, False):
+        gstack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+        if folded:
+            _lib.check(lib.chebgcn_contract_bwd_x_relu(P(gout), P(mask), P(W), P(gstack), B, M, Fin, K, Fout, st), 'bwd_x_relu')
+        else:
+            _lib.check(lib.chebgcn_contract_bwd_x(P(gated), P(W), P(gstack), B, M, Fin, K, Fout, st), 'bwd_x')
+        name = _lib.last_dispatch()
+        assert name == bwx_stem % ('true' if folded else 'false'), name
+        key = 'bwd_x_relu' if folded else 'bwd_x'
+        got[key] = rel_err(gstack[..., :M], gs_ref)
+        assert got[key] <= GREL, '%s (%s): %.3e' % (key, name, got[key])
+        gss[folded] = gstack[..., :M]
+    assert torch.equal(gss[True], gss[False]), 'folded and plain dstack differ'
+    record_measured('contraction_arm_vs_float64[%s]' % case, **got)
+
+
+# how contract_bwd_w's partials are reduced, by launch size (contract.hip launch_bwd_w)
+BWD_W_TAIL = {'big': ' + reduce_partials_stage1 + reduce_partials_stage2', 'small': ' + reduce_partials_small'}
+
+
+@pytest.mark.parametrize('B,Fin,K,fwd,adj', [
+    (256, 32, 5, 'cheb4_kernel<10240,20,6,512,false,true>', 'cheb4_kernel<10240,20,6,512,true,false>'),       # north star
+    (64, 32, 5, 'cheb_onchip_kernel<2,14,4,768,false>', 'cheb_onchip_kernel<2,14,4,768,true>'),               # bench step, layers 2-6
+    (64, 15, 5, 'cheb_onchip_kernel<2,14,4,768,false>', 'cheb_onchip_kernel<2,14,4,768,true>'),               # bench step, layer 1
+    (64, 64, 25, 'cheb4_kernel<10240,20,6,512,false,true>', 'cheb4_kernel<10240,20,6,512,true,false>'),       # config 4
+])
+def test_recurrence_arm(ops, dev, lib, B, Fin, K, fwd, adj):
+    """Which recurrence kernel a launch of B*Fin planes on the benchmark graph reaches (common.h ``pick_ell``: four planes
+    per workgroup from four plane groups per CU) -- the values of these launches are checked by
+    test_gpu_bench_shapes.py::test_northstar_launch_properties; here every plane of a short launch against the oracle."""
+    import bench
+    from gcn_fmri_decoding_amd import _lib
+    from oracle import graph_ref as GR
+    Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
+    L = Ls[0]
+    M = L.shape[0]
+    g = ops.graph_for(L, dev)
+    Mp = g.Mp
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B + Fin)
+    x = torch.randn((B, Fin, Mp), generator=gen, device=dev)
+    x[..., M:] = float('nan')
+    stack = torch.empty((K, B, Fin, Mp), device=dev)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, stream()), 'recurrence_fwd')
+    assert _lib.last_dispatch() == fwd
+    G = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    G[..., M:] = float('nan')
+    dx = torch.empty((B, Fin, Mp), device=dev)
+    _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, stream()), 'recurrence_bwd')
+    assert _lib.last_dispatch() == adj
+    # oracle on the planes of one window from the middle of the batch (graph.chebyshev, graph.py:155-172, and its adjoint)
+    Lr = GR.rescale_L(L, 2)
+    b = B // 2
+    xv = x[b, :, :M].cpu().numpy().T.astype(np.float32)                      # [M, Fin]
+    T = [xv, (Lr @ xv).astype(np.float32)]
+    for k in range(2, K):
+        T.append((2 * (Lr @ T[-1]) - T[-2]).astype(np.float32))
+    ref = np.stack(T).transpose(0, 2, 1)
+    e_f = np.abs(stack[:, b, :, :M].cpu().numpy() - ref).max() / np.abs(ref).max()
+    Gb = G[:, b, :, :M].cpu().numpy().transpose(0, 2, 1).astype(np.float64)   # [K, M, Fin]
+    LT = Lr.T.tocsr().astype(np.float64)
+    c1, c2 = Gb[K - 1], np.zeros_like(Gb[0])
+    for j in range(K - 2, 0, -1):
+        c1, c2 = Gb[j] + 2 * (LT @ c1) - c2, c1
+    dref = Gb[0] + LT @ c1 - c2
+    e_a = np.abs(dx[b, :, :M].cpu().numpy().T - dref).max() / np.abs(dref).max()
+    record_measured('recurrence_arm[%d,%d,%d]' % (B, Fin, K), fwd=e_f, adjoint=e_a)
+    assert e_f <= REL, 'forward %s: %.3e' % (fwd, e_f)
+    # K = 25 grows the terms by 2^k-like factors before they cancel: the K-term sums are compared at the scale of the result
+    assert e_a <= GREL, 'adjoint %s: %.3e' % (adj, e_a)
+
+
+def test_bwd_x_mask_at_the_end_of_an_allocation(ops, dev, lib):
+    """contract_bwd_x_lds_kernel reads the ReLU mask one dword per lane; a mask row is Mp / 4 bytes and Mp is padded to 32
+    vertices, not to the 128 of a tile: with Mp % 128 == 32 the last tile's dwords 2..7 lie beyond the row.  The mask sits at
+    the very end of its (exact-size) allocation here; results against float64."""
+    from gcn_fmri_decoding_amd import _lib
+    B, M, Fin, K, Fout = 512, 1050, 32, 5, 32
+    Mp = ops.plane_stride(M)
+    assert Mp % 128 == 32 and (B * Fout * (Mp // 4)) % 512 == 0
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * 0.1
+    gout = torch.randn((B, Fout, Mp), generator=gen, device=dev)
+    keep = torch.rand((B, Fout, Mp), generator=gen, device=dev) > 0.5
+    keep[..., M:] = False
+    packed = (keep.reshape(B, Fout, Mp // 4, 4).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=dev)).sum(-1).to(torch.uint8)
+    torch.cuda.empty_cache()
+    mask = torch.empty(B * Fout * (Mp // 4), dtype=torch.uint8, device=dev)          # its own block, exact size
+    mask.copy_(packed.reshape(-1))
+    gstack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_x_relu(P(gout), P(mask), P(W), P(gstack), B, M, Fin, K, Fout, stream()), 'bwd_x_relu')
+    assert _lib.last_dispatch() == 'contract_bwd_x_lds_kernel<true>'
+    torch.cuda.synchronize()
+    dy = (gout[..., :M] * keep[..., :M]).double()
+    ref = torch.einsum('ro,bom->rbm', W.double(), dy).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    err = rel_err(gstack[..., :M], ref)
+    assert err <= GREL, 'contract_bwd_x_relu at Mp %% 128 == 32: %.3e' % err
+
+
+def test_fwd_mean_not_served_below_four_filters(lib):
+    """chebgcn_contract_fwd_mean's ring kernel loads 16 bytes around a per-filter bias: layers of fewer than four filters are
+    declined (the caller runs chebgcn_contract_fwd + chebgcn_feature_mean_fwd)."""
+    assert lib.chebgcn_contract_fwd_mean_supported(64, 10466, 32, 5, 3) == 0
+    assert lib.chebgcn_contract_fwd_mean_supported(64, 10466, 32, 5, 4) == 1
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE configs[1] at the batch the benchmark times
+# ---------------------------------------------------------------------------------------
+
+def _oracle_worker(args):
+    """Runs in a fresh process (spawn): the NumPy oracle of one training step in the given precision."""
+    import numpy as np
+    import bench
+    from oracle import layers_ref as R
+    dtype, seed, B = args
+    dt = np.dtype(dtype).type
+    Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
+    L = Ls[0].astype(dt)
+    F, K, p, Mfc, C = [32] * 6, [5] * 6, [1] * 6, [512, 256, 22], 15
+    onet = R.Net([L], F, K, p, Mfc, channel=C, brelu='b2relu', regularization=5e-4, dtype=dt)
+    params, x, labels = _network_inputs(onet, L.shape[0], C, B, seed)
+    params = {k: v.astype(dt) for k, v in params.items()}
+    logits, cache = onet.forward(params, x.astype(dt))
+    loss, dlogits = onet.loss(params, logits, labels)
+    grads = onet.backward(params, cache, dlogits)
+    return logits, float(loss), grads
+
+
+def _network_inputs(onet, M, C, B, seed):
+    rs = np.random.RandomState(seed)
+    params = {}
+    for k, s in onet.param_shapes().items():
+        params[k] = ((0.2 + 0.05 * rs.randn(*s)) if k.endswith('bias') else rs.randn(*s) * np.sqrt(2.0 / s[0])).astype(np.float32)
+    x = rs.randn(B, M, C).astype(np.float32)
+    labels = rs.randint(0, 21, B)
+    return params, x, labels
+
+
+STEP_KERNELS = {
+    'recurrence_fwd': {'cheb_onchip_kernel<2,14,4,768,false>'},
+    'recurrence_bwd': {'cheb_onchip_kernel<2,14,4,768,true>'},
+    'contract_fwd': {'contract_fwd_ring_kernel'},
+    'contract_bwd_x_relu': {'contract_bwd_x_lds_kernel<true>'},
+    'brelu_pool_bwd': {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>'},
+}
+
+
+def test_config2_network_b64_vs_oracle(ops, dev):
+    """BASELINE configs[1] as bench.py times it -- 6 x [K=5, F=32, p=1, b2relu], FC 512-256-22, block_dura 15, batch 64 on
+    the M = 10466 graph -- logits, loss, EVERY gradient and one TF-form Adam step against the oracle
+    (oracle/layers_ref.Net <-> lib_new/models_gcn.py:658-682, :253-276, :296), with the last layer fused with
+    tf.reduce_mean (:673) and without.  The kernels of the step are the ring / LDS / two-plane instantiations (asserted
+    from the dispatch log), not the small-launch ones the batch-2 test reaches.
+
+    Ground truth is the oracle in float64; the fp32 oracle run beside it gives the error fp32 arithmetic itself makes on
+    this network (another summation order, another side of zero for a ReLU within round-off).  Bounds: logits 1e-5 of
+    max (north star) against float64; gradients at the 99.9 % quantile (per-vertex biases 99 %) within 2e-5 of the
+    gradient's scale or three times the fp32 oracle's own error, whichever is larger."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    import bench
+    from gcn_fmri_decoding_amd import _lib, models_gcn
+    from oracle import layers_ref as R
+    B, seed, reg = 64, 4, 5e-4
+    with cf.ProcessPoolExecutor(2, mp_context=mp.get_context('spawn')) as ex:
+        futs = [ex.submit(_oracle_worker, ('float32', seed, B)), ex.submit(_oracle_worker, ('float64', seed, B))]
+        Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
+        L = Ls[0]
+        M = L.shape[0]
+        F, K, p, Mfc, C = [32] * 6, [5] * 6, [1] * 6, [512, 256, 22], 15
+        onet = R.Net([L], F, K, p, Mfc, channel=C, brelu='b2relu', regularization=reg)
+        params, x, labels = _network_inputs(onet, M, C, B, seed)
+        xs = torch.full((B, C, ops.plane_stride(M)), float('nan'), device=dev)
+        xs[:, :, :M] = torch.as_tensor(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+        ld = torch.as_tensor(labels).to(dev)
+        results = {}
+        for fused in (True, False):
+            net = models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1',
+                                   initial='he', channel=C, regularization=reg, dropout=1, batch_size=B, verbose=False)
+            net.fuse_feature_mean = fused
+            for k, v in params.items():
+                net.set_variable(k, v)
+            with torch.no_grad():
+                logits = net._inference_storage(xs, 1).cpu().numpy()
+            _lib.dispatch_log = log = []
+            try:
+                _, loss_avg = net.train_step(xs, ld)
+                torch.cuda.synchronize()
+            finally:
+                _lib.dispatch_log = None
+            seen = {}
+            for what, name in log:
+                seen.setdefault(what, set()).add(name)
+            expect = dict(STEP_KERNELS)
+            if fused:
+                expect['contract_fwd_mean'] = {'contract_fwd_ring_kernel<mean>'}
+                expect['contract_bwd_x_relu_mean'] = {'contract_bwd_x_lds_kernel<true>'}
+                expect['bias_grad_relu_mean'] = {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4><mean>'}
+            for what, names in expect.items():
+                assert seen.get(what) == names, (what, seen.get(what), names)
+            assert all(n.startswith(('contract_bwd_w_kernel<5,true>', 'contract_bwd_w_kernel<3,true>')) for n in seen['contract_bwd_w']), seen['contract_bwd_w']
+            grads = {}
+            for k in params:
+                spec = next(s for s in net._spec_list if s.name == k)
+                gk = net._params[k].grad
+                if spec.group == 'convb':
+                    gk = gk[:, :spec.ref_shape[1]].t().unsqueeze(0)
+                grads[k] = gk.cpu().numpy().astype(np.float64)
+            results[fused] = (logits, float(loss_avg), grads, {k: net.get_var(k) for k in params})
+            del net
+        (l32, loss32, g32), (l64, loss64, g64) = [f.result() for f in futs]
+    assert l64.dtype == np.float64
+    measured = {}
+    for fused, (logits, loss, grads, after) in results.items():
+        tag = 'fused' if fused else 'unfused'
+        e = np.abs(logits - l64).max() / np.abs(l64).max()
+        e32 = np.abs(l32 - l64).max() / np.abs(l64).max()
+        measured['logits_' + tag] = e
+        measured['logits_oracle32'] = e32
+        assert e <= max(REL, 3 * e32), 'logits (%s): %.3e of max against float64 (fp32 oracle: %.3e)' % (tag, e, e32)
+        assert abs(loss - loss64) <= GREL * abs(loss64), 'loss (%s): %.8f against %.8f' % (tag, loss, loss64)
+        for k in params:
+            l2 = reg * params[k].astype(np.float64) if onet.regularized(k) else 0
+            ref = g64[k] - l2
+            scale = max(np.abs(ref).max(), 1e-30)
+            e_gpu = np.abs(grads[k] - ref) / scale
+            e_o32 = np.abs(g32[k].astype(np.float64) - l2 - ref) / scale
+            qq = 0.99 if (k.startswith('conv') and k.endswith('bias')) else 0.999
+            q_gpu, q_o32 = float(np.quantile(e_gpu, qq)), float(np.quantile(e_o32, qq))
+            measured['grad_%s_%s' % (k, tag)] = [q_gpu, float(e_gpu.max())]
+            measured['grad_%s_oracle32' % k] = [q_o32, float(e_o32.max())]
+            assert q_gpu <= max(GREL, 3 * q_o32), 'grad %s (%s): %.1f %% quantile %.3e of scale, max %.3e (fp32 oracle %.3e, %.3e)' % (
+                k, tag, 100 * qq, q_gpu, e_gpu.max(), q_o32, e_o32.max())
+            if not (k.startswith('conv') and k.endswith('bias')):
+                assert e_gpu.max() <= max(10 * GREL, 3 * e_o32.max()), 'grad %s (%s): max %.3e (fp32 oracle %.3e)' % (
+                    k, tag, e_gpu.max(), e_o32.max())
+        # one TF-form Adam step from the float32 oracle's gradients
+        p32 = {k: v.copy() for k, v in params.items()}
+        state, ill = {}, {}
+        R.adam_tf_step(p32, {k: g32[k] for k in params}, state)
+        for k in params:
+            assert_adam_params_close(after[k], p32[k], state['v/' + k], 0, ill, k, rel=GREL, lr=2e-3, quantile=0.999)
+    record_measured('config2_network_b64_vs_oracle', **measured)
+    # fused and unfused differ only in the order of the sum over the 32 filters of the last layer
+    lf, lu = results[True][0], results[False][0]
+    assert np.abs(lf - lu).max() <= REL * np.abs(lu).max()
