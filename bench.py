@@ -234,7 +234,6 @@ def refshape_leg(dev, n_nodes, steps, warmup, batch=128, korder=10, block_dura=1
     S = 4 * batch
     data = torch.randn((S, n_nodes, block_dura), generator=gen, device=dev)
     labels = torch.randint(0, 21, (S,), generator=gen, device=dev)
-    perm_dev = torch.as_tensor(np.asarray(perm, np.int32)).to(dev)
     order = torch.stack([torch.randperm(S, generator=gen, device=dev)[:batch].to(torch.int32) for _ in range(steps + warmup)])
     for mode in ('eager', 'hip_graph'):
         torch.manual_seed(0)
@@ -244,10 +243,11 @@ def refshape_leg(dev, n_nodes, steps, warmup, batch=128, korder=10, block_dura=1
         if mode == 'hip_graph':
             net.enable_step_graph(True)
         xbuf = ops.plane_empty(batch, block_dura, int(Ls[0].shape[0]), dev)
+        perm_dev = net.compose_perm(perm)
 
         def step(i):
             idx = order[i]
-            x = ops.perm_data(data, perm_dev, idx, out=xbuf)
+            x = net.as_internal(ops.perm_data(data, perm_dev, idx, out=xbuf))
             return net.train_step(x, labels[idx.long()])
         for i in range(warmup):
             step(i)
@@ -452,7 +452,7 @@ def main():
     g.manual_seed(1234 + rank)
     data = torch.randn((S, args.nodes, args.block_dura), generator=g, device=dev)
     labels = torch.randint(0, 21, (S,), generator=g, device=dev)
-    perm_dev = torch.as_tensor(perm.astype(np.int32)).to(dev)
+    perm_dev = net.compose_perm(perm)                 # perm_data_3d's index map, composed with the model's internal vertex order
     repeats = max(1, args.repeats)
     n_dp = 13 if (world == 1 and args.kernel_legs) else 0
     n_order = args.warmup + repeats * args.steps + args.instrumented_steps + n_dp
@@ -460,7 +460,7 @@ def main():
 
     def step(i):
         idx = order[i]
-        x = ops.perm_data(data, perm_dev, idx)          # perm_data_3d + batch gather, on device
+        x = net.as_internal(ops.perm_data(data, perm_dev, idx))          # perm_data_3d + batch gather, on device
         return net.train_step(x, labels[idx.long()])
 
     for i in range(args.warmup):

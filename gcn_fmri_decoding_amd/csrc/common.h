@@ -56,6 +56,16 @@ struct Ell {
     // uids[g][lane] = the eight 16-bit slot ids of quads 0 and 1.  Entries beyond 12 stay in colo / valq.
     float4* uval = nullptr;       // [ngroups*4*64]
     uint4* uids = nullptr;        // [ngroups*64]
+    // Ordered image (recurrence_ord.hip; graphs whose rows come sorted by descending length): thread t of a workgroup of
+    // ord_NT threads owns ord_NQ vertex quads (rows 4q..4q+3, the same 16 bytes it loads and stores per plane),
+    // vertex v has LDS slot (v & 3)*ord_SQ + (v >> 2) while (v >> 2) < ord_SQ; group (4u + i)*(ord_NT/64) + w, lane l is row
+    // 4*(64*blkmap[w*ord_NQ + u] + l) + i.  Only ginfo / colo / valq / uval / uids / blkmap are built.
+    // Which 64-quad block a wave works on at level u is a table (blkmap[w*ord_NQ + u], ascending in u): the rows are sorted,
+    // so block b holds longer rows than block b + 1 -- dealt out in order, wave 0 would get the longest rows of every level
+    // (measured: its gather 27k cycles against 20-22k for the others, and every step waits for it); the host balances the
+    // gather cost of the waves instead.
+    int ord_NT = 0, ord_NQ = 0, ord_NG = 0, ord_SQ = 0;
+    int32_t* blkmap = nullptr;    // [NT/64 * ord_NQ]
     uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> LDS slot of that row, 0xFFFF for padding ranks
     uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> LDS slot, 0xFFFF = none (isolated / pad)
     // plain CSR for the out-of-LDS fallback
@@ -76,10 +86,11 @@ struct EllView {
     int ngroups, zero_slot;
     const float4* uval;
     const uint4* uids;
+    const int32_t* blkmap;
 };
 
 static inline EllView view(const Ell& e) {
-    return EllView{e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot, e.uval, e.uids};
+    return EllView{e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.ngroups, e.zero_slot, e.uval, e.uids, e.blkmap};
 }
 
 }  // namespace chebgcn
@@ -93,6 +104,12 @@ inline bool generic4_fits(int rows, int Mq) { return rows <= 2048 && Mq <= 768; 
 bool onchip4_fits(int lds_entries, int rows, int Mq);
 template <bool ADJ>
 int dispatch_onchip4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
+                     hipStream_t stream);
+// recurrence_ord.hip: shape {NQ, NG} of the ordered kernel for a graph of Mq vertex quads of which the first SQ have rows
+// (512 threads, 10240 LDS entries); false = not served
+bool ordered_shape(int Mq, int SQ, int* NQ, int* NG);
+template <bool ADJ>
+int dispatch_ordered(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
                      hipStream_t stream);
 }  // namespace chebgcn
 
@@ -110,6 +127,11 @@ struct chebgcn_graph {
     // 8 per CU); with one or two (batch 64) the two-plane kernel's lighter group turn-over wins.
     int has_alt2 = 0;
     chebgcn::Ell fwd2, adj2;
+    // Rows (of L~ and of L~^T) sorted by descending length and a shape recurrence_ord.hip serves: the ordered images.  The
+    // automatic plane choice then runs every launch on them (one 16-byte piece of a plane = the four rows a thread owns:
+    // planes go from HBM to registers and back without a pass through LDS).
+    int ord_ok = 0;
+    chebgcn::Ell ofwd, oadj;
 };
 
 #ifndef CG_PICK4_GROUPS_PER_CU

@@ -56,7 +56,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 static void free_ell(Ell& e) {
-    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval, e.uval, e.uids};
+    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval, e.uval, e.uids, e.blkmap};
     for (void* p : ptrs) (void)hipFree(p);
     e = Ell();
 }
@@ -71,6 +71,87 @@ static int planes_for(int n) {
     if (entries * 16 <= (size_t)kLdsBytes) return 4;
     if (entries * 8 <= (size_t)kLdsBytes) return 2;
     return 0;
+}
+
+// Entry order inside a row is free (a sum).  The 64 rows of a group gather entry position e with one LDS instruction, which
+// the hardware serves in fixed lane sets (two of 32 lanes for the 8-byte reads of P = 2, four of 16 for the 16-byte reads of
+// P = 4, MI355X_MICROARCH.md "LDS"); inside a set, distinct entries on one bank serialise.  The positions of each row's
+// entries are therefore chosen greedily, position by position, so that the rows of a lane set hit different banks; rows
+// shorter than the group may leave holes (zero-slot padding).  rows[lane] = the vertex whose row lane gathers (-1: none),
+// q0 / L = the group's first quad and (even) length, slot_of(v) = the LDS slot of vertex v.
+template <class SlotOf>
+static void place_group(int planes, const int (&rows)[64], int q0, int L, const std::vector<int32_t>& rowptr,
+                        const std::vector<int32_t>& col, const std::vector<float>& val, SlotOf slot_of, std::vector<uint2>& colq,
+                        std::vector<float4>& valq, int64_t* cost_before, int64_t* cost_after, int64_t* cost_ideal) {
+    const int nbanks = planes == 4 ? 16 : 32;            // distinct entry-sized bank groups
+    auto lane_set = [&](int lane) {
+        if (planes != 4) return lane >> 5;
+        static const int blk[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};
+        return blk[lane >> 2];
+    };
+    // positions the kernel visits (recurrence*.hip); a third quad of at most two entries is
+    // gathered as a pair (its ids travel in the value record, see valp below)
+    const int npos = L <= 8 ? 8 : L <= 10 ? 10 : 4 * ((L + 3) / 4);
+    for (int set = 0; set < (planes == 4 ? 4 : 2); ++set) {
+        std::vector<int> lanes;
+        for (int lane = 0; lane < 64; ++lane)
+            if (lane_set(lane) == set && rows[lane] >= 0) lanes.push_back(lane);
+        const int nr = (int)lanes.size();
+        std::vector<std::vector<int>> rem(nr);          // remaining CSR entry ids per row
+        for (int i = 0; i < nr; ++i) {
+            const int row = rows[lanes[i]];
+            for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) rem[i].push_back(e);
+        }
+        // cost of the caller's order, for the statistics
+        for (int pos = 0; pos < npos; ++pos) {
+            std::vector<std::vector<uint32_t>> seen(nbanks);
+            int worst = 1;
+            for (int i = 0; i < nr; ++i) {
+                if (pos >= (int)rem[i].size()) continue;
+                const uint32_t sl = slot_of(col[rem[i][pos]]);
+                auto& v = seen[sl % nbanks];
+                if (std::find(v.begin(), v.end(), sl) == v.end()) v.push_back(sl);
+                worst = std::max(worst, (int)v.size());
+            }
+            *cost_before += worst;
+        }
+        std::vector<int> idx(nr);
+        for (int pos = 0; pos < npos; ++pos) {
+            for (int i = 0; i < nr; ++i) idx[i] = i;
+            // rows that may not leave a hole any more go first, then the longer ones
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+                const int sa = (npos - pos) - (int)rem[a].size(), sb = (npos - pos) - (int)rem[b].size();
+                if ((sa <= 0) != (sb <= 0)) return sa <= 0;
+                return rem[a].size() > rem[b].size();
+            });
+            std::vector<std::vector<uint32_t>> seen(nbanks);
+            int worst = 1;
+            for (int i : idx) {
+                if (rem[i].empty()) continue;
+                const int slack = (npos - pos) - (int)rem[i].size();
+                int best = -1, best_load = 1 << 30;
+                for (int k = 0; k < (int)rem[i].size(); ++k) {
+                    const uint32_t sl = slot_of(col[rem[i][k]]);
+                    const auto& v = seen[sl % nbanks];
+                    const int load = std::find(v.begin(), v.end(), sl) != v.end() ? 0 : (int)v.size();
+                    if (load < best_load) { best_load = load; best = k; }
+                }
+                if (best_load > 0 && slack > 0) continue;       // leave a hole, try a later position
+                const int e = rem[i][best];
+                rem[i].erase(rem[i].begin() + best);
+                const uint32_t slot = slot_of(col[e]);
+                auto& v = seen[slot % nbanks];
+                if (std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot);
+                worst = std::max(worst, (int)v.size());
+                const size_t at = ((size_t)q0 + pos / 4) * 64 + lanes[i];
+                uint32_t* w = (pos & 2) ? &colq[at].y : &colq[at].x;
+                *w = (pos & 1) ? ((*w & 0x0000FFFFu) | (slot << 16)) : ((*w & 0xFFFF0000u) | slot);
+                (&valq[at].x)[pos & 3] = val[e];
+            }
+            *cost_after += worst;
+            *cost_ideal += 1;
+        }
+    }
 }
 
 // CSR (host) -> device Ell.  Entry order inside a row is NOT the caller's: positions are chosen
@@ -152,85 +233,15 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     std::vector<uint2> colq((size_t)(nquads + kQuadPad) * 64, make_uint2(zz, zz));
     std::vector<float4> valq((size_t)(nquads + kQuadPad) * 64, make_float4(0.f, 0.f, 0.f, 0.f));
     std::vector<uint16_t> rowslot((size_t)ngroups * 64, 0xFFFF);
-    // Entry order inside a row is free (a sum).  The 64 rows of a group gather entry position e
-    // with one LDS instruction, which the hardware serves in fixed lane sets (two of 32 lanes for
-    // the 8-byte reads of P = 2, four of 16 for the 16-byte reads of P = 4, MI355X_MICROARCH.md
-    // "LDS"); inside a set, distinct entries on one bank serialise.  The positions of each row's
-    // entries are therefore chosen greedily, position by position, so that the rows of a lane
-    // set hit different banks; rows shorter than the group may leave holes (zero-slot padding).
-    const int nbanks = planes == 4 ? 16 : 32;            // distinct entry-sized bank groups
-    auto lane_set = [&](int lane) {
-        if (planes != 4) return lane >> 5;
-        static const int blk[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};
-        return blk[lane >> 2];
-    };
     int64_t cost_before = 0, cost_after = 0, cost_ideal = 0;
     for (int g = 0; g < ngroups; ++g) {
-        const int L = ginfo[g].y;
-        // positions the kernel visits (recurrence*.hip); a third quad of at most two entries is
-        // gathered as a pair (its ids travel in the value record, see valp below)
-        const int npos = L <= 8 ? 8 : L <= 10 ? 10 : 4 * ((L + 3) / 4);
-        for (int set = 0; set < (planes == 4 ? 4 : 2); ++set) {
-            std::vector<int> lanes;
-            for (int lane = 0; lane < 64; ++lane)
-                if (lane_set(lane) == set && g * 64 + lane < nranked) lanes.push_back(lane);
-            const int nr = (int)lanes.size();
-            std::vector<std::vector<int>> rem(nr);          // remaining CSR entry ids per row
-            for (int i = 0; i < nr; ++i) {
-                const int row = order[g * 64 + lanes[i]];
-                for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) rem[i].push_back(e);
-                rowslot[g * 64 + lanes[i]] = nodeslot[row];
-            }
-            // cost of the caller's order, for the statistics
-            for (int pos = 0; pos < npos; ++pos) {
-                std::vector<std::vector<uint32_t>> seen(nbanks);
-                int worst = 1;
-                for (int i = 0; i < nr; ++i) {
-                    if (pos >= (int)rem[i].size()) continue;
-                    const uint32_t sl = nodeslot[col[rem[i][pos]]];
-                    auto& v = seen[sl % nbanks];
-                    if (std::find(v.begin(), v.end(), sl) == v.end()) v.push_back(sl);
-                    worst = std::max(worst, (int)v.size());
-                }
-                cost_before += worst;
-            }
-            std::vector<int> idx(nr);
-            for (int pos = 0; pos < npos; ++pos) {
-                for (int i = 0; i < nr; ++i) idx[i] = i;
-                // rows that may not leave a hole any more go first, then the longer ones
-                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
-                    const int sa = (npos - pos) - (int)rem[a].size(), sb = (npos - pos) - (int)rem[b].size();
-                    if ((sa <= 0) != (sb <= 0)) return sa <= 0;
-                    return rem[a].size() > rem[b].size();
-                });
-                std::vector<std::vector<uint32_t>> seen(nbanks);
-                int worst = 1;
-                for (int i : idx) {
-                    if (rem[i].empty()) continue;
-                    const int slack = (npos - pos) - (int)rem[i].size();
-                    int best = -1, best_load = 1 << 30;
-                    for (int k = 0; k < (int)rem[i].size(); ++k) {
-                        const uint32_t sl = nodeslot[col[rem[i][k]]];
-                        const auto& v = seen[sl % nbanks];
-                        const int load = std::find(v.begin(), v.end(), sl) != v.end() ? 0 : (int)v.size();
-                        if (load < best_load) { best_load = load; best = k; }
-                    }
-                    if (best_load > 0 && slack > 0) continue;       // leave a hole, try a later position
-                    const int e = rem[i][best];
-                    rem[i].erase(rem[i].begin() + best);
-                    const uint32_t slot = nodeslot[col[e]];
-                    auto& v = seen[slot % nbanks];
-                    if (std::find(v.begin(), v.end(), slot) == v.end()) v.push_back(slot);
-                    worst = std::max(worst, (int)v.size());
-                    const size_t at = ((size_t)ginfo[g].x + pos / 4) * 64 + lanes[i];
-                    uint32_t* w = (pos & 2) ? &colq[at].y : &colq[at].x;
-                    *w = (pos & 1) ? ((*w & 0x0000FFFFu) | (slot << 16)) : ((*w & 0xFFFF0000u) | slot);
-                    (&valq[at].x)[pos & 3] = val[e];
-                }
-                cost_after += worst;
-                cost_ideal += 1;
-            }
+        int rows[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            rows[lane] = g * 64 + lane < nranked ? order[g * 64 + lane] : -1;
+            if (rows[lane] >= 0) rowslot[g * 64 + lane] = nodeslot[rows[lane]];
         }
+        place_group(planes, rows, ginfo[g].x, ginfo[g].y, rowptr, col, val, [&](int v) { return (uint32_t)nodeslot[v]; }, colq, valq,
+                    &cost_before, &cost_after, &cost_ideal);
     }
     out->cost_before = cost_before;
     out->cost_after = cost_after;
@@ -306,6 +317,157 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     if ((rc = upload(&out->rowslot, rowslot))) return rc;
     if ((rc = upload(&out->nodeslot, nodeslot))) return rc;
     return CHEBGCN_OK;
+}
+
+// Ordered image (common.h, recurrence_ord.hip): the operator of a graph whose rows are sorted by descending length, laid
+// out for threads that own whole vertex quads.  Same record formats as above (fixed-stride image of the first 12 entries of
+// every row group + the variable-stride quads for longer rows), same bank-aware placement of the entries of a row.
+static int build_ell_ordered(int M, int NT, int NQ, int NG, int SQ, const std::vector<int32_t>& rowptr,
+                             const std::vector<int32_t>& col, const std::vector<float>& val, Ell* out) {
+    int rc;
+    const int NW = NT / 64, NJ = 4 * NG, ngroups = NJ * NW;
+    out->planes = 4;
+    out->ord_NT = NT; out->ord_NQ = NQ; out->ord_NG = NG; out->ord_SQ = SQ;
+    auto slot_of_vertex = [&](int v) { return (uint32_t)((v & 3) * SQ + (v >> 2)); };
+    const uint32_t zero_slot = (uint32_t)(4 * SQ);
+    auto rlen = [&](int r) { return r < 0 ? 0 : rowptr[r + 1] - rowptr[r]; };
+    // ---- blocks of 64 quads -> (wave, level).  Cost of a block = the entry positions its four slices visit (8 / 10 / 12 /
+    // whole quads beyond: what recurrence_ord.hip gathers for the longest row of a slice).  Longest-processing-time first
+    // onto the least loaded wave that still has a free level, then pairwise swaps while the heaviest wave gets lighter.
+    const int nblk_rows = (SQ + 63) / 64;              // blocks that hold rows: levels 0..NG-1 of the waves
+    std::vector<int> bcost(NG * NW, 0);
+    for (int b = 0; b < nblk_rows; ++b)
+        for (int i = 0; i < 4; ++i) {
+            int len = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = b * 64 + lane, v = 4 * q + i;
+                if (q < SQ && v < M) len = std::max(len, rlen(v));
+            }
+            len = (len + 1) & ~1;
+            bcost[b] += len <= 8 ? 8 : len <= 10 ? 10 : len <= 12 ? 12 : 4 * ((len + 3) / 4);
+        }
+    // (a block that is not full of rows -- the last one with rows, and empty ones behind it: fewer than NW + 1 -- must be the
+    // LAST level of its wave: the kernel treats the levels below NG - 1 as "every lane has a slot")
+    auto full = [&](int b) { return 64 * (b + 1) <= SQ; };
+    std::vector<std::vector<int>> mine(NW);
+    std::vector<int> load(NW, 0), partial(NW, 0);
+    {
+        std::vector<int> idx(NG * NW);
+        std::iota(idx.begin(), idx.end(), 0);
+        // the blocks that are not full first (at most one per wave), then the full ones by descending cost
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+            if (full(a) != full(b)) return !full(a);
+            return bcost[a] > bcost[b];
+        });
+        for (int b : idx) {
+            int best = -1;
+            for (int w = 0; w < NW; ++w)
+                if ((int)mine[w].size() < NG && (full(b) || !partial[w]) && (best < 0 || load[w] < load[best])) best = w;
+            if (best < 0) return fail(CHEBGCN_EUNSUPPORTED, "graph_create: no block assignment for the ordered image");
+            mine[best].push_back(b);
+            load[best] += bcost[b];
+            partial[best] += !full(b);
+        }
+        for (bool moved = true; moved;) {
+            moved = false;
+            const int hw = (int)(std::max_element(load.begin(), load.end()) - load.begin());
+            for (int w = 0; w < NW && !moved; ++w)
+                for (size_t x = 0; x < mine[hw].size() && !moved; ++x)
+                    for (size_t y = 0; y < mine[w].size() && !moved; ++y) {
+                        const int d = bcost[mine[hw][x]] - bcost[mine[w][y]];
+                        if (w != hw && d > 0 && load[w] + d < load[hw] && full(mine[hw][x]) && full(mine[w][y])) {
+                            std::swap(mine[hw][x], mine[w][y]);
+                            load[hw] -= d;
+                            load[w] += d;
+                            moved = true;
+                        }
+                    }
+        }
+    }
+    std::vector<int32_t> blkmap((size_t)NW * NQ);
+    for (int w = 0; w < NW; ++w) {
+        std::sort(mine[w].begin(), mine[w].end());     // ascending: a wave's slices stay sorted by descending length
+        for (int u = 0; u < NQ; ++u) blkmap[(size_t)w * NQ + u] = u < NG ? mine[w][u] : u * NW + w;
+    }
+    auto row_of = [&](int g, int lane) {               // vertex of a rank, -1 = none
+        const int j = g / NW, w = g % NW, u = j >> 2, i = j & 3;
+        const int q = blkmap[(size_t)w * NQ + u] * 64 + lane, v = 4 * q + i;
+        return (q < SQ && v < M) ? v : -1;
+    };
+    std::vector<int2> ginfo(ngroups);
+    int max_len = 0;
+    int64_t nquads = 0, nslots = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        int len = 0;
+        for (int lane = 0; lane < 64; ++lane) len = std::max(len, rlen(row_of(g, lane)));
+        max_len = std::max(max_len, len);
+        ginfo[g] = make_int2((int)nquads, (len + 1) & ~1);
+        nquads += (std::max((len + 3) / 4, kQuadMin) + 1) & ~1;
+        nslots += (len + 1) & ~1;
+    }
+    const uint32_t zz = zero_slot | (zero_slot << 16);
+    std::vector<uint2> colq((size_t)(nquads + kQuadPad) * 64, make_uint2(zz, zz));
+    std::vector<float4> valq((size_t)(nquads + kQuadPad) * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int g = 0; g < ngroups; ++g) {
+        int rows[64];
+        for (int lane = 0; lane < 64; ++lane) rows[lane] = row_of(g, lane);
+        place_group(4, rows, ginfo[g].x, ginfo[g].y, rowptr, col, val, slot_of_vertex, colq, valq, &out->cost_before, &out->cost_after,
+                    &out->cost_ideal);
+    }
+    out->ngroups = ngroups;
+    out->max_len = max_len;
+    out->nranked = ngroups * 64;
+    out->lds_entries = (4 * SQ + 2 + 3) & ~3;
+    out->zero_slot = (int)zero_slot;
+    out->nslots = nslots;
+    out->nquads = nquads;
+    if ((rc = upload(&out->ginfo, ginfo))) return rc;
+    std::vector<uint4> colo(colq.size() / 2);
+    for (size_t o = 0; o < colo.size() / 64; ++o)
+        for (int lane = 0; lane < 64; ++lane) {
+            const uint2 a = colq[(2 * o) * 64 + lane], b = colq[(2 * o + 1) * 64 + lane];
+            colo[o * 64 + lane] = make_uint4(a.x, a.y, b.x, b.y);
+        }
+    if ((rc = upload(&out->colo, colo))) return rc;
+    if ((rc = upload(&out->valq, valq))) return rc;
+    // fixed-stride image of entries 0..11; two spare groups behind the last one (the ring requests two groups ahead)
+    std::vector<float4> uval((size_t)(ngroups + 2 * NW) * 4 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<uint4> uids((size_t)(ngroups + 2 * NW) * 64, make_uint4(zz, zz, zz, zz));
+    for (size_t i = 2 * 64; i < uval.size(); i += 4 * 64)          // record 2 of every group: its two id words default to the zero slot
+        for (int lane = 0; lane < 64; ++lane) {
+            memcpy(&uval[i + lane].z, &zz, 4);
+            memcpy(&uval[i + lane].w, &zz, 4);
+        }
+    for (int g = 0; g < ngroups; ++g) {
+        const size_t q0 = (size_t)ginfo[g].x;
+        for (int lane = 0; lane < 64; ++lane) {
+            const uint2 c0 = colq[q0 * 64 + lane], c1 = colq[(q0 + 1) * 64 + lane], c2 = colq[(q0 + 2) * 64 + lane];
+            const float4 v2 = valq[(q0 + 2) * 64 + lane];
+            uids[(size_t)g * 64 + lane] = make_uint4(c0.x, c0.y, c1.x, c1.y);
+            uval[((size_t)g * 4 + 0) * 64 + lane] = valq[q0 * 64 + lane];
+            uval[((size_t)g * 4 + 1) * 64 + lane] = valq[(q0 + 1) * 64 + lane];
+            float4 r2 = make_float4(v2.x, v2.y, 0.f, 0.f);
+            memcpy(&r2.z, &c2.x, 4);
+            memcpy(&r2.w, &c2.y, 4);
+            uval[((size_t)g * 4 + 2) * 64 + lane] = r2;
+            uval[((size_t)g * 4 + 3) * 64 + lane] = make_float4(v2.z, v2.w, 0.f, 0.f);
+        }
+    }
+    if ((rc = upload(&out->uval, uval))) return rc;
+    if ((rc = upload(&out->uids, uids))) return rc;
+    if ((rc = upload(&out->blkmap, blkmap))) return rc;
+    return CHEBGCN_OK;
+}
+
+// rows sorted by descending length, every empty row behind every non-empty one: the number of non-empty rows, else -1
+static int sorted_rows(int M, const std::vector<int32_t>& rp) {
+    int n = 0;
+    for (int r = 0; r < M; ++r) {
+        const int len = rp[r + 1] - rp[r];
+        if (r > 0 && len > rp[r] - rp[r - 1]) return -1;
+        n += len > 0;
+    }
+    return n;
 }
 
 }  // namespace chebgcn
@@ -404,6 +566,18 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
         if (rc == CHEBGCN_OK) rc = build_ell(M, g->Mp, 2, active, trp, tci, tva, &g->adj2);
         g->has_alt2 = rc == CHEBGCN_OK;
     }
+    // rows of L~ and of L~^T sorted by descending length (the caller relabelled the vertices: graph.length_order in the
+    // Python host), isolated vertices last: the ordered images
+    if (rc == CHEBGCN_OK && want_planes == 0 && g->lds_ok) {
+        const int nf = sorted_rows(M, rp), na = sorted_rows(M, trp);
+        int NQ = 0, NG = 0;
+        if (nf >= 0 && nf == na && nf == nactive && ordered_shape(g->Mp / 4, (nactive + 3) / 4, &NQ, &NG)) {
+            const int SQ = (nactive + 3) / 4;
+            rc = build_ell_ordered(M, 512, NQ, NG, SQ, rp, ci, va, &g->ofwd);
+            if (rc == CHEBGCN_OK) rc = build_ell_ordered(M, 512, NQ, NG, SQ, trp, tci, tva, &g->oadj);
+            g->ord_ok = rc == CHEBGCN_OK;
+        }
+    }
     if (rc != CHEBGCN_OK) {
         chebgcn_graph_destroy(g);
         return rc;
@@ -418,6 +592,8 @@ extern "C" void chebgcn_graph_destroy(chebgcn_graph* g) {
     free_ell(g->adj);
     free_ell(g->fwd2);
     free_ell(g->adj2);
+    free_ell(g->ofwd);
+    free_ell(g->oadj);
     delete g;
 }
 
@@ -436,6 +612,10 @@ extern "C" int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* va
         case 6: *value = g->fwd.planes; break;                               // planes per workgroup (0, 2, 4)
         case 7: *value = g->fwd.nranked; break;                              // rows in the LDS image
         case 8: *value = (int64_t)g->fwd.lds_entries * 4 * g->fwd.planes; break;   // LDS bytes of the image
+        case 12: *value = g->ord_ok; break;                                  // 1: rows sorted by length, ordered kernels in use
+        case 13: *value = g->ord_ok ? g->ofwd.cost_before : 0; break;        // items 9..11 of the ordered image
+        case 14: *value = g->ord_ok ? g->ofwd.cost_after : 0; break;
+        case 15: *value = g->ord_ok ? g->ofwd.cost_ideal : 0; break;
         default: return fail(CHEBGCN_EINVAL, "graph_query: unknown item %d", what);
     }
     return CHEBGCN_OK;

@@ -113,6 +113,30 @@ def rescaled_laplacian_csr(L):
     return (Lr.indptr.astype(np.int32), Lr.indices.astype(np.int32), Lr.data.astype(np.float32))
 
 
+def length_order(L):
+    """Vertex order in which the library's recurrence kernels are fastest: rows of the rescaled Laplacian sorted by
+    DESCENDING length (number of neighbours), ties in the caller's order (stable), so isolated vertices -- the fake
+    vertices the coarsening adds -- come last.  ``order[i]`` = the caller's index of internal vertex ``i``.
+
+    With ``Lp = permute(L, order)`` a quad of four consecutive vertices is four rows of (nearly) equal length: a
+    16-byte piece of an activation plane is then exactly the rows one thread of the recurrence kernel owns, and planes
+    go from HBM to registers and back without a pass through LDS (csrc/recurrence_ord.hip).  The network is invariant
+    under a relabelling of the vertices as long as everything per-vertex follows it (input columns, per-vertex biases,
+    the rows of the first FC layer; pooling needs the tree order of ``coarsening.compute_perm`` and is not relabelled):
+    ``models_gcn.cgcnn`` does that behind the reference's variable layout."""
+    indptr, _, _ = rescaled_laplacian_csr(L)
+    lengths = np.diff(indptr)
+    return np.argsort(-lengths.astype(np.int64), kind='stable').astype(np.int64)
+
+
+def permute(L, order):
+    """``P L P^T``: row / column ``i`` of the result is row / column ``order[i]`` of ``L`` (CSR, sorted indices)."""
+    L = sp.csr_matrix(L)
+    Lp = sp.csr_matrix(L[order][:, order])
+    Lp.sort_indices()
+    return Lp
+
+
 def synthetic_graph(n_nodes=10000, k=8, levels=1, noise_level=0.01, seed=0, dtype=np.float32):
     """The seeded synthetic "brain" graph of the benchmark: kNN
     graph on uniform points in the unit cube, 1 % random edges, ``levels`` rounds of

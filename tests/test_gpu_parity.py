@@ -577,7 +577,6 @@ def test_train_step_vs_oracle(ops, dev, name):
         _, loss_avg = net.train_step(xs, ld)
         if step == 0:
             for k in params:                                   # net._grad holds d(CE); add the L2 part
-                gk = net._params[k].grad
                 ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
                 got = net_grad_in_ref_shape(net, k)
                 close(got, ref, rel=5e-5, what='grad ' + k)
@@ -609,13 +608,7 @@ def test_second_stream_for_bwd_w_is_bit_identical(ops, dev):
 
 
 def net_grad_in_ref_shape(net, name):
-    spec = next(s for s in net._spec_list if s.name == name)
-    g = net._params[name].grad
-    if spec.group == 'convb':
-        if len(spec.shape) == 2:
-            return g[:, :spec.ref_shape[1]].t().unsqueeze(0).cpu().numpy()
-        return g.view(spec.ref_shape).cpu().numpy()
-    return g.cpu().numpy()
+    return net.gradient(name).cpu().numpy()
 
 
 def test_predict_evaluate_fit_smoke(ops, dev, tmp_path, monkeypatch):

@@ -178,11 +178,10 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
     ld = torch.as_tensor(labels).to(dev)
     _, loss_avg = net.train_step(xs, ld)
     assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
+    measured = {}
     for k in params:
         spec = next(s for s in net._spec_list if s.name == k)
-        g = net._params[k].grad
-        if spec.group == 'convb':
-            g = g[:, :spec.ref_shape[1]].t().unsqueeze(0)
+        g = net.gradient(k)
         l2 = reg * p64[k] if onet.regularized(k) else 0
         ref64 = grads64[k] - l2
         scale = max(np.abs(ref64).max(), 1e-30)
@@ -193,10 +192,14 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
         # deeper layers in either fp32 evaluation -- so they are compared at the 99 % quantile, weights at 99.9 %
         qq = 0.99 if spec.group == 'convb' else 0.999
         q_gpu, q_o32 = np.quantile(e_gpu, qq), np.quantile(e_o32, qq)
+        measured[k] = [float(q_gpu), float(e_gpu.max()), float(q_o32), float(e_o32.max())]
         assert q_gpu <= max(1e-4 if spec.group == 'convb' else 5e-4, 3 * q_o32), \
             'grad %s: %.1f %% quantile %.3e (fp32 oracle %.3e)' % (k, 100 * qq, q_gpu, q_o32)
         if spec.group != 'convb':          # a weight gradient sums over every vertex and window: single flips average out
             assert e_gpu.max() <= max(2e-3, 3 * e_o32.max()), 'grad %s: max %.3e (fp32 oracle %.3e)' % (k, e_gpu.max(), e_o32.max())
+    from conftest import record_measured
+    record_measured('reference_training_shape_vs_oracle[%d]' % n_nodes, what='[quantile, max] of the GPU, of the fp32 oracle; of scale',
+                    **measured)
     state, ill = {}, {}
     R.adam_tf_step(params, grads, state)
     for k in params:
