@@ -37,9 +37,6 @@ extern int g_stagger;
 #ifndef CG_ORD_PRIO
 #define CG_ORD_PRIO 1
 #endif
-#ifndef CG_ORD_LATE_STORE
-#define CG_ORD_LATE_STORE 1      // forward, last step of a plane group: the slab goes out BEHIND the request of the next group's input
-#endif
 #ifndef CG_X
 #define CG_X 0               // 64: in-kernel phase stamps (tools/vbuild.sh, tools/kbench.py --stamps); 0 in production
 #endif
@@ -201,10 +198,35 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
     // request holds the ring up for a whole memory latency (measured with G_j requested level by level inside the gather:
     // 41k cycles per step instead of 27k) -- and their latency runs under the wait for the slower waves and the rotate.
     float4 gin[NQ][4];
-    auto request_in = [&](const float* base, int g) __attribute__((always_inline)) {
+    // adjoint: G_{K-2} of the NEXT group, requested with its G_{K-1} when a group ends (behind the dx stores, whose registers
+    // it takes over): the first step of a group then starts without a memory round trip of its own
+    float4 gin2[ADJ ? NQ : 1][4];
+    auto request_into = [&](float4 (*d)[4], const float* base, int g) __attribute__((always_inline)) {
         const rsrc_t rs = slab_rsrc(base, slab_bytes);
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) load_level(rs, g, u, gin[u]);
+        for (int u = 0; u < NQ; ++u) load_level(rs, g, u, d[u]);
+    };
+    auto request_in = [&](const float* base, int g) __attribute__((always_inline)) { request_into(gin, base, g); };
+    auto clear = [&](float4 (*d)[4]) __attribute__((always_inline)) {      // ends a live range (see the group end)
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) d[u][p] = zero4;
+    };
+    // adjoint: c_j = G_j + f L^T c_{j+1} - c_{j+2}: the state takes G_j - c_{j+2} when G_j arrives, the gather adds the rest
+    // (isolated rows: dx += c(j) G_j)
+    auto consume = [&](float4 (*d)[4], int jm) __attribute__((always_inline)) {
+        const float ck = iso_coef(jm);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const bool hs = has_slot(u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 gr = column(d[u], i), old = st[4 * u + i];
+                const float4 a = make_float4(gr.x - old.x, gr.y - old.y, gr.z - old.z, gr.w - old.w), b = fma4(ck, gr, old);
+                st[4 * u + i] = u < NG - 1 ? a : u < NG ? sel4(hs, a, b) : b;
+            }
+        }
     };
 
     // ---- a plane group's input (in `gin`) -> LDS image + row state ------------------------------------------------------
@@ -230,14 +252,17 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
 
     int grp = blockIdx.x;
     const float* in0 = src + (ADJ ? (size_t)(K - 1) * slab : 0);
-    if (grp < ngrp) request_in(in0, grp);
+    if (grp < ngrp) {
+        request_in(in0, grp);
+        if (ADJ) request_into(gin2, src + (size_t)(K - 2) * slab, grp);    // (K >= 2 here)
+    }
     lds_barrier();                                    // the zero slot
     for (; grp < ngrp; grp += gridDim.x) {
         CG_STAMP(0);
         stage(grp);
         if (ADJ) {
-            __builtin_amdgcn_sched_barrier(0);       // (requested earlier, beside the pieces being staged, G_{K-2} spills)
-            request_in(src + (size_t)(K - 2) * slab, grp);          // G_{K-2} (K >= 2 here)
+            consume(gin2, K - 2);
+            clear(gin2);
         }
         CG_STAMP(1);
         lds_barrier();                                // the image of this group is complete
@@ -248,20 +273,7 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
             const float f = ADJ ? (last ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
             const rsrc_t rs_out = slab_rsrc(ADJ ? dst : dst + (size_t)step * slab, slab_bytes);
             const float ck = iso_coef(ADJ ? jm : step);
-            if (ADJ) {
-                // c_j = G_j + f L^T c_{j+1} - c_{j+2}: G_j - c_{j+2} now, the gather adds the rest (isolated rows: dx += c(j) G_j)
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const bool hs = has_slot(u);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float4 gr = column(gin[u], i), old = st[4 * u + i];
-                        const float4 a = make_float4(gr.x - old.x, gr.y - old.y, gr.z - old.z, gr.w - old.w), b = fma4(ck, gr, old);
-                        st[4 * u + i] = u < NG - 1 ? a : u < NG ? sel4(hs, a, b) : b;
-                    }
-                }
-            }
-            if (ADJ) __builtin_amdgcn_sched_barrier(0);      // G_j is consumed HERE: its registers are the ring's in the gather
+            __builtin_amdgcn_sched_barrier(0);      // (what precedes stays in front of the gather: its registers are the ring's)
             CG_STAMP(3);
 
             // ---- gather: st <- f * (A T_{k-1})[own rows] - st  (adjoint: + st, which holds G_j - c_{j+2}) ------------------
@@ -305,11 +317,9 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
             static_for<NG, NQ>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 if (!ADJ) {
-                    if (!(CG_ORD_LATE_STORE && last))
+                    if (!last)
                         store_level(rs_out, grp, u, scale4(ck, st[4 * u]), scale4(ck, st[4 * u + 1]), scale4(ck, st[4 * u + 2]),
                                     scale4(ck, st[4 * u + 3]));
-                } else if (last) {
-                    store_level(rs_out, grp, u, st[4 * u], st[4 * u + 1], st[4 * u + 2], st[4 * u + 3]);
                 }
             });
             static_for<0, NJ>([&](auto jc) {
@@ -369,7 +379,7 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
                 st[j] = nw;
                 // ---- the level's pieces go out as soon as its four slices are done: slab `step` (forward), dx (adjoint) ----
                 if constexpr (i == 3) {
-                    if (ADJ ? last : !(CG_ORD_LATE_STORE && last)) {
+                    if (!ADJ && !last) {       // (the last slab / dx: behind the next group's request, see the group end)
                         if constexpr (u == NG - 1 && !ADJ) {
                             // mixed level: isolated rows hold x and go out as c(step) x
                             const float sc = has_slot(u) ? 1.f : ck;
@@ -402,13 +412,12 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
                     }
                 });
                 CG_STAMP(4 * step + 2);
+                if (ADJ) {
+                    consume(gin, jm - 1);            // G of the next step, in front of the barrier: the wait overlaps the other waves' rotate
+                    clear(gin);
+                }
                 lds_barrier();   
                 CG_STAMP(4 * step + 3);
-            } else if (ADJ) {                        // (ends the live range of G_j, see below)
-#pragma unroll
-                for (int u = 0; u < NQ; ++u)
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) gin[u][p] = zero4;
             }
         }
         // ---- the next group's input takes the image over -----------------------------------------------------------------
@@ -416,23 +425,24 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
         // The CU's memory pipeline is in order: requested behind the 168 KB of stores of the last slab, the next group's input
         // was not even ISSUED until those had drained at the CU's share of HBM write bandwidth (17-22k cycles at this barrier,
         // phase stamps of round 4).  Forward: request first, then the last slab from the registers it is still in.
-        if (grp + (int)gridDim.x < ngrp) request_in(in0, grp + gridDim.x);
-        else {                                       // (ends the live range of the old pieces: without it they stay allocated through every gather)
-#pragma unroll
-            for (int u = 0; u < NQ; ++u)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) gin[u][p] = zero4;
-        }
-        if (!ADJ && CG_ORD_LATE_STORE && K > 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            const rsrc_t rs_last = slab_rsrc(dst + (size_t)(K - 1) * slab, slab_bytes);
+        const bool more = grp + (int)gridDim.x < ngrp;
+        if (more) request_in(in0, grp + gridDim.x);
+        else clear(gin);                             // (ends the live range of the old pieces: without it they stay allocated through every gather)
+        __builtin_amdgcn_sched_barrier(0);
+        if (K > 1) {                                 // forward: slab K-1; adjoint: dx -- from the registers it is still in
+            const rsrc_t rs_last = slab_rsrc(ADJ ? dst : dst + (size_t)(K - 1) * slab, slab_bytes);
             const float ck = iso_coef(K - 1);
 #pragma unroll
             for (int u = 0; u < NQ; ++u) {
-                const float sc = has_slot(u) ? 1.f : ck;
+                const float sc = (ADJ || has_slot(u)) ? 1.f : ck;
                 store_level(rs_last, grp, u, scale4(sc, st[4 * u]), scale4(sc, st[4 * u + 1]), scale4(sc, st[4 * u + 2]),
                             scale4(sc, st[4 * u + 3]));
             }
+        }
+        if (ADJ) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) request_into(gin2, src + (size_t)(K - 2) * slab, grp + gridDim.x);
+            else clear(gin2);
         }
         lds_barrier();                                // every gather of the last step is done: the image may be overwritten
         CG_STAMP(41);
