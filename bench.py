@@ -145,7 +145,7 @@ def kernel_leg(lib_graph, B, Fin, K, launches, what):
         ms = [s.elapsed_time(e) for s, e in evs]
         avg = float(np.mean(ms))
         out[name] = {'avg_ms': avg, 'min_ms': float(np.min(ms)), 'algorithmic_bytes': nbytes, 'GBps': nbytes / avg / 1e6,
-                     'frac': nbytes / avg / 1e6 / HBM_PEAK_GBS}
+                     'frac': nbytes / avg / 1e6 / HBM_PEAK_GBS, 'kernel': _lib.last_dispatch()}
     del stack, gstack, dx, xcopy
     torch.cuda.empty_cache()
     return out
@@ -263,6 +263,60 @@ def refshape_leg(dev, n_nodes, steps, warmup, batch=128, korder=10, block_dura=1
     return out
 
 
+DP_STEPS = 40
+
+
+def fit_leg(dev, L, cfg, batch, n_train, n_val, epochs, tag):
+    """The caller's own number: ``t_step`` exactly as the reference defines it (models_gcn.py:183-184: wall time of
+    ``fit`` / number of steps, evaluation passes and checkpoints included), once with the training set already staged
+    in HBM (``model.stage``) and once with the float64 NumPy array ``coarsening.perm_data_3d`` returns
+    (coarsening.py:255) -- that run pays the host cast and the copy over PCIe inside ``fit``."""
+    import contextlib
+    import io
+    import tempfile
+    import torch
+    from gcn_fmri_decoding_amd import models_gcn
+    M = int(L.shape[0])
+    rs = np.random.RandomState(5)
+    train = rs.randn(n_train, M, cfg['channel'])                   # float64, like perm_data_3d's output
+    tl = rs.randint(0, 21, n_train)
+    val, vl = rs.randn(n_val, M, cfg['channel']), rs.randint(0, 21, n_val)
+    steps = int(epochs * n_train / batch)
+    out = {'shape': {'M': M, 'batch': batch, 'train': n_train, 'val': n_val, 'steps': steps, 'evaluations': 1},
+           'what': 't_step of fit() as models_gcn.py:183-184 defines it (wall time of fit / steps; the evaluation pass over the '
+                   'validation set and the checkpoint of the last step inside), ' + tag}
+    old_home = os.environ.get('CHEBGCN_HOME')
+    with tempfile.TemporaryDirectory() as tmp:
+        os.environ['CHEBGCN_HOME'] = tmp
+        try:
+            for mode in ('staged', 'numpy_float64'):
+                torch.manual_seed(0)
+                np.random.seed(0)
+                net = models_gcn.cgcnn({'device': dev}, [L] * len(cfg['F']), cfg['F'], cfg['K'], cfg['p'], cfg['M'],
+                                       filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he', channel=cfg['channel'],
+                                       regularization=5e-4, dropout=0.5, batch_size=batch, learning_rate=0.001, decay_rate=0.9,
+                                       momentum=0.9, num_epochs=epochs, eval_frequency=steps, dir_name='bench_fit',
+                                       verbose=False)
+                t0 = time.perf_counter()
+                a, b = (net.stage(train), net.stage(val)) if mode == 'staged' else (train, val)
+                torch.cuda.synchronize()
+                t_stage = time.perf_counter() - t0
+                with contextlib.redirect_stdout(io.StringIO()):
+                    _, _, t_step = net.fit(a, tl, b, vl)
+                out[mode] = {'t_step_ms': 1e3 * t_step, 'windows_per_s': batch / t_step}
+                if mode == 'staged':
+                    out[mode]['staging_ms_outside_fit'] = 1e3 * t_stage
+                del net, a, b
+                torch.cuda.empty_cache()
+        finally:
+            if old_home is None:
+                os.environ.pop('CHEBGCN_HOME', None)
+            else:
+                os.environ['CHEBGCN_HOME'] = old_home
+    out['pcie_inclusive_over_staged'] = out['numpy_float64']['t_step_ms'] / out['staged']['t_step_ms']
+    return out
+
+
 def dp_overhead_leg(net, step, first, steps, plain_ms, dev):
     """Fixed cost of the data-parallel plumbing, visible at N = 1: the same training step with the model wrapped in
     ``dist.DataParallel`` on backend nccl (RCCL) with a world of ONE rank -- the broadcast, the gradient hooks and
@@ -270,22 +324,28 @@ def dp_overhead_leg(net, step, first, steps, plain_ms, dev):
     import torch
     import torch.distributed as dist
     from gcn_fmri_decoding_amd import dist as gdist
-    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % free_port(), rank=0, world_size=1, device_id=dev)
-    try:
-        dp = gdist.DataParallel(net)
-        for i in range(first, first + 3):
+    def timed(i0):
+        for i in range(i0, i0 + 3):
             step(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(first + 3, first + 3 + steps):
+        for i in range(i0 + 3, i0 + 3 + steps):
             step(i)
         torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / steps
+        return 1e3 * (time.perf_counter() - t0) / steps
+
+    plain_now = timed(first)                         # measured again, right in front of the wrapped steps (same clocks, same caches)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % free_port(), rank=0, world_size=1, device_id=dev)
+    try:
+        dp = gdist.DataParallel(net)
+        ms = timed(first + steps + 3)
         dp.remove()
     finally:
         dist.destroy_process_group()
-    return {'plain_ms_per_step': plain_ms, 'dp_world1_ms_per_step': ms, 'overhead_ms': ms - plain_ms, 'steps': steps,
-            'what': 'same step under dist.DataParallel on RCCL with world_size 1 (hooks + 3 async all-reduces + waits) vs plain'}
+    return {'plain_ms_per_step': plain_now, 'dp_world1_ms_per_step': ms, 'overhead_ms': ms - plain_now, 'steps': steps,
+            'timed_region_ms_per_step': plain_ms,
+            'what': 'same step under dist.DataParallel on RCCL with world_size 1 (hooks + 5 async all-reduces + waits) vs plain, '
+                    '%d steps each, back to back' % steps}
 
 
 def free_port():
@@ -454,7 +514,7 @@ def main():
     labels = torch.randint(0, 21, (S,), generator=g, device=dev)
     perm_dev = net.compose_perm(perm)                 # perm_data_3d's index map, composed with the model's internal vertex order
     repeats = max(1, args.repeats)
-    n_dp = 13 if (world == 1 and args.kernel_legs) else 0
+    n_dp = 2 * (DP_STEPS + 3) if (world == 1 and args.kernel_legs) else 0
     n_order = args.warmup + repeats * args.steps + args.instrumented_steps + n_dp
     order = torch.stack([torch.randperm(S, generator=g, device=dev)[:args.batch].to(torch.int32) for _ in range(n_order)])
 
@@ -488,8 +548,11 @@ def main():
     # ---- separate instrumented pass: HIP events around every hot-kernel launch on the launch stream (no second stream
     # on these steps: a kernel's time must not include a neighbour)
     kern, sampled = {}, 0
+    exposed_ms = None
     if args.instrumented_steps > 0:
         ops.timers = ops.KernelTimers(every=1)
+        if world > 1:
+            net._dp.exposed_events = []
         for i in range(nxt, nxt + args.instrumented_steps):
             ops.timers.next_step()
             step(i)
@@ -497,6 +560,12 @@ def main():
         sampled = ops.timers.sampled_steps
         ops.timers = None
         nxt += args.instrumented_steps
+        if world > 1:
+            ev, net._dp.exposed_events = net._dp.exposed_events, None
+            if ev:
+                t = torch.tensor([float(np.mean([a.elapsed_time(b) for a, b in ev]))], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exposed_ms = float(t.item())
 
     if rank == 0:
         global_batch = args.batch * world
@@ -511,6 +580,9 @@ def main():
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world,
                        'step': 'fwd+loss+bwd+allreduce+Adam, batch gathered on device'},
             'final_loss': loss,
+            # HIP-event time between this rank's last backward kernel and the point where every gradient bucket has arrived
+            # (max over ranks of the mean over the instrumented steps): the part of the all-reduce backward does not hide
+            'allreduce_exposed_ms': exposed_ms,
             'ms_per_step_repeats': {'all': region_ms, 'median': float(np.median(region_ms)), 'min': float(np.min(region_ms)),
                                     'max': float(np.max(region_ms)),
                                     'what': '%d timed regions of %d steps each, back to back; `value` / `ms_per_step` are the first'
@@ -530,7 +602,10 @@ def main():
                                                   'tools/pmc_traffic.sh at this shape, not measured in this run)',
                                 'avg_launch_ms': d['avg_ms'], 'launches': d['launches'],
                                 'algorithmic_bytes_per_launch': d['bytes'] / d['launches']}
-            step_ms = float(np.median(region_ms))
+            step_ms = 1e3 * dt / args.steps            # the same region `value` comes from
+            step_bytes = sum(v['bytes'] for v in kern.values()) / max(sampled, 1)
+            line['step_roofline'] = {'algorithmic_bytes_per_step': step_bytes, 'frac': step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     'what': 'algorithmic bytes of the hot kernels of one step (SURVEY.md 8d) / ms_per_step / 8 TB/s'}
             line['kernels'] = {k: {'avg_ms': v['avg_ms'], 'launches': v['launches'],
                                    'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
                                    'frac_hbm': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -545,10 +620,16 @@ def main():
                                                                 'M=10466; target frac >= 0.40')
             line['config4'] = kernel_leg(g0, 64, 64, 25, 30, 'BASELINE configs[3]: K=25, Fin=Fout=64, batch 64 (SpMM-bound regime)')
             line['config5'] = config5_leg(g0, 64, 60, 5, 256, 10)
-            line['dp_overhead'] = dp_overhead_leg(net, step, nxt, 10, float(np.median(region_ms)), dev)
+            line['dp_overhead'] = dp_overhead_leg(net, step, nxt, DP_STEPS, 1e3 * dt / args.steps, dev)
             del net, data
             torch.cuda.empty_cache()
             line['refshape'] = {'n360': refshape_leg(dev, 360, 100, 10), 'n1000': refshape_leg(dev, 1000, 100, 10)}
+            from gcn_fmri_decoding_amd import graph as G
+            line['fit'] = {'configs1': fit_leg(dev, Ls[0], cfg, args.batch, 8 * args.batch, 2 * args.batch, 25,
+                                               'BASELINE configs[1] (M = %d, batch %d)' % (Ls[0].shape[0], args.batch)),
+                           'refshape_n360': fit_leg(dev, G.synthetic_graph(360, k=8, levels=1)[0][0],
+                                                    dict(F=[32] * 6, K=[10] * 6, p=[1] * 6, M=[512, 256, 22], channel=15), 128, 1024,
+                                                    256, 25, "the reference's training shape (N = 360, K = 10, batch 128)")}
         if world == 1 and args.cpu_windows > 0:
             line['cpu_baseline'] = cpu_baseline(Ls[:1], cfg, args.cpu_windows)
         result_out.write(json.dumps(line) + '\n')

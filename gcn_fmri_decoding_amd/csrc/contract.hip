@@ -771,38 +771,7 @@ contract_bwd_w_kernel(BwdWArgs a) {
     for (int o = threadIdx.x; o < per; o += 256) dst[o] = lds[o];
 }
 
-// partial: [Z][Y][X][RT*16*64] raw accumulator images.  Stage 1: block (row, y*S + s, z) sums
-// the partials x = s, s+S, ... of one 64-lane accumulator row into stage[z][y][s][row][lane].
-constexpr int BW_SPLIT = 8;
-__global__ void __launch_bounds__(256)
-reduce_partials_stage1(const float* __restrict__ partial, float* __restrict__ stage, int nx, int ny, int rt) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int per = rt * 16 * 64;
-    const int row = blockIdx.x;
-    const int y = blockIdx.y / BW_SPLIT, sp = blockIdx.y % BW_SPLIT, z = blockIdx.z;
-    const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
-    float s = 0.f;
-    // eight partials in flight, added in the order they are indexed (as one load per iteration hipcc waits for each load
-    // before the add: 24 serial round trips per thread at 768 partials)
-    for (int x0 = sp + BW_SPLIT * part; x0 < nx; x0 += 8 * 4 * BW_SPLIT) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int x = x0 + u * 4 * BW_SPLIT;
-            v[u] = base[(size_t)(x < nx ? x : x0) * per];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (x0 + u * 4 * BW_SPLIT < nx) s += v[u];
-    }
-    red[part][lane] = s;
-    __syncthreads();
-    if (part == 0)
-        stage[((((size_t)z * ny + y) * BW_SPLIT + sp) * rt * 16 + row) * 64 + lane] =
-            ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-}
-
+// partial: [Z][Y][X][RT*16*64] raw accumulator images, summed in a fixed order by ONE launch:
 // Both stages in one launch for few partials (small launches: an atlas-sized layer leaves 192): block (row, y, z), four
 // thread groups take every fourth partial (eight in flight), fixed-order LDS sum, scatter to dW[kk][o].  One launch and
 // one pass instead of two launches with a round trip through `stage` (6.5 + 4.8 us + a launch gap at N = 360).
@@ -836,18 +805,41 @@ reduce_partials_small(const float* __restrict__ partial, float* __restrict__ dW,
     }
 }
 
-// Stage 2: sum the BW_SPLIT stage rows and scatter from the accumulator layout to dW[kk][o].
-__global__ void __launch_bounds__(64)
-reduce_partials_stage2(const float* __restrict__ stage, float* __restrict__ dW, int ny, int rt, int FinK, int Fout) {
-    const int lane = threadIdx.x;
+// Many partials (big launches: 768 workgroups), ONE launch: block (row, y, z) of 1024 threads = 16 thread groups that take
+// every 16th partial each (eight loads in flight), a fixed-order sum over the groups in LDS, scatter to dW[kk][o].  Replaces
+// the two-stage pass of rounds 1-3 (two launches with a round trip through a `stage` buffer); measured equal in the step
+// (0.107-0.109 ms per layer either way: the partials are not what this op waits for), one launch less.
+constexpr int BW_PARTS = 16;
+__global__ void __launch_bounds__(64 * BW_PARTS)
+reduce_partials_wide(const float* __restrict__ partial, float* __restrict__ dW, int nx, int ny, int rt, int FinK, int Fout) {
+    __shared__ float red[BW_PARTS][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int per = rt * 16 * 64;
     const int row = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+    const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
     float s = 0.f;
-    for (int sp = 0; sp < BW_SPLIT; ++sp)
-        s += stage[((((size_t)z * ny + y) * BW_SPLIT + sp) * rt * 16 + row) * 64 + lane];
-    const int t = row >> 4, j = row & 15, h = lane >> 5;
-    const int kk = (y * rt + t) * 32 + acc_row(j, h);
-    const int fo = z * 32 + (lane & 31);
-    if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = s;
+    for (int x0 = part; x0 < nx; x0 += 8 * BW_PARTS) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = x0 + BW_PARTS * u;
+            v[u] = base[(size_t)(x < nx ? x : x0) * per];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (x0 + BW_PARTS * u < nx) s += v[u];
+    }
+    red[part][lane] = s;
+    __syncthreads();
+    if (part == 0) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int q = 1; q < BW_PARTS; ++q) t += red[q][lane];
+        const int tt = row >> 4, j = row & 15, h = lane >> 5;
+        const int kk = (y * rt + tt) * 32 + acc_row(j, h);
+        const int fo = z * 32 + (lane & 31);
+        if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = t;
+    }
 }
 
 static int bw_rt(int ntiles) { return ntiles < 5 ? ntiles : 5; }
@@ -1036,7 +1028,7 @@ extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K,
     if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
     const int ntiles = (Fin * K + 31) / 32, rt = bw_rt(ntiles);
     const int gy = (ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
-    return ((size_t)gx + BW_SPLIT) * gy * gz * rt * 16 * 64 * sizeof(float);   // partials + stage
+    return (size_t)gx * gy * gz * rt * 16 * 64 * sizeof(float);   // one partial per workgroup
 }
 
 static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask, float* dW, void* workspace, int B, int M,
@@ -1081,13 +1073,9 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
         CG_HIP(hipGetLastError());
         return CHEBGCN_OK;
     }
-    float* stage = (float*)workspace + (size_t)gx * gy * gz * rt * 16 * 64;
-    note_dispatch_more("reduce_partials_stage1");
-    note_dispatch_more("reduce_partials_stage2");
-    hipLaunchKernelGGL(reduce_partials_stage1, dim3(rt * 16, gy * BW_SPLIT, gz), dim3(256), 0, stream,
-                       (const float*)workspace, stage, gx, gy, rt);
-    hipLaunchKernelGGL(reduce_partials_stage2, dim3(rt * 16, gy, gz), dim3(64), 0, stream, (const float*)stage, dW,
-                       gy, rt, a.FinK, Fout);
+    note_dispatch_more("reduce_partials_wide");
+    hipLaunchKernelGGL(reduce_partials_wide, dim3(rt * 16, gy, gz), dim3(64 * BW_PARTS), 0, stream, (const float*)workspace, dW, gx, gy,
+                       rt, a.FinK, Fout);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

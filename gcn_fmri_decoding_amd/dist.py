@@ -12,6 +12,7 @@ a ring is per-link bound and wants big messages):
 * bucket 0 = the FC head (71 % of the bytes at the benchmark config).  Its all-reduce is
   issued from a post-accumulate hook as soon as the last head gradient lands and overlaps
   the whole convolutional backward on RCCL's own stream.
+  (``cgcnn.enable_step_graph`` captures the step WITH its collectives on RCCL: the graph replays them like kernels.)
 * conv buckets = groups of consecutive layers, last layers first (default: two groups).  The
   conv layers write their gradients straight into the flat buffer (ops.ChebConv, no autograd
   hook fires), so ``ChebConv.backward`` reports a finished layer through ``layer_done``; when
@@ -36,6 +37,12 @@ class DataParallel:
         self._work = []
         self._hooks = []
         self._stream_ordered = dist.get_backend(process_group) == 'nccl'
+        # the step may be captured as a HIP graph with its collectives inside (cgcnn.enable_step_graph): RCCL's all-reduce
+        # is enqueued on a stream like a kernel; other backends run on the host
+        self.capturable = self._stream_ordered
+        # bench.py --gpus N: HIP events around the tail of the step that waits for the collectives (what of the all-reduce
+        # is NOT hidden behind backward); None = off
+        self.exposed_events = None
         for name in self._head_names:
             p = model._params[name]
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, name=name: self.head_grads_done((name,))))
@@ -138,8 +145,15 @@ class DataParallel:
                         self._reduce(a, b)
         elif m._n_total > m._n_head:
             self._reduce(m._n_head, m._n_total)
+        ev = None
+        if self.exposed_events is not None and m._grad.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()                          # behind the last backward kernel of this rank
         for w in self._work:
             w.wait()
+        if ev is not None:
+            ev[1].record()                          # the stream may go on (Adam): every bucket has arrived
+            self.exposed_events.append(ev)
         self._work = []
         return 1.0 / self.world
 

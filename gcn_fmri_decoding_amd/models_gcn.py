@@ -402,7 +402,8 @@ class base_model(object):
         forward, loss, backward, (gradient all-reduce), TF-form Adam.  Returns
         (reported learning rate, loss_average tensor).  With ``enable_step_graph(True)`` the step is captured
         once as a HIP graph and replayed (small graphs: the step is a chain of short kernels and launch-bound)."""
-        if self._step_graph_on and self._dp is None and self.momentum != 0 and self._fusable():
+        if (self._step_graph_on and (self._dp is None or self._dp.capturable) and self.momentum != 0 and self._fusable()
+                and ops.timers is None):
             return self._train_step_graphed(x_storage, labels)
         t = self.global_step + 1
         loss_average = self._step_body(x_storage, labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
@@ -458,7 +459,9 @@ class base_model(object):
         bookkeeping, the second stream of ``contract_bwd_w`` included -- and every later call copies the batch into
         the graph's input buffers, writes this step's two scalars (Adam's lr_t, the EMA's debiasing factor) and
         replays.  Same kernels, same arithmetic, same results as the eager step; the batch shape must stay fixed.
-        Not used under data parallelism (the all-reduces are issued from Python while backward runs)."""
+        Under ``dist.DataParallel`` on RCCL the gradient all-reduces are captured with the step (they are enqueued on
+        streams like kernels, forked from and joined to the capture stream) and replayed with it; on other backends
+        (gloo) the step stays eager.  While per-kernel event timers are set (``ops.timers``) the step runs eagerly too."""
         self._step_graph_on = bool(on)
         self._sg = None
         self._sg_warm = 0

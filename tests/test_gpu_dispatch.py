@@ -161,7 +161,7 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
 
 
 # how contract_bwd_w's partials are reduced, by launch size (contract.hip launch_bwd_w)
-BWD_W_TAIL = {'big': ' + reduce_partials_stage1 + reduce_partials_stage2', 'small': ' + reduce_partials_small'}
+BWD_W_TAIL = {'big': ' + reduce_partials_wide', 'small': ' + reduce_partials_small'}
 
 
 ORD_F, ORD_A = 'cheb_ord_kernel<10240,6,5,512,false>', 'cheb_ord_kernel<10240,6,5,512,true>'

@@ -156,7 +156,7 @@ sys.path.insert(0, os.environ['CHEBGCN_ROOT']); sys.path.insert(0, os.path.join(
 from conftest import csr_from, load_golden
 from gcn_fmri_decoding_amd import models_gcn, ops, dist as gdist
 rank, world, out = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), os.environ['CHEBGCN_OUT']
-dev = torch.device('cuda:0')
+dev = torch.device('cuda', rank if os.environ.get('CHEBGCN_DEV_PER_RANK') == '1' else 0)     # one GPU per rank, or all on cuda:0
 torch.cuda.set_device(dev)
 force_dp = os.environ.get('CHEBGCN_FORCE_DP') == '1'      # world 1 on RCCL: the collective calls as the 8-GPU bench makes them
 if world > 1 or force_dp:
@@ -171,6 +171,8 @@ net = models_gcn.cgcnn({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z[
                        dropout=1, initial='he', verbose=False)
 if world > 1 or force_dp:
     dp = gdist.DataParallel(net)
+if os.environ.get('CHEBGCN_STEP_GRAPH') == '1':
+    net.enable_step_graph(True)                    # two eager steps, the third is captured (with its collectives) and replayed
 net._init_variables()                              # what fit() does after wrapping (the reference re-runs op_init) ...
 if world > 1 or force_dp:
     dp.broadcast_parameters()                      # ... followed by this (models_gcn.fit): rank 0's second draw wins
@@ -188,11 +190,17 @@ for step in range(3):
 torch.cuda.synchronize()
 np.savez(out % rank, flat0=flat0, flat=net._flat.detach().cpu().numpy(), g0=grads[0], g2=grads[2],
          sent=np.array(sorted(net._dp._sent) if net._dp is not None else []),
-         nb=len(net._dp._buckets) if net._dp is not None else 0)
+         nb=len(net._dp._buckets) if net._dp is not None else 0, captured=int(net._sg is not None))
 if world > 1 or force_dp:
     dist.barrier()
     dist.destroy_process_group()
 '''
+
+
+@pytest.fixture
+def fixture_two_gpus():
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (this box has %d): the RCCL path between two devices is exercised on any multi-GPU box' % torch.cuda.device_count())
 
 
 def _run_ranks(world, fixture, tmp_path, tag, extra_env=None):
@@ -252,3 +260,31 @@ def test_cgcnn_data_parallel_on_rccl_world_one(dev, tmp_path):
         # bit-identical: every gradient of the library is a fixed-order sum (the per-filter bias sums of this b1relu
         # model too: two-stage reduction since round 3), and a sum over one rank is the identity
         assert np.array_equal(dp[k], one[k]), k
+    # the same with the step captured as ONE HIP graph, the RCCL all-reduces inside it (cgcnn.enable_step_graph under
+    # dist.DataParallel: steps 1-2 eager, step 3 captured and replayed)
+    cap = _run_ranks(1, fixture, tmp_path, 'rccl_graph', {'CHEBGCN_FORCE_DP': '1', 'CHEBGCN_BACKEND': 'nccl', 'CHEBGCN_STEP_GRAPH': '1'})[0]
+    assert int(cap['captured']) == 1
+    for k in ('g0', 'g2', 'flat'):
+        assert np.array_equal(cap[k], one[k]), k
+
+
+@pytest.mark.parametrize('step_graph', ['0', '1'])
+def test_cgcnn_data_parallel_two_gpus_rccl(fixture_two_gpus, tmp_path, step_graph):
+    """Two RCCL ranks on two GPUs (what ``bench.py --gpus 2`` runs; skipped on a one-GPU box): halves of a batch of 4
+    against one process on the whole batch -- identical start after the broadcast, averaged gradients equal to the
+    full-batch gradients, same variables after three Adam steps; eagerly and with the third step captured as a HIP graph
+    that holds the all-reduces.  Exercises dist.DataParallel._reduce's reliance on RCCL ordering a collective behind the
+    kernels already enqueued on the stream that issues it, from inside autograd's backward."""
+    fixture = 'inference_pool_n212'
+    env = {'CHEBGCN_BACKEND': 'nccl', 'CHEBGCN_DEV_PER_RANK': '1', 'CHEBGCN_STEP_GRAPH': step_graph}
+    two = _run_ranks(2, fixture, tmp_path, 'g2', env)
+    one = _run_ranks(1, fixture, tmp_path, 'g1')[0]
+    a, b = two
+    assert np.array_equal(a['flat0'], b['flat0']) and np.array_equal(a['flat0'], one['flat0'])
+    assert int(a['nb']) == 2 and a['sent'].tolist() == [0, 1]
+    assert np.array_equal(a['g0'], b['g0']) and np.array_equal(a['flat'], b['flat'])
+    assert np.abs(0.5 * a['g0'] - one['g0']).max() <= 2e-5 * np.abs(one['g0']).max()
+    assert np.abs(0.5 * a['g2'] - one['g2']).max() <= 1e-3 * np.abs(one['g2']).max()
+    d = np.abs(a['flat'] - one['flat'])
+    assert np.quantile(d, 0.99) <= 2e-5 * np.abs(one['flat']).max() and d.max() <= 3 * 1.1e-3
+    assert int(a['captured']) == int(step_graph)

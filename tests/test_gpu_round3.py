@@ -238,7 +238,7 @@ def test_bench_prints_one_json_line_on_stdout():
     assert len(lines) == 1, r.stdout[:2000]
     line = json.loads(lines[0])
     assert line['n_gpus'] == 1 and line['n_ranks_seen'] == 1 and line['steps'] == 3
-    for key in ('roofline', 'kernels', 'northstar', 'config4', 'config5', 'dp_overhead', 'refshape'):        # (cpu_baseline: --cpu-windows 0 here)
+    for key in ('roofline', 'step_roofline', 'kernels', 'northstar', 'config4', 'config5', 'dp_overhead', 'refshape', 'fit'):        # (cpu_baseline: --cpu-windows 0 here)
         assert key in line, key
     assert line['roofline']['bound'] == 'hbm' and 0.2 < line['roofline']['frac'] < 1.0
 
