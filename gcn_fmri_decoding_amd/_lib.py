@@ -54,6 +54,10 @@ SIGNATURES = {
     'chebgcn_contract_bwd_w_relu_mean': (_i, [_p, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_x_relu_mean': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'chebgcn_bias_grad_relu_mean': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p]),
+    'chebgcn_fused_layer_supported': (_i, [_p, _i, _i, _i, _i]),
+    'chebgcn_fused_layer_workspace': (C.c_size_t, [_p, _i, _i, _i, _i]),
+    'chebgcn_fused_layer_fwd': (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
+    'chebgcn_fused_layer_bwd_x': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'chebgcn_perm_data': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'chebgcn_to_plane': (_i, [_p, _p, _i, _i, _i, _p]),
     'chebgcn_from_plane': (_i, [_p, _p, _i, _i, _i, _p]),

@@ -731,11 +731,19 @@ class cgcnn(base_model):
         self.graphs = []
         if self.device.type == 'cuda':
             order = None
+            force = self.vertex_order == 'length!'          # experiments: relabel even where no kernel gains from it
+            if force:
+                self.vertex_order = 'length'
             if (self.vertex_order == 'length' and all(pp == 1 for pp in p) and all(Li is self.L[0] for Li in self.L)
                     and self._fusable()):
                 order = graph_mod.length_order(self.L[0])
                 g = ops.Graph(self.L[0], self.device, order=order)
-                if g.ordered:
+                # Who gains from sorted rows: the ordered recurrence kernels (big graphs).  The on-chip layer of atlas-sized
+                # graphs (csrc/fused_small.hip) would gain 3 % (its waves then gather rows of equal length; captured step at
+                # N = 360 0.943 -> 0.911 ms) -- not taken: in the coarsening's tree order spatial neighbours are adjacent and
+                # the weight gradients' long cancelling sums over the vertices come out within 2e-7 of float64; in degree
+                # order they carry plain fp32 summation noise (1e-4 of their scale, like NumPy's fp32).
+                if g.ordered or force:
                     self.graphs = [g] * len(self.L)
                 else:
                     order = None                        # no ordered kernel for this graph size: nothing to gain

@@ -73,6 +73,8 @@ class KernelTimers:
 
 timers = None
 fold_relu_grad = True        # pool == 1 layers: ReluGrad inside chebgcn_contract_bwd_*_relu (False: separate brelu_pool_bwd pass)
+# atlas-sized graphs: recurrence + contraction (and the gradient wrt the input) as one on-chip launch per layer
+fused_small = os.environ.get('CHEBGCN_FUSED_SMALL', '1') != '0' 
 # contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd (dW feeds neither): +1.5 % on the
 # configs[1] step.  Not on instrumented steps, whose per-kernel event times must not include a neighbour.
 overlap_bwd_w = True
@@ -343,14 +345,20 @@ class ChebConv(torch.autograd.Function):
         if FinK != Fin * K:
             raise ValueError('weight rows %d != Fin*K = %d' % (FinK, Fin * K))
         Wc = W.detach().contiguous()
+        Mo = M // pool
+        mean = bool(bufs is not None and bufs.mean)
+        precision = getattr(bufs, 'precision', 'f32') if bufs is not None else 'f32'
+        # atlas-sized graphs (<= 384 vertices, Fin, Fout <= 32, no pooling): the whole layer in one on-chip launch
+        # (csrc/fused_small.hip); the stack is written only when a weight gradient will read it
+        if (fused_small and pool == 1 and precision == 'f32' and not mean
+                and lib.chebgcn_fused_layer_supported(graph.handle, B, Fin, K, Fout)):
+            return ChebConv._forward_fused(ctx, x, Wc, bias, graph, K, relu, bias_kind, bufs, stack, out)
         if stack is None:
             stack = torch.empty((K, B, Fin, Mp), dtype=torch.float32, device=x.device)
         # algorithmic bytes: recurrence 4*M*Fin*K per window; the contraction's
         # compulsory traffic 4*(M*Fin*K + M*Fout/pool) per window, flops 2*M*Fin*K*Fout
         _lib.check(_launch('recurrence_fwd', 4.0 * M * Fin * K * B, 0.0, lambda: lib.chebgcn_recurrence_fwd(
             graph.handle, _p(x), _p(stack), B, Fin, K, _stream())), 'recurrence_fwd')
-        Mo = M // pool
-        mean = bool(bufs is not None and bufs.mean)
         if mean:
             if not conv_mean_supported(B, M, Fin, K, Fout, pool, relu, getattr(bufs, 'precision', 'f32')):
                 raise ValueError('cheb_conv(mean=True): layer not served (ops.conv_mean_supported)')
@@ -362,7 +370,7 @@ class ChebConv(torch.autograd.Function):
                                lambda: lib.chebgcn_contract_fwd_mean(_p(stack), _p(Wc), _p(b), bias_kind, _p(y), _p(mask), B, M,
                                                                      Fin, K, Fout, _stream())), 'contract_fwd_mean')
             ctx.save_for_backward(stack, Wc, None, mask)
-            ctx.fold, ctx.mean = True, True
+            ctx.fold, ctx.mean, ctx.fused = True, True, False
             ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
             ctx.bias_shape = None if bias is None else tuple(bias.shape)
             ctx.grad_bufs = (bufs.dW, bufs.dbias)
@@ -375,7 +383,6 @@ class ChebConv(torch.autograd.Function):
             out = out.detach()                # fresh alias: an output, not an input, for autograd
             if tuple(out.shape) != (B, Fout, plane_stride(Mo)) or not out.is_contiguous():
                 raise ValueError('out buffer has the wrong shape')
-        precision = getattr(bufs, 'precision', 'f32') if bufs is not None else 'f32'
         argmax = None
         if pool > 1 and (pool_kind == POOL_MAX or relu):
             argmax = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
@@ -391,12 +398,48 @@ class ChebConv(torch.autograd.Function):
             b = b.contiguous()
         contract_fwd_into(stack, Wc, b, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision)
         ctx.save_for_backward(stack, Wc, None if (pool == 1 and relu) else out, argmax)
-        ctx.fold, ctx.mean = fold, False
+        ctx.fold, ctx.mean, ctx.fused = fold, False, False
         ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
         ctx.bias_shape = None if bias is None else tuple(bias.shape)
         ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
         ctx.done = bufs.done if bufs is not None else None
         ctx.precision = precision
+        return out
+
+    @staticmethod
+    def _forward_fused(ctx, x, Wc, bias, graph, K, relu, bias_kind, bufs, stack, out):
+        lib = _lib.lib()
+        B, Fin, Mp = x.shape
+        M, Fout = graph.M, Wc.shape[1]
+        need_w = bool(ctx.needs_input_grad[1])
+        wants_grad = any(ctx.needs_input_grad[:3])
+        if not need_w:
+            stack = None                          # nothing will read it (inference, frozen weights): it is never written
+        elif stack is None:
+            stack = torch.empty((K, B, Fin, Mp), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = plane_empty(B, Fout, M, x.device)
+        else:
+            out = out.detach()
+            if tuple(out.shape) != (B, Fout, Mp) or not out.is_contiguous():
+                raise ValueError('out buffer has the wrong shape')
+        mask = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device) if (relu and wants_grad) else None
+        b = bias.detach() if bias is not None else None
+        if b is not None and not b.is_contiguous():
+            b = b.contiguous()
+        nws = lib.chebgcn_fused_layer_workspace(graph.handle, B, Fin, K, Fout)
+        ws = _workspace(nws, x.device, 'fused_fwd') if nws else None
+        nbytes = 4.0 * B * M * (Fin + Fout + (Fin * (K - 1) if stack is not None else 0))
+        _lib.check(_launch('fused_layer_fwd', nbytes, 2.0 * B * M * Fin * K * Fout, lambda: lib.chebgcn_fused_layer_fwd(
+            graph.handle, _p(x), _p(Wc), _p(b), bias_kind, _p(stack), _p(out), _p(mask), _p(ws), nws, B, Fin, K, Fout, int(relu),
+            _stream())), 'fused_layer_fwd')
+        ctx.save_for_backward(stack, Wc, None if relu else out, mask)
+        ctx.fold, ctx.mean, ctx.fused = bool(relu), False, True
+        ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, 1, POOL_MAX, int(relu), bias_kind)
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
+        ctx.done = bufs.done if bufs is not None else None
+        ctx.precision = 'f32'
         return out
 
     @staticmethod
@@ -492,7 +535,13 @@ class ChebConv(torch.autograd.Function):
         else:
             side = None
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.fused:
+            # G_j = dy W_j^T on the matrix cores feeding the adjoint recurrence on chip: no gradient stack in memory
+            dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
+            _lib.check(_launch('fused_layer_bwd_x', 4.0 * B * M * (Fin + Fout), 2.0 * B * M * Fin * K * Fout,
+                               lambda: lib.chebgcn_fused_layer_bwd_x(g.handle, _p(dy), _p(mask), _p(Wc), _p(dx), B, Fin, K, Fout,
+                                                                     _stream())), 'fused_layer_bwd_x')
+        elif ctx.needs_input_grad[0]:
             gstack = torch.empty((K, B, Fin, g.Mp), dtype=torch.float32, device=dev)
             passes = PRECISIONS[ctx.precision]
             if passes:

@@ -217,6 +217,27 @@ int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* relu_mask, fl
                                 int B, int M, int F, void* workspace, size_t workspace_bytes,
                                 chebgcn_stream stream);
 
+/* ---- atlas-sized graphs: one Chebyshev layer per launch, on chip ---------------------------------
+ * models_gcn.py:587-629 (chebyshev5 + b1relu / b2relu, no pooling) for graphs of at most 384 vertices (the
+ * reference's own atlases: 246..360 regions, configure_fmri.py:11) and Fin, Fout <= 32: a workgroup carries a whole
+ * window through the recurrence in LDS / registers and multiplies every T_k with W_k on the matrix cores while it is
+ * still on chip -- the stack is written only if `stack` is non-NULL (training: chebgcn_contract_bwd_w reads it), never
+ * read; slab 0 may be x itself.  Same operands, layouts, results (fp32 round-off) and ReLU mask as
+ * chebgcn_recurrence_fwd + chebgcn_contract_fwd(pool = 1).  chebgcn_fused_layer_supported() says whether a shape is
+ * served (else CHEBGCN_EUNSUPPORTED).
+ *   chebgcn_fused_layer_bwd_x: d(loss)/dx of the same layer from d(loss)/d(output) (gated by relu_mask unless NULL):
+ *   G_j = dy W_j^T on the matrix cores feeding the adjoint recurrence directly -- replaces chebgcn_contract_bwd_x[_relu]
+ *   + chebgcn_recurrence_bwd, no gradient stack in memory. */
+int chebgcn_fused_layer_supported(const chebgcn_graph* g, int B, int Fin, int K, int Fout);
+/* Device scratch the forward needs (0 for large batches): with fewer than ~3/4 of a window per CU a window is split between
+ * two workgroups (half of the input planes each) whose partial sums a second small launch adds in a fixed order. */
+size_t chebgcn_fused_layer_workspace(const chebgcn_graph* g, int B, int Fin, int K, int Fout);
+int chebgcn_fused_layer_fwd(const chebgcn_graph* g, const float* x, const float* W, const float* bias, int bias_kind,
+                            float* stack, float* out, uint8_t* relu_mask, void* workspace, size_t workspace_bytes,
+                            int B, int Fin, int K, int Fout, int relu, chebgcn_stream stream);
+int chebgcn_fused_layer_bwd_x(const chebgcn_graph* g, const float* dout, const uint8_t* relu_mask, const float* W,
+                              float* dx, int B, int Fin, int K, int Fout, chebgcn_stream stream);
+
 /* ---- layout / staging -----------------------------------------------------------
  * perm_data: coarsening.perm_data_3d (lib_new/coarsening.py:244-265) fused with the
  * fp32 cast and batch gather of fit() (models_gcn.py:138-146):

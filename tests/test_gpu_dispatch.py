@@ -453,3 +453,81 @@ def test_internal_vertex_order_is_invisible(ops, dev, monkeypatch):
         assert torch.equal(a._ref_view(a._adam_m, k), b._ref_view(b._adam_m, k)), k
     a.load_state_dict(b.state_dict())
     assert all(np.array_equal(a.get_var(k), b.get_var(k)) for k in a.variables())
+
+
+@pytest.mark.parametrize('N,B,Fin,K,Fout,bias_kind,split', [
+    (360, 128, 32, 10, 32, 'vertex', 2),        # the reference's training shape (training.py:34, configure_fmri.py:11, 28): layers 2-6
+    (360, 128, 15, 10, 32, 'vertex', 2),        # ... layer 1 (block_dura = 15 input planes)
+    (360, 200, 32, 4, 32, 'filter', 1),         # more than 3/4 of a window per CU: one workgroup per window
+    (246, 7, 5, 3, 20, 'none', 2),              # M = 260 (eight waves); no bias, no ReLU: plain gradients
+])
+def test_fused_atlas_layer_vs_oracle(ops, dev, lib, N, B, Fin, K, Fout, bias_kind, split):
+    """csrc/fused_small.hip: recurrence + contraction of a layer in one on-chip launch (atlas-sized graphs), and the gradient
+    wrt its input (G_j = dy W_j^T feeding the adjoint recurrence) -- against the CPU oracle (oracle/layers_ref.py <->
+    lib_new/models_gcn.py:587-629 and its autodiff): output, ReLU mask, the stack it leaves for the weight gradient, dx."""
+    from gcn_fmri_decoding_amd import _lib, graph
+    from oracle import layers_ref as R
+    Ls, _, _ = graph.synthetic_graph(N, k=8, levels=1)
+    L = Ls[0]
+    g = ops.Graph(L, dev)
+    M, Mp = g.M, g.Mp
+    assert lib.chebgcn_fused_layer_supported(g.handle, B, Fin, K, Fout) == 1
+    rs = np.random.RandomState(N + B)
+    x = rs.randn(B, M, Fin).astype(np.float32)
+    W = (rs.randn(Fin * K, Fout) * (0.5 / np.sqrt(Fin * K))).astype(np.float32)
+    relu = bias_kind != 'none'
+    kind = {'vertex': ops.BIAS_VERTEX, 'filter': ops.BIAS_FILTER, 'none': ops.BIAS_NONE}[bias_kind]
+    bref = (rs.randn(1, M if bias_kind == 'vertex' else 1, Fout) * 0.3).astype(np.float32) if relu else np.zeros((1, 1, Fout), np.float32)
+    y, T = R.chebyshev5_fwd(x, L, W, K, return_stack=True)               # T: [K, M, Fin, B]
+    act = R.brelu_fwd(y, bref) if relu else y
+    do = rs.randn(B, M, Fout).astype(np.float32)
+    dy = R.brelu_bwd(do, act, bref.shape)[0] if relu else do
+    dx_ref, _ = R.chebyshev5_bwd(dy.astype(np.float32), L, W, K, T, need_dx=True)
+
+    xs = torch.full((B, Fin, Mp), float('nan'), device=dev)
+    xs[:, :, :M] = torch.as_tensor(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    Wd = torch.as_tensor(W).to(dev)
+    bd = None
+    if bias_kind == 'vertex':
+        bd = torch.zeros((Fout, Mp), device=dev)
+        bd[:, :M] = torch.as_tensor(bref[0].T.copy()).to(dev)
+    elif bias_kind == 'filter':
+        bd = torch.as_tensor(bref.reshape(-1)).to(dev)
+    nws = lib.chebgcn_fused_layer_workspace(g.handle, B, Fin, K, Fout)
+    assert (nws > 0) == (split == 2)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+    stack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    out = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    mask = torch.zeros((B, Fout, Mp // 4), dtype=torch.uint8, device=dev)
+    nw = 8 if Mp <= 256 else 12
+    _lib.check(lib.chebgcn_fused_layer_fwd(g.handle, P(xs), P(Wd), P(bd), kind, P(stack), P(out), P(mask) if relu else None, P(ws), nws,
+                                           B, Fin, K, Fout, int(relu), stream()), 'fused_layer_fwd')
+    want = 'fused_layer_kernel<%d,%d,false>' % (nw, 16 // split) + (' + fused_combine_kernel' if split == 2 else '')
+    assert _lib.last_dispatch() == want, _lib.last_dispatch()
+    got = {}
+    o = out[:, :, :M].permute(0, 2, 1).cpu().numpy()
+    got['out'] = np.abs(o - act).max() / np.abs(y).max()
+    assert got['out'] <= REL, 'output: %.3e' % got['out']
+    st = stack[:, :, :, :M].permute(0, 3, 2, 1).cpu().numpy()             # [K, M, Fin, B]
+    got['stack'] = np.abs(st - T).max() / np.abs(T).max()
+    assert got['stack'] <= REL, 'stack: %.3e' % got['stack']
+    if relu:
+        bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, Fout, Mp)[..., :M].bool()
+        assert torch.equal(bits, out[..., :M] > 0), 'ReLU bit mask disagrees with the output'
+    # inference form: no stack is written, same output bits
+    out2 = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_fused_layer_fwd(g.handle, P(xs), P(Wd), P(bd), kind, None, P(out2), None, P(ws), nws, B, Fin, K, Fout, int(relu),
+                                           stream()), 'fused_layer_fwd')
+    assert torch.equal(out2[..., :M], out[..., :M])
+    dout = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    dout[:, :, :M] = torch.as_tensor(np.ascontiguousarray(do.transpose(0, 2, 1))).to(dev)
+    if not relu:
+        dout[..., M:] = 0.0
+    dx = torch.full((B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_fused_layer_bwd_x(g.handle, P(dout), P(mask) if relu else None, P(Wd), P(dx), B, Fin, K, Fout, stream()),
+               'fused_layer_bwd_x')
+    assert _lib.last_dispatch() == 'fused_layer_kernel<%d,%d,true>' % (nw, 16 // split)
+    d = dx[:, :, :M].permute(0, 2, 1).cpu().numpy()
+    got['dx'] = np.abs(d - dx_ref).max() / np.abs(dx_ref).max()
+    assert got['dx'] <= GREL, 'dx: %.3e' % got['dx']
+    record_measured('fused_atlas_layer_vs_oracle[%d,%d,%d,%d,%d]' % (N, B, Fin, K, Fout), **got)

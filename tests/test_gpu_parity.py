@@ -178,8 +178,15 @@ def test_chebyshev5_layer_vs_reference_vectors(ops, dev):
             close(from_storage(ymp, M // p), z['cheb_%s_mp%d' % (tag, p)], what='mpool %s %d' % (tag, p))
             yap = ops.cheb_conv(xs, Wd, b2, g, K, pool=p, pool_kind=ops.POOL_AVG, relu=True, bias_kind=ops.BIAS_VERTEX)
             close(from_storage(yap, M // p), z['cheb_%s_ap%d' % (tag, p)], what='apool %s %d' % (tag, p))
-            # unfused kernels give the same numbers
-            y2 = ops.cheb_conv(xs, Wd, None, g, K)
+            # unfused kernels give the same numbers (the same contraction kernel with and without its epilogue: the
+            # on-chip layer of csrc/fused_small.hip, which serves p == 1 on graphs of this size, sums in another order)
+            fs, ops.fused_small = ops.fused_small, False
+            try:
+                y2 = ops.cheb_conv(xs, Wd, None, g, K)
+                if p == 1:
+                    ymp = ops.cheb_conv(xs, Wd, b2, g, K, pool=p, pool_kind=ops.POOL_MAX, relu=True, bias_kind=ops.BIAS_VERTEX)
+            finally:
+                ops.fused_small = fs
             yu = ops.BiasReluPool.apply(y2, b2, M, p, ops.POOL_MAX, True, ops.BIAS_VERTEX)
             assert torch.equal(yu[:, :, :M // p], ymp[:, :, :M // p])
 

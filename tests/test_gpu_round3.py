@@ -192,14 +192,15 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
         # deeper layers in either fp32 evaluation -- so they are compared at the 99 % quantile, weights at 99.9 %
         qq = 0.99 if spec.group == 'convb' else 0.999
         q_gpu, q_o32 = np.quantile(e_gpu, qq), np.quantile(e_o32, qq)
-        measured[k] = [float(q_gpu), float(e_gpu.max()), float(q_o32), float(e_o32.max())]
-        assert q_gpu <= max(1e-4 if spec.group == 'convb' else 5e-4, 3 * q_o32), \
-            'grad %s: %.1f %% quantile %.3e (fp32 oracle %.3e)' % (k, 100 * qq, q_gpu, q_o32)
-        if spec.group != 'convb':          # a weight gradient sums over every vertex and window: single flips average out
-            assert e_gpu.max() <= max(2e-3, 3 * e_o32.max()), 'grad %s: max %.3e (fp32 oracle %.3e)' % (k, e_gpu.max(), e_o32.max())
+        measured[k] = [float(q_gpu), float(e_gpu.max()), float(q_o32), float(e_o32.max()), spec.group]
     from conftest import record_measured
     record_measured('reference_training_shape_vs_oracle[%d]' % n_nodes, what='[quantile, max] of the GPU, of the fp32 oracle; of scale',
                     **measured)
+    for k, (q_gpu, m_gpu, q_o32, m_o32, group) in measured.items():
+        assert q_gpu <= max(1e-4 if group == 'convb' else 5e-4, 3 * q_o32), \
+            'grad %s: quantile %.3e (fp32 oracle %.3e)' % (k, q_gpu, q_o32)
+        if group != 'convb':          # a weight gradient sums over every vertex and window: single flips average out
+            assert m_gpu <= max(2e-3, 3 * m_o32), 'grad %s: max %.3e (fp32 oracle %.3e)' % (k, m_gpu, m_o32)
     state, ill = {}, {}
     R.adam_tf_step(params, grads, state)
     for k in params:

@@ -13,13 +13,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'refresh')
 DST = os.path.join(ROOT, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 
 for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats.csv', '%s_bench_kernel_stats.csv'),
                  ('kbench.txt', '%s_kbench.txt'), ('kbench.json', '%s_kbench.json'),
                  ('kbench_config4.txt', '%s_kbench_config4_K25_F64.txt'), ('kbench_config5.txt', '%s_kbench_config5_bf16.txt'),
                  ('hbm_stream_probe.txt', '%s_hbm_stream_probe.txt'), ('mfma_f32_probe.txt', '%s_mfma_f32_probe.txt'),
-                 ('traffic_raw.json', '%s_traffic_raw.json'), ('kbench_two_planes.txt', '%s_kbench_two_plane_recurrence.txt'),
+                 ('traffic_raw.json', '%s_traffic_raw.json'), ('kbench_two_planes.txt', '%s_kbench_two_plane_recurrence.txt'), ('kbench_reference_order.txt', '%s_kbench_reference_order_recurrence.txt'),
+                 ('stampso.txt', '%s_recurrence_ord_phase_stamps.txt'), ('parity_measured.jsonl', '%s_parity_measured.jsonl'),
                  ('mfma.txt', '%s_contraction_mfma_counters.txt'), ('stamps4.txt', '%s_recurrence4_phase_stamps.txt'), ('mfma_counters_available.txt', '%s_mfma_counters_available.txt'),
                  ('config4_kernel_stats.csv', '%s_config4_kernel_stats.csv'), ('config5_kernel_stats.csv', '%s_config5_kernel_stats.csv'),
                  ('northstar_recurrence_fwd_inplace_kernel_stats.csv', '%s_northstar_fwd_inplace_kernel_stats.csv'),
@@ -42,7 +43,8 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
             shutil.copy(p, os.path.join(DST, dst % tag))
 
 raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
-names = {'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd',
+names = {'cheb_ord_kernel<10240, 6, 5, 512, false>': 'recurrence_fwd', 'cheb_ord_kernel<10240, 6, 5, 512, true>': 'recurrence_bwd',
+         'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd_2planes', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd_2planes',
          'cheb4_kernel<10240, 20, 6, 512, false,': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true,': 'recurrence_bwd_4planes',
          'contract_fwd_kernel<1>': 'contract_fwd', 'contract_fwd_ring_kernel': 'contract_fwd', 'contract_bwd_w_kernel<5, true>': 'contract_bwd_w',
          'contract_bwd_x_kernel<true, true>': 'contract_bwd_x', 'contract_bwd_x_lds_kernel<true>': 'contract_bwd_x',

@@ -31,6 +31,9 @@ def main():
     ap.add_argument('--nodes', type=int, default=10000, help='points of the synthetic kNN graph (10000 -> M = 10466)')
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (0 = automatic, 2, 4)')
+    ap.add_argument('--order', default='length', choices=['length', 'reference'],
+                    help="vertex order of the graph: 'length' = relabelled by descending row length as cgcnn does for a network "
+                         "without pooling (ordered recurrence kernels); 'reference' = the caller's numbering")
     ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
     ap.add_argument('--stagger', type=int, default=0, help='chebgcn_tune(4, x): start stagger override (x-1 eighths), 0 = automatic')
     ap.add_argument('--wide', type=int, default=0, help='chebgcn_tune(3, x): 1 = 1024-thread recurrence shape')
@@ -50,7 +53,9 @@ def main():
     if tune is not None:
         tune(3, args.wide)
         tune(4, args.stagger)
-    g = ops.Graph(Ls[0], dev, planes=args.planes)
+    from gcn_fmri_decoding_amd import graph as G
+    g = ops.Graph(Ls[0], dev, planes=args.planes, order=G.length_order(Ls[0]) if (args.order == 'length' and not args.planes) else None)
+    print('ordered recurrence kernels:', bool(g.query(12)), flush=True)
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
           g.query(11), flush=True)
     M, Mp = g.M, g.Mp
@@ -146,7 +151,7 @@ def main():
                 results.append(r)
                 if args.stamps and name.startswith('recurrence'):
                     buf = (ctypes.c_longlong * (16 * 64))()
-                    assert (handle.chebgcn_debug_stamps4 if g.query(6) == 4 and g.query(7) > 2048 else handle.chebgcn_debug_stamps)(buf) == 0
+                    assert (handle.chebgcn_debug_stampso if g.query(12) else handle.chebgcn_debug_stamps4 if g.query(6) == 4 and g.query(7) > 2048 else handle.chebgcn_debug_stamps)(buf) == 0
                     t = np.array(buf, dtype=np.int64).reshape(16, 64)
                     t0 = t[:, 0][t[:, 0] > 0].min()
                     print('   stamps (cycle counter ticks since the first wave entered the group), one row per wave:')
@@ -155,8 +160,8 @@ def main():
                     for w in range(16):
                         if t[w, 0] > 0:
                             print('   w%-3d ' % w + ' '.join('%7d' % (t[w, i] - t0) for i in ids))
-                print('%-16s B=%-4d abl=%-2d  %8.3f ms (min %7.3f)  %7.0f GB/s  %5.1f%% of 8 TB/s  %6.1f TFLOP/s'
-                      % (name, B, abl, med, best, r['GBps'], 100 * r['frac_hbm'], r['TFLOPs']), flush=True)
+                print('%-16s B=%-4d abl=%-2d  %8.3f ms (min %7.3f)  %7.0f GB/s  %5.1f%% of 8 TB/s  %6.1f TFLOP/s   %s'
+                      % (name, B, abl, med, best, r['GBps'], 100 * r['frac_hbm'], r['TFLOPs'], _lib.last_dispatch()), flush=True)
     if args.json:
         with open(args.json, 'w') as f:
             json.dump(results, f, indent=1)

@@ -10,6 +10,8 @@ cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench_line.json 2> $out/bench.err
 python3 tools/kbench.py --json $out/kbench.json > $out/kbench.txt 2>&1
 python3 tools/kbench.py --planes 2 --B 64 256 --kernels recurrence_fwd recurrence_fwd_inplace recurrence_bwd > $out/kbench_two_planes.txt 2>&1
+# the kernels of rounds 1-3 (the caller's vertex numbering: four planes at batch 256, two at batch 64) beside the ordered ones
+python3 tools/kbench.py --order reference --B 64 256 --kernels recurrence_fwd recurrence_fwd_inplace recurrence_bwd > $out/kbench_reference_order.txt 2>&1
 python3 tools/kbench.py --B 64 256 --fin 64 --K 25 --kernels recurrence_fwd_inplace recurrence_bwd --iters 30 > $out/kbench_config4.txt 2>&1
 python3 tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 --iters 10 > $out/kbench_config5.txt 2>&1
 bash tools/pmc_traffic.sh refresh > $out/traffic.log 2>&1
@@ -42,4 +44,5 @@ grep "^{\"shape\"" $out/profr.log | tail -1 > $out/refshape_n360_line.json
 for b in 8 16 32 64; do $GRAFT_REPO_ROOT/tools/probes/hbm_stream_probe $b; done > $out/hbm_stream_probe.txt 2>&1
 $GRAFT_REPO_ROOT/tools/probes/mfma_f32_probe > $out/mfma_f32_probe.txt 2>&1
 rm -rf $out/prof $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr
+cp gpurun_out/parity_measured.jsonl $out/ 2>/dev/null
 ls -la $out
