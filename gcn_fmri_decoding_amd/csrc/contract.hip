@@ -862,7 +862,10 @@ static int bw_grid_x(int B, int M) {
     // small launches: at least four chunks per workgroup -- every workgroup leaves a partial of the whole row-tile group
     // (20 KB at five row tiles) that the reduce kernels read back; one chunk per workgroup made the partials of an
     // atlas-sized layer (N = 360, batch 128) 31 MB and reduce_partials_stage1 18 us beside a 38 us kernel
-    if (gx > (total + 3) / 4) gx = (total + 3) / 4;
+#ifndef CG_BWW_MINCHUNK
+#define CG_BWW_MINCHUNK 4
+#endif
+    if (gx > (total + CG_BWW_MINCHUNK - 1) / CG_BWW_MINCHUNK) gx = (total + CG_BWW_MINCHUNK - 1) / CG_BWW_MINCHUNK;
     return gx < 1 ? 1 : gx;
 }
 

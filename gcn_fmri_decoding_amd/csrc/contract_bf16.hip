@@ -458,7 +458,6 @@ contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
     // DMA instruction n = wave + 8u (n < 36) fills ring rows 16n..16n+15: lane l -> row 16n + l/4,
     // position l%4, source piece (l%4) ^ ((row >> 2) & 3) = (l%4) ^ ((l >> 4) & 3) for every n
     const int spiece = (lane & 3) ^ ((lane >> 4) & 3);
-    const int ndma = wave < 4 ? 5 : 4;
     const float* rsrc[5];
 #pragma unroll
     for (int u = 0; u < 5; ++u) {

@@ -176,8 +176,6 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
     std::vector<uint16_t> nodeslot((size_t)Mp + 4, 0xFFFF);
     std::vector<int32_t> order;
     int nslot = 0;
-    int nactive = 0;
-    for (int v = 0; v < M; ++v) nactive += active[v] != 0;
     for (int i = 0; i < 4; ++i)
         for (int v = i; v < M; v += 4)
             if (planes == 2 || active[v]) {

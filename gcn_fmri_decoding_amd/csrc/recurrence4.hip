@@ -40,18 +40,6 @@ extern int g_stagger;
 #ifndef CG_X
 #define CG_X 0               // 64: in-kernel phase stamps (tools/vbuild.sh, tools/kbench.py --stamps); 0 in production
 #endif
-#ifndef CG_SLOT_PREFETCH
-#define CG_SLOT_PREFETCH 0   // 1 (experiment, measured slower): the piece slot ids of ISOREG kernels re-fetched three groups before the end of a gather instead of at the start of a copy-out
-#endif
-#ifndef CG_INTERLEAVE_OUT
-#define CG_INTERLEAVE_OUT 0  // 1 (experiment, measured equal): forward copy-out pieces between the row groups of the gather instead of a burst behind it
-#endif
-#ifndef CG_GATHER_ASM
-// 2 (shipped): C++ gather on the fixed-stride operator image (compile-time record offsets, length classes by scalar tests);
-// 1: the same records gathered by one asm statement per row group with EXEC-masked optional entries (gather12; measured
-//    slower, kept for the experiments of EXPERIMENTS.md); 0: the round-2 gather on the variable-stride image
-#define CG_GATHER_ASM 2
-#endif
 // In-kernel phase stamps (CG_X & 64, tools/xbuild.sh): lane 0 of every wave of workgroup 37 records the
 // cycle counter at the phase boundaries of its SECOND plane group (tools/kbench.py --stamps).
 __device__ long long g_dbg4[16 * 64];
@@ -63,10 +51,10 @@ __device__ long long g_dbg4[16 * 64];
 
 namespace {
 
-constexpr int QMAX = kQuadMin;       // quads stored for every group and requested two groups ahead
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Plane accesses are buffer instructions: the descriptor of one slab (SGPRs), a uniform byte offset
 // (plane + piece, an SGPR) and ONE per-thread offset register (tid * 16) -- no 64-bit per-lane
@@ -124,111 +112,6 @@ __device__ __forceinline__ float4 fma4(float s, const float4& t, const float4& a
 // plane p of the four vertices whose entries are t[0..3]
 __device__ __forceinline__ float4 plane_of_entries(const float4 (&t)[4], int p) {
     return make_float4(comp(t[0], p), comp(t[1], p), comp(t[2], p), comp(t[3], p));
-}
-
-// ---- the gather of one row group as ONE asm statement without control flow (CG_GATHER_ASM) ----------------------
-// Round 3 measurements on the benchmark graph (profiles/r03_recurrence4_gather_ablations.txt): of the 15.5-17.4k cycles a
-// gather step took, LDS reads were 2.8k, the multiply-adds 0.1k, the operator loads 3k -- and 7k were the skeleton around
-// them: per row group six v_readlane (table lookups of {offset, length}) feeding scalar compares, and eight branches (length
-// classes 8 / 10 / 12 / longer, conditional operator requests).  With lengths and offsets known at compile time (wrong
-// results) the same gather ran in 9.0k cycles.  Bank conflicts turned out not to matter (a conflict-free address pattern
-// changed nothing), nor did issuing more than four LDS reads at a time (-12 %).  So the gather is built without control flow:
-//   * the operator image has a FIXED stride per row group (common.h, uval / uids): the offset of a record is a constant
-//     of the group's slot j plus one per-wave base -- no table lookups;
-//   * rows are sorted by length, so the slots of a wave are [nB groups beyond 10 entries | up to nA beyond 8 | the rest];
-//     entries 8..9 and 10..11 of every group are gathered under an EXEC mask derived from j < nA, j < nB with two scalar
-//     instructions (s_cmp + s_cselect into exec): an inactive part costs its issue slots, never a branch;
-//   * the only branches left are the two scalar-only tests that skip the optional operator requests two groups ahead, and
-//     the tail of rows longer than 12 entries in the first slots.
-// The statement issues the eight reads of quads 0 and 1, consumes the first quad, sends the masked reads of entries 8..11
-// into the freed registers and finishes behind counted `s_waitcnt lgkmcnt(n)`; nothing is in flight when it ends (hipcc
-// neither counts nor moves these loads, cdna_hip_programming.md 5.7).  The thresholds behind the masked reads are the
-// ones that are safe whether or not the hardware counts a read issued with EXEC = 0.  The 16-byte results live in a fixed
-// block of registers (v[224:255], named in the clobber list): an asm operand cannot name the halves of a 128-bit tuple, and
-// v_pk_fma_f32 wants them (planes 0-1 / 2-3 of one entry).  The address of a read is computed into the first register of
-// its own destination.  A scalar of a value pair is broadcast with op_sel (low dword) / op_sel + op_sel_hi (high dword) --
-// hipcc copies the odd components to an even register first.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// slot n of the register block: the 16-byte result (R), its halves (L = planes 0-1, H = planes 2-3), its first register (A)
-#define CG_R0 "v[224:227]"
-#define CG_L0 "v[224:225]"
-#define CG_H0 "v[226:227]"
-#define CG_A0 "v224"
-#define CG_R1 "v[228:231]"
-#define CG_L1 "v[228:229]"
-#define CG_H1 "v[230:231]"
-#define CG_A1 "v228"
-#define CG_R2 "v[232:235]"
-#define CG_L2 "v[232:233]"
-#define CG_H2 "v[234:235]"
-#define CG_A2 "v232"
-#define CG_R3 "v[236:239]"
-#define CG_L3 "v[236:237]"
-#define CG_H3 "v[238:239]"
-#define CG_A3 "v236"
-#define CG_R4 "v[240:243]"
-#define CG_L4 "v[240:241]"
-#define CG_H4 "v[242:243]"
-#define CG_A4 "v240"
-#define CG_R5 "v[244:247]"
-#define CG_L5 "v[244:245]"
-#define CG_H5 "v[246:247]"
-#define CG_A5 "v244"
-#define CG_R6 "v[248:251]"
-#define CG_L6 "v[248:249]"
-#define CG_H6 "v[250:251]"
-#define CG_A6 "v248"
-#define CG_R7 "v[252:255]"
-#define CG_L7 "v[252:253]"
-#define CG_H7 "v[254:255]"
-#define CG_A7 "v252"
-// address of the entry named by the low / high 16 bits of id register c into slot n, and its read
-#define CG_RDLO(n, c) "v_lshlrev_b32_sdwa " CG_A##n ", 4, " c " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\tds_read_b128 " CG_R##n ", " CG_A##n "\n\t"
-#define CG_RDHI(n, c) "v_lshlrev_b32_sdwa " CG_A##n ", 4, " c " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\tds_read_b128 " CG_R##n ", " CG_A##n "\n\t"
-#define CG_W(n) "s_waitcnt lgkmcnt(" #n ")\n\t"
-// acc (+)= v.lo * slot n / v.hi * slot n for both plane pairs; F0 starts the sums
-#define CG_F0(n, v) "v_pk_fma_f32 %[a01], " v ", " CG_L##n ", 0 op_sel_hi:[0,1,0]\n\tv_pk_fma_f32 %[a23], " v ", " CG_H##n ", 0 op_sel_hi:[0,1,0]\n\t"
-#define CG_FL(n, v) "v_pk_fma_f32 %[a01], " v ", " CG_L##n ", %[a01] op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %[a23], " v ", " CG_H##n ", %[a23] op_sel_hi:[0,1,1]\n\t"
-#define CG_FH(n, v) "v_pk_fma_f32 %[a01], " v ", " CG_L##n ", %[a01] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %[a23], " v ", " CG_H##n ", %[a23] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-// EXEC = all lanes if the scalar n is greater than the constant slot number, else none
-#ifndef CG_UNIFORM12
-#define CG_UNIFORM12 0             // 1: entries 8..11 of every group are gathered (zero padded) and requested: no masks, no branches
-#endif
-#if CG_UNIFORM12
-#define CG_MASK(n) ""
-#define CG_UNMASK ""
-#else
-#define CG_MASK(n) "s_cmp_gt_u32 " n ", %[slot]\n\ts_cselect_b64 exec, -1, 0\n\t"
-#define CG_UNMASK "s_mov_b64 exec, -1\n\t"
-#endif
-#define CG_GATHER_CLOBBERS                                                                                                 \
-    "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238",   \
-        "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252",       \
-        "v253", "v254", "v255", "scc"
-
-// Sum over the first 12 entries of the row of every lane: ids / values of quads 0 and 1 (c0..c3, v0, v1), entries 8..9
-// (values v2xy, ids c4) for slots below nA, entries 10..11 (values v3xy, ids c5) for slots below nB.
-template <int SLOT>
-__device__ __forceinline__ float4 gather12(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned c4, unsigned c5, f32x2 v0xy,
-                                           f32x2 v0zw, f32x2 v1xy, f32x2 v1zw, f32x2 v2xy, f32x2 v3xy, int nA, int nB) {
-    f32x2 a01, a23;
-    asm volatile(
-        CG_RDLO(0, "%[c0]") CG_RDHI(1, "%[c0]") CG_RDLO(2, "%[c1]") CG_RDHI(3, "%[c1]") CG_RDLO(4, "%[c2]") CG_RDHI(5, "%[c2]")
-            CG_RDLO(6, "%[c3]") CG_RDHI(7, "%[c3]")
-        CG_W(7) CG_F0(0, "%[v0xy]") CG_W(6) CG_FH(1, "%[v0xy]") CG_W(5) CG_FL(2, "%[v0zw]") CG_W(4) CG_FH(3, "%[v0zw]")
-#if !(CG_X & 8192)
-        CG_MASK("%[nA]") CG_RDLO(0, "%[c4]") CG_RDHI(1, "%[c4]") CG_MASK("%[nB]") CG_RDLO(2, "%[c5]") CG_RDHI(3, "%[c5]") CG_UNMASK
-#endif
-        // (reads issued with EXEC = 0 may or may not be counted: 3 = the reads certainly behind slot 4, and so on)
-        CG_W(3) CG_FL(4, "%[v1xy]") CG_W(2) CG_FH(5, "%[v1xy]") CG_W(1) CG_FL(6, "%[v1zw]") CG_W(0) CG_FH(7, "%[v1zw]")
-#if !(CG_X & 8192)
-        CG_MASK("%[nA]") CG_FL(0, "%[v2xy]") CG_FH(1, "%[v2xy]") CG_MASK("%[nB]") CG_FL(2, "%[v3xy]") CG_FH(3, "%[v3xy]") CG_UNMASK
-#endif
-        : [a01] "=&v"(a01), [a23] "=&v"(a23)
-        : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4), [c5] "v"(c5), [v0xy] "v"(v0xy), [v0zw] "v"(v0zw),
-          [v1xy] "v"(v1xy), [v1zw] "v"(v1zw), [v2xy] "v"(v2xy), [v3xy] "v"(v3xy), [nA] "s"(nA), [nB] "s"(nB), [slot] "i"(SLOT)
-        : CG_GATHER_CLOBBERS);
-    return make_float4(a01.x, a01.y, a23.x, a23.y);
 }
 
 // compile-time loop: f(std::integral_constant<int, J>) for J = FIRST .. LAST-1 (the slot number of a row group must be a
@@ -313,13 +196,11 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     if (lane < NJ && lane * NW4 + wave < e.ngroups) gtab = e.ginfo[lane * NW4 + wave];
     // slots of this wave are sorted by length: the first nB have more than 10 entries, the first nA more than 8; bit j of
     // mC: slot j has more than 12 (uniform values: SGPRs)
-    const int nA = (CG_X & 32768) ? (int)(flags >> 30) : __popcll(__ballot(lane < NJ && gtab.y > 8));       // (32768: timing experiment)
-    const int nB = (CG_X & 32768) ? (int)(flags >> 30) : __popcll(__ballot(lane < NJ && gtab.y > 10));
-    const unsigned mC = (CG_X & 32768) ? 0u : (unsigned)__ballot(lane < NJ && gtab.y > 12);
+    const int nA = __popcll(__ballot(lane < NJ && gtab.y > 8));
+    const int nB = __popcll(__ballot(lane < NJ && gtab.y > 10));
+    const unsigned mC = (unsigned)__ballot(lane < NJ && gtab.y > 12);
     const __amdgpu_buffer_rsrc_t uval_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.uval, 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t uids_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.uids, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t colo_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.colo, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t valq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)e.valp, 0, 0x7FFFFFFF, 0x00020000);
     if (tid == 0) T[zslot] = zero4;                  // never written again
     {   // one-off stagger of the workgroups of an XCD (see recurrence.hip)
         const int gpw = (ngrp + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -417,7 +298,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
     // a vertex without a slot: pads and isolated vertices).  ISOREG: iso_sign = what an isolated vertex holds in this slab
     // relative to x (0 in odd slabs -- what the zero slot gave anyway --, -1 / +1 in even ones).
     auto copy_out = [&](rsrc_t out, int g, int u0, int u1, float iso_sign = 0.f) __attribute__((always_inline)) {
-        if (ISOREG && !CG_SLOT_PREFETCH && u0 == 0) reload_piece_slots();
+        if (ISOREG && u0 == 0) reload_piece_slots();
 #pragma unroll
         for (int u = u0; u < u1; ++u) {
             const int q = tid + u * NT4;
@@ -683,8 +564,7 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
             const bool do_out = !ADJ && step > 1;
             const rsrc_t out_slab = slab_rsrc(dst + (size_t)(step - 1) * slab, slab_bytes);
 
-#if CG_GATHER_ASM
-            // ---- gather: st <- f * (A T_{k-1})[own rows] - st, without control flow (see gather12) ----------
+            // ---- gather: st <- f * (A T_{k-1})[own rows] - st -----------------------------------------------
             // Operator records of slot j (group j*NW4 + wave) sit at compile-time offsets behind one per-wave base; they
             // travel through a ring two slots deep: values of quads 0 / 1, the record of entries 8..11, the eight ids of
             // quads 0 and 1.  The two optional requests are skipped by scalar-only tests (j is a constant, nA / nB SGPRs).
@@ -702,11 +582,11 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 uq[0][j & 1] = make_float4(a.x, a.y, a.z, a.w);
                 uq[1][j & 1] = make_float4(b.x, b.y, b.z, b.w);
                 uo[j & 1] = make_uint4(c.x, c.y, c.z, c.w);
-                if (CG_UNIFORM12 || (!(CG_X & 16384) && j < opaque_s(nA))) {
+                if (j < opaque_s(nA)) {
                     const f32x4 d = __builtin_amdgcn_raw_buffer_load_b128(uval_rsrc, lane * 16, vs + (vo + 2048u), 0);
                     uq[2][j & 1] = make_float4(d.x, d.y, d.z, d.w);
                 }
-                if (CG_UNIFORM12 || (!(CG_X & 16384) && __builtin_expect(j < opaque_s(nB), 0))) {
+                if (__builtin_expect(j < opaque_s(nB), 0)) {
                     const f32x2 h = __builtin_amdgcn_raw_buffer_load_b64(uval_rsrc, lane * 16, vs + (vo + 3072u), 0);
                     ub[j & 1] = make_float2(h.x, h.y);
                 }
@@ -734,41 +614,6 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                 const uint4 o01 = uo[j & 1];
                 const float4 v0 = uq[0][j & 1], v1 = uq[1][j & 1], v2 = uq[2][j & 1];
                 const float2 v3 = ub[j & 1];
-                const f32x2 v0xy = {v0.x, v0.y}, v0zw = {v0.z, v0.w}, v1xy = {v1.x, v1.y}, v1zw = {v1.z, v1.w};
-                const f32x2 v2xy = {v2.x, v2.y}, v3xy = {v3.x, v3.y};
-#if CG_GATHER_ASM == 3
-                // C++ gather with every LDS read of the group issued before the first multiply-add: the scheduling barrier
-                // keeps hipcc from sinking the second quad's reads behind the first quad's arithmetic (it does, to save
-                // registers: four reads in flight per wave instead of eight)
-                float4 acc = zero4;
-                {
-                    const unsigned a0 = ofs_lo(o01.x), a1 = ofs_hi(o01.x), a2 = ofs_lo(o01.y), a3 = ofs_hi(o01.y);
-                    const unsigned a4 = ofs_lo(o01.z), a5 = ofs_hi(o01.z), a6 = ofs_lo(o01.w), a7 = ofs_hi(o01.w);
-                    const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3), t4 = lds(a4), t5 = lds(a5), t6 = lds(a6), t7 = lds(a7);
-                    if (j < opaque_s(nA)) {
-                        const unsigned c4 = __float_as_uint(v2.z);
-                        const float4 t8 = lds(ofs_lo(c4)), t9 = lds(ofs_hi(c4));
-                        if (j < opaque_s(nB)) {
-                            const unsigned c5 = __float_as_uint(v2.w);
-                            const float4 t10 = lds(ofs_lo(c5)), t11 = lds(ofs_hi(c5));
-                            __builtin_amdgcn_sched_barrier(0);
-                            acc = fma4(v0.x, t0, acc); acc = fma4(v0.y, t1, acc); acc = fma4(v0.z, t2, acc); acc = fma4(v0.w, t3, acc);
-                            acc = fma4(v1.x, t4, acc); acc = fma4(v1.y, t5, acc); acc = fma4(v1.z, t6, acc); acc = fma4(v1.w, t7, acc);
-                            acc = fma4(v2.x, t8, acc); acc = fma4(v2.y, t9, acc); acc = fma4(v3.x, t10, acc); acc = fma4(v3.y, t11, acc);
-                        } else {
-                            __builtin_amdgcn_sched_barrier(0);
-                            acc = fma4(v0.x, t0, acc); acc = fma4(v0.y, t1, acc); acc = fma4(v0.z, t2, acc); acc = fma4(v0.w, t3, acc);
-                            acc = fma4(v1.x, t4, acc); acc = fma4(v1.y, t5, acc); acc = fma4(v1.z, t6, acc); acc = fma4(v1.w, t7, acc);
-                            acc = fma4(v2.x, t8, acc); acc = fma4(v2.y, t9, acc);
-                        }
-                    } else {
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc = fma4(v0.x, t0, acc); acc = fma4(v0.y, t1, acc); acc = fma4(v0.z, t2, acc); acc = fma4(v0.w, t3, acc);
-                        acc = fma4(v1.x, t4, acc); acc = fma4(v1.y, t5, acc); acc = fma4(v1.z, t6, acc); acc = fma4(v1.w, t7, acc);
-                    }
-                }
-                (void)v0xy; (void)v0zw; (void)v1xy; (void)v1zw; (void)v2xy; (void)v3xy;
-#elif CG_GATHER_ASM == 2
                 // the same records gathered by compiler-scheduled C++ (no fixed register block): length classes chosen by
                 // scalar-only tests of the slot number against nA / nB
                 float4 acc = zero4;
@@ -786,28 +631,9 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                         acc = fma4(v3.y, t3, acc);
                     }
                 }
-                (void)v0xy; (void)v0zw; (void)v1xy; (void)v1zw; (void)v2xy; (void)v3xy;
-#else
-                float4 acc = gather12<j>(o01.x, o01.y, o01.z, o01.w, __float_as_uint(v2.z), __float_as_uint(v2.w), v0xy, v0zw, v1xy,
-                                         v1zw, v2xy, v3xy, nA, nB);
-#endif
                 if constexpr (j + 2 < NJ) urequest(std::integral_constant<int, j + 2>{});      // refill the ring slots just consumed
-                // (ISOREG) the slot ids of the linear pieces for the phases behind this gather, requested three groups early
-                if constexpr (ISOREG && CG_SLOT_PREFETCH && j == (NJ > 3 ? NJ - 3 : 0)) reload_piece_slots();
                 st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
                                     fmaf(f, acc.w, -st[j].w));
-#if CG_INTERLEAVE_OUT
-                // forward: the slab the gather reads (step - 1) goes out piece by piece BETWEEN the row groups instead of in
-                // one burst behind them: a burst of 168 KB of stores drains at the CU's share of HBM bandwidth (~12 B/clk)
-                // and everything queued behind it in the CU's in-order memory pipeline -- the operator requests of the next
-                // gather, the loads of the turn-over -- waits for that (measured: 16-20k cycles to ISSUE the turn-over's
-                // loads, the first gather of a group 7k slower than the others)
-                if constexpr (!ADJ) {
-                    constexpr int u = (2 * NQ * j + NQ) / (2 * NJ);              // piece whose turn comes at this slot
-                    if constexpr (u < NQ && ((2 * u + 1) * NJ) / (2 * NQ) == j)
-                        if (do_out) copy_out(out_slab, grp, u, u + 1, slab_iso_sign(step - 1));
-                }
-#endif
             });
             // Rows beyond 12 entries (rare; rows are sorted, so they sit in the first slots of a wave): the sum over their
             // further quads, from the variable-stride image the round-2 way, is added afterwards -- st = f * (sum) - st_old
@@ -827,104 +653,11 @@ cheb4_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, 
                     }
                 });
             }
-#else
-            // ---- gather: st <- f * (A T_{k-1})[own rows] - st -----------------------------------
-            // Operator entries travel through a ring of RING quads (4 entries of each of the 64 rows):
-            // every group stores QMAX zero-padded quads, quad n = QMAX*j + q lives in ring slot
-            // n % RING and is requested two groups before it is gathered.  The slot ids come eight
-            // per lane and record (one 16-byte load per two quads); a third quad of at most two
-            // entries carries its ids in the unused half of its value record (graph.hip).
-            constexpr int RING = 2 * QMAX;
-            constexpr int QO = (QMAX + 1) / 2;
-            constexpr int ORING = 2 * QO;
-            uint4 ro[ORING];
-            float4 rv[RING];
-            auto group_info = [&](int j, int& qoff, int& len) {
-                qoff = __builtin_amdgcn_readlane(gtab.x, j);
-                len = __builtin_amdgcn_readlane(gtab.y, j);
-            };
-            auto request_ids = [&](int j, int o) {
-                int qoff, len;
-                group_info(j, qoff, len);
-                if (o >= 1 && len <= 10) return;               // the second record only beyond 10 entries
-                const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(colo_rsrc, lane * 16, ((qoff >> 1) + o) * 1024, 0);
-                ro[(QO * j + o) % ORING] = make_uint4(c.x, c.y, c.z, c.w);
-            };
-            auto request = [&](int j, int q) {
-                int qoff, len;
-                group_info(j, qoff, len);
-                if (q >= 2 && len <= 8) return;                // the third quad only where a row needs it
-                const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(valq_rsrc, lane * 16, (qoff + q) * 1024, 0);
-                rv[(QMAX * j + q) % RING] = make_float4(v.x, v.y, v.z, v.w);
-            };
-            auto ids_of = [&](int j, int q) {
-                const uint4 o = ro[(QO * j + (q >> 1)) % ORING];
-                return (q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y);
-            };
-            auto pair = [&](const unsigned c, const float v0, const float v1, float4& acc) {
-                const float4 t0 = lds(ofs_lo(c)), t1 = lds(ofs_hi(c));
-                acc = fma4(v0, t0, acc);
-                acc = fma4(v1, t1, acc);
-            };
-            auto quad = [&](const uint2 c, const float4 v, float4& acc) {
-                const unsigned a0 = ofs_lo(c.x), a1 = ofs_hi(c.x), a2 = ofs_lo(c.y), a3 = ofs_hi(c.y);
-                const float4 t0 = lds(a0), t1 = lds(a1), t2 = lds(a2), t3 = lds(a3);
-                acc = fma4(v.x, t0, acc);
-                acc = fma4(v.y, t1, acc);
-                acc = fma4(v.z, t2, acc);
-                acc = fma4(v.w, t3, acc);
-            };
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-                for (int o = 0; o < QO; ++o) request_ids(jj, o);
-#pragma unroll
-                for (int q = 0; q < QMAX; ++q) request(jj, q);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                // waves that are ahead yield to the ones behind (see recurrence.hip)
-                if (j == 0 || (4 * j) / NJ != (4 * (j - 1)) / NJ) {
-                    const int pr = 3 - (4 * j) / NJ;
-                    if (pr == 3) __builtin_amdgcn_s_setprio(3);
-                    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-                    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
-                }
-                int qoff, len;
-                group_info(j, qoff, len);
-                float4 acc = zero4;
-#pragma unroll
-                for (int q = 0; q < QMAX; ++q) {
-                    // the first two quads always (zero-padded), the third for rows beyond 8 entries
-                    // (ring values pass through an opaque identity at their use: otherwise hipcc hoists a copy
-                    // of a component into the block of the conditional request, with `s_waitcnt vmcnt(0)` right
-                    // behind the load -- see recurrence.hip)
-                    if (q == 2 && len > 8 && len <= 10) {
-                        const float4 v = opaque(rv[(QMAX * j + q) % RING]);
-                        pair(__float_as_uint(v.z), v.x, v.y, acc);
-                    } else if (q < 2 || len > 10) quad(ids_of(j, q), opaque(rv[(QMAX * j + q) % RING]), acc);
-                    if (j + 2 < NJ) {
-                        request(j + 2, q);                       // refill the slots just consumed
-                        if ((q & 1) || q == QMAX - 1) request_ids(j + 2, q >> 1);
-                    }
-                }
-                if (len > 4 * QMAX) {
-                    for (int q = QMAX; 4 * q < len; ++q) {       // rows longer than 4*QMAX entries (rare)
-                        const uint4 o = e.colo[(size_t)((qoff >> 1) + (q >> 1)) * 64 + lane];
-                        const float4 v = e.valq[(size_t)(qoff + q) * 64 + lane];
-                        quad((q & 1) ? make_uint2(o.z, o.w) : make_uint2(o.x, o.y), v, acc);
-                    }
-                }
-                st[j] = make_float4(fmaf(f, acc.x, -st[j].x), fmaf(f, acc.y, -st[j].y), fmaf(f, acc.z, -st[j].z),
-                                    fmaf(f, acc.w, -st[j].w));
-            }
-#endif
             CG_STAMP(24 + step);
             // forward: slab step-1 (the image the gather just read) goes out now, before the barrier --
             // waves that finish their rows early stream while the others still gather; kept out of the
             // gather loop: its 40-odd temporaries do not fit next to the row state and the operator ring
-            if (do_out && !(CG_GATHER_ASM && CG_INTERLEAVE_OUT)) copy_out(out_slab, grp, 0, NQ, slab_iso_sign(step - 1));
+            if (do_out) copy_out(out_slab, grp, 0, NQ, slab_iso_sign(step - 1));
         }
         finish_step(K - 1, true);
         // ---- the final image goes out, the next group's input comes in -------------------------

@@ -17,6 +17,13 @@ python3 tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --kernels contract_fwd 
 bash tools/pmc_traffic.sh refresh > $out/traffic.log 2>&1
 cp gpurun_out/traffic_refresh/traffic_raw.json $out/ 2>/dev/null
 bash tools/pmc_mfma.sh refresh > $out/mfma.txt 2>&1
+# the ordered recurrence kernels: SQ instruction / wait / LDS counters at the north-star shape and at the batch of the bench
+# step, and the in-kernel phase stamps of one plane group (build_x/libchebgcn_x64.so: tools/xbuild.sh 64)
+bash tools/pmc_sq.sh refresh_ord --B 256 --iters 3 --kernels recurrence_fwd_inplace recurrence_bwd > $out/recurrence_ord_sq_counters.txt 2>&1
+if [ -f build_x/libchebgcn_x64.so ]; then
+  CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_x64.so python3 tools/kbench.py --B 256 --kernels recurrence_fwd_inplace recurrence_bwd --stamps > $out/stampso.txt 2>&1
+fi
+python3 tools/fused_check.py > $out/fused_small_check.txt 2>&1
 cp gpurun_out/pmcmfma_refresh/available.txt $out/mfma_counters_available.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-windows 0 --kernel-legs 0 > $out/prof.log 2>&1
