@@ -289,13 +289,14 @@ def fit_leg(dev, L, cfg, batch, n_train, n_val, epochs, tag):
     with tempfile.TemporaryDirectory() as tmp:
         os.environ['CHEBGCN_HOME'] = tmp
         try:
-            for mode in ('staged', 'numpy_float64'):
+            for mode in ('warmup', 'numpy_float64', 'staged'):
                 torch.manual_seed(0)
                 np.random.seed(0)
                 net = models_gcn.cgcnn({'device': dev}, [L] * len(cfg['F']), cfg['F'], cfg['K'], cfg['p'], cfg['M'],
                                        filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he', channel=cfg['channel'],
                                        regularization=5e-4, dropout=0.5, batch_size=batch, learning_rate=0.001, decay_rate=0.9,
-                                       momentum=0.9, num_epochs=epochs, eval_frequency=steps, dir_name='bench_fit',
+                                       momentum=0.9, num_epochs=epochs if mode != 'warmup' else max(1, epochs // 8),
+                                       eval_frequency=steps, dir_name='bench_fit',
                                        verbose=False)
                 t0 = time.perf_counter()
                 a, b = (net.stage(train), net.stage(val)) if mode == 'staged' else (train, val)
@@ -303,6 +304,9 @@ def fit_leg(dev, L, cfg, batch, n_train, n_val, epochs, tag):
                 t_stage = time.perf_counter() - t0
                 with contextlib.redirect_stdout(io.StringIO()):
                     _, _, t_step = net.fit(a, tl, b, vl)
+                if mode == 'warmup':                        # (first use of this shape: library and allocator warm-up, not reported)
+                    del net, a, b
+                    continue
                 out[mode] = {'t_step_ms': 1e3 * t_step, 'windows_per_s': batch / t_step}
                 if mode == 'staged':
                     out[mode]['staging_ms_outside_fit'] = 1e3 * t_stage
