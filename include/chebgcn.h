@@ -89,7 +89,11 @@ void chebgcn_graph_destroy(chebgcn_graph* g);
  * kernel is used for this graph, 4 = padded ELL slots of L~, 5 = max row length,
  * 6 = planes per workgroup (0, 2, 4), 7 = rows held in the LDS image, 8 = LDS bytes of the
  * image, 9 / 10 / 11 = modelled LDS cycles of one gather pass in the caller's entry order /
- * after the library's bank-aware placement / without any conflict. */
+ * after the library's bank-aware placement / without any conflict, 12 = 1 if the handle carries
+ * the ORDERED operator image: the rows of the caller's matrix are sorted by descending length
+ * (isolated vertices last) and the graph was created with planes = 0 -- recurrence launches then
+ * run the kernel that moves planes between HBM and registers directly (csrc/recurrence_ord.hip);
+ * 13 / 14 / 15 = items 9 / 10 / 11 for that image. */
 int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* value);
 
 /* ---- Chebyshev recurrence, forward: models_gcn.py:598-610 -----------------------
