@@ -21,6 +21,8 @@
 // no LDS staging, no transpose.  The four waves of a workgroup read the same rows at the same
 // time (L1 hits); the A operand comes from a bf16 image of W packed once per call in fragment
 // order (16 B per lane and tile), resident in L2.
+#include <type_traits>
+
 #include "contract_common.h"
 
 namespace chebgcn {
@@ -52,40 +54,76 @@ pack_w_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ Wp, int Fin
 // Operand pipeline.  Both operands of a k-step travel by LDS-DMA (global_load_lds, 16 B per lane,
 // no register round trip) into a ring of stages in LDS:
 //   stage = [16 rows][128 vertices] fp32 of the stack (8 KB) + PARTS x [256 filters][16] bf16 of W (8 KB each).
-// The four waves split every stage between them (2 + 2*PARTS wave instructions each), so what is
-// in flight per CU is DEPTH *distinct* stages -- with register prefetch the four waves of a
+// What is in flight per CU is DEPTH *distinct* stages -- with register prefetch the waves of a
 // workgroup would all request the same rows and only one wave's worth of bytes would be in the
-// air.  Every vector-memory operation of the main loop is such a DMA issued DEPTH steps ahead:
+// air.  Every vector-memory operation of a producer wave is such a DMA issued DEPTH steps ahead:
 // the queue returns in order, so a short L2 load between them would wait for the HBM ones.
-// Hand-placed waits: the wave's own DMAs of the step about to be consumed are DEPTH*NDMA
+// Hand-placed waits: a producer's own DMAs of the step about to be consumed are DEPTH*NDMA
 // operations old (s_waitcnt vmcnt(DEPTH*NDMA)), a barrier WITHOUT a fence (the fence would
 // drain the queue) publishes them, and the operands are read with ds_read_b128 in one asm
 // block (compiler-visible LDS reads would be ordered behind every DMA in flight).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// NW = waves per workgroup = 64-filter slices per work item: 4 (256 filters), or 5 (320) where that pads the
+// NW = compute waves per workgroup = 64-filter slices per work item: 4 (256 filters), or 5 (320) where that pads the
 // filter count less -- the gradient wrt the stack at config 5 has 300 "filters" (rows Fin*K): one group of 320
-// instead of two of 256.  The fifth wave takes no part in the stack DMA (16 rows = 4 waves x 4).
+// instead of two of 256.
 #ifndef CG_BF16_XCD
 #define CG_BF16_XCD 1
 #endif
-template <int PASSES, int NW>
+#ifndef CG_X
+#define CG_X 0               // 64: in-kernel phase stamps (tools/bbuild.sh, tools/kbench.py --stamps); 0 in production
+#endif
+__device__ long long g_dbgb[16 * 64];
+// third item of workgroup 37: compute waves stamp id = k-step (after its barrier), 40 = k-loop done, 41.. = bias steps, 50 = epilogue
+// done; producer waves stamp id = stage of the item (after its vmcnt wait)
+#define CG_BSTAMP(cond, id)                                                                                   \
+    do {                                                                                                      \
+        if ((CG_X & 64) && (cond) && (id) < 64 && lane == 0 && blockIdx.x == 37)                              \
+            g_dbgb[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();                               \
+    } while (0)
+// Who issues the DMAs.  Vector-memory operations of a wave complete IN ORDER and s_waitcnt vmcnt counts loads and stores
+// alike: when the waves that multiply also issued the DMAs, the first k-step of an item waited for the 32 result stores of the
+// previous item's epilogue to be acknowledged by memory before it could see its operands, with nothing else in flight (timing
+// experiment without the epilogue: config 5 forward 0.42 -> 0.21 ms, gradient wrt the stack 0.40 -> 0.20 ms).  So the DMAs
+// belong to TWO PRODUCER WAVES (waves NW and NW + 1) that never store: they run the operand ring DEPTH stages ahead, wait for
+// their own DMAs with vmcnt and release the NW compute waves through the workgroup barrier; the compute waves never wait on
+// vmcnt in the main loop and their stores drain behind the next item's matrix work.  Two producers because vmcnt is a 6-bit
+// counter: DEPTH stages x the DMA instructions of a stage must stay below 64 per wave.
+// Producer 0 issues what compute waves 0, 1 (and 4: packed W only) used to issue, producer 1 those of waves 2, 3.
+//
+// X16: the reduction rows arrive as bf16 planes (the gradient wrt the stack reading the dy that chebgcn_relu_grad_bf16 wrote):
+// a stage holds [16 rows][128 vertices] bf16 (4 KB, one DMA instruction per four rows), lane (c, g) reads the four vertices
+// 4c..4c+3 of its eight rows with ds_read_b64 and transposes 8 x 4 halves into the four operands with v_perm_b32 (as many
+// instructions as the fp32 -> bf16 conversions they replace).
+template <int PASSES, int NW, bool X16 = false>
 struct Bf16Cfg {
     static constexpr int PARTS = PASSES == 3 ? 2 : 1;
     static constexpr int WPART = NW * 64 * 32;                    // bytes of one bf16 image of W per stage
-    static constexpr int STAGE = 8192 + PARTS * WPART;            // bytes
-    static constexpr int NSTAGE = (147456 / STAGE);               // 9 / 6 stages (NW = 4), 8 / 5 (NW = 5): <= 144 KB
-    static constexpr int DEPTH = NSTAGE - 2;
-    static constexpr int NDMA = 2 + 2 * PARTS;                    // wave instructions per wave and stage (waves 0..3)
-    static constexpr int NDMA_W = 2 * PARTS;                      // ... of the fifth wave
+    static constexpr int XPART = X16 ? 4096 : 8192;               // bytes of the reduction rows per stage
+    static constexpr int STAGE = XPART + PARTS * WPART;           // bytes
+    static constexpr int NSTAGE = (147456 / STAGE);               // <= 144 KB
+    static constexpr int NXDMA = X16 ? 1 : 2;                     // DMA instructions of the reduction rows per four rows and stage
+    static constexpr int NDMA1 = 2 * (NXDMA + 2 * PARTS);         // DMA instructions per stage of producer 1
+    static constexpr int NDMA0 = NDMA1 + (NW > 4 ? 2 * PARTS : 0);    // ... of producer 0
+    static constexpr int DEPTH = (NSTAGE - 2) < 63 / NDMA0 ? (NSTAGE - 2) : 63 / NDMA0;
+    static_assert(DEPTH >= 2 && DEPTH * NDMA0 <= 63, "vmcnt is a 6-bit counter");
+    // A per-vertex bias (b2relu: [Fout][Mp], as large as the result) travels through the SAME ring: after the k-steps of an
+    // item come BIAS_STEPS stages of [wave][8 rows][128 vertices] fp32 -- for compute wave w the rows 32t + acc_row(4i..4i+3, g)
+    // of its slice at step 4t + i -- which the compute waves add to their accumulators row by row as they store them.  No compute
+    // wave loads anything from memory: the epilogue used to pay a round trip per batch of rows (config 5 forward: 8 per item).
+    // A stage must be the same number of DMA instructions whatever it carries (the vmcnt waits are constants): 8 per
+    // producer for the bias (2 waves x 8 rows x 512 B), padded with re-reads to NDMA1.  Four compute waves only.
+    static constexpr bool RING_BIAS = NW == 4 && !X16 && NDMA1 >= 8;
+    static constexpr int BIAS_STEPS = 8;
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int PASSES, int NW>
-__global__ void __launch_bounds__(NW * 64)
+template <int PASSES, int NW, bool X16 = false>
+__global__ void __launch_bounds__((NW + 2) * 64)
 contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int FoutP, int ntm, int nitems) {
-    using C = Bf16Cfg<PASSES, NW>;
+    static_assert(!X16 || PASSES == 1, "bf16 rows have no low part");
+    using C = Bf16Cfg<PASSES, NW, X16>;
     extern __shared__ __attribute__((aligned(16))) char ring[];         // [NSTAGE][STAGE]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -106,66 +144,120 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
     auto item_b = [&](int it) { return (it / ntx) % a.B; };
     auto item_z = [&](int it) { return it / ntx / a.B; };
 
-    // ---- producer state: the step DEPTH ahead of the consumer -----------------------------------
-    // Kept incremental -- with one wave per SIMD every instruction of the loop is on the critical
-    // path: the item is decomposed once per item, the plane of reduction row r = 16*ks + row
-    // (row = 4*wave + 2q + (lane >> 5) for DMA instruction q) advances by 16 rows per step.
-    int p_it = lw, p_ks = 0;
-    const int s16f = 16 / a.K, s16k = 16 % a.K;
-    int pf[2], pk[2];
-    const float* p_base;                                           // window + vertex part of the source address
-    const __bf16* p_w;                                             // this lane's 16 bytes of the packed W, k-step 0
-    auto producer_item = [&]() {
-        int m = item_mt(p_it) * 128 + 4 * c;
-        if (m >= a.Mp) m = 0;                                      // beyond the plane: any readable address, never stored
-        p_base = a.stack + (size_t)item_b(p_it) * a.Fin * a.Mp + m;
-        p_w = Wp + (size_t)item_z(p_it) * (NW * 64) * 16 + (size_t)wave * 1024 + lane * 8;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int row = 4 * wave + 2 * q + g;
-            pf[q] = row / a.K;
-            pk[q] = row - pf[q] * a.K;
-        }
-    };
-    producer_item();
-    const size_t w_step = (size_t)FoutP * 16;                      // bf16 elements per k-step of the packed W
-    auto produce = [&](int slot) {
-        const unsigned stage = (unsigned)(size_t)ring + slot * C::STAGE;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (NW > 4 && wave >= 4) break;                           // the stack rows belong to the first four waves
-            // rows beyond Fin*K re-read the last plane (finite data) against zero weights
-            const bool live = pf[q] < a.Fin;
-            const int fin = live ? pf[q] : a.Fin - 1, k = live ? pk[q] : a.K - 1;
-            const float* src = p_base + (size_t)k * a.slab + (size_t)fin * a.Mp;
-            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                                                      stage + (4 * wave + 2 * q) * 512), 16, 0, 0);
-            pk[q] += s16k;
-            pf[q] += s16f;
-            if (pk[q] >= a.K) { pk[q] -= a.K; ++pf[q]; }
-        }
-#pragma unroll
-        for (int part = 0; part < C::PARTS; ++part)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                __builtin_amdgcn_global_load_lds(p_w + part * lo_part + q * 512,
-                                                 reinterpret_cast<__attribute__((address_space(3))) void*>(
-                                                     stage + 8192 + part * C::WPART + wave * 2048 + q * 1024),
-                                                 16, 0, 0);
-        p_w += w_step;
-        if (++p_ks == nks) {
-            p_ks = 0;
-            if (p_it + Lw < nmine) p_it += Lw;                      // after the last item: harmless re-reads
-            producer_item();
-        }
-    };
-
     if (lw >= nmine) return;
-    int pslot = 0;
+    if (wave >= NW) {
+        // ---- producer waves: the operand ring, DEPTH stages ahead of the consumers ---------------------------------
+        // Incremental addressing: the item is decomposed once per item, the plane of reduction row r = 16*ks + row advances by
+        // 16 rows per step.  Producer pw stands in for the compute waves v = 2 pw, 2 pw + 1 of the original schedule: DMA
+        // instruction q of v covers the rows 4v + 2q + (lane >> 5) (fp32) or 4v + (lane >> 4) (X16).
+        const int pw = wave - NW;
+        int p_it = lw, p_ks = 0;
+        const int nbias = (C::RING_BIAS && a.bias_kind == CHEBGCN_BIAS_VERTEX) ? C::BIAS_STEPS : 0;     // bias stages per item
+        const int s16f = 16 / a.K, s16k = 16 % a.K;
+        int pf[2][2], pk[2][2];
+        const float* p_base;                                       // window + vertex part of the source address
+        const __bf16* p_w;                                         // this lane's 16 bytes of the packed W, k-step 0, wave 0
+        auto producer_item = [&]() {
+            // (X16: addresses in units of float: a bf16 plane is Mp/2 floats long; lane l takes the 16-byte piece l%16 of its row)
+            int m = item_mt(p_it) * 128 + (X16 ? 8 * (lane & 15) : 4 * c);
+            if (m >= a.Mp) m = 0;                                  // beyond the plane: any readable address, never stored
+            p_base = X16 ? a.stack + (((size_t)item_b(p_it) * a.Fin * a.Mp + m) >> 1)
+                         : a.stack + (size_t)item_b(p_it) * a.Fin * a.Mp + m;
+            p_w = Wp + (size_t)item_z(p_it) * (NW * 64) * 16 + lane * 8;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < C::NXDMA; ++q) {
+                    const int v = 2 * pw + j;
+                    const int row = X16 ? 4 * v + (lane >> 4) : 4 * v + 2 * q + g;
+                    pf[j][q] = row / a.K;
+                    pk[j][q] = row - pf[j][q] * a.K;
+                }
+        };
+        producer_item();
+        const size_t w_step = (size_t)FoutP * 16;                  // bf16 elements per k-step of the packed W
+        auto w_dma = [&](unsigned stage, int v) {
+#pragma unroll
+            for (int part = 0; part < C::PARTS; ++part)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    __builtin_amdgcn_global_load_lds(p_w + (size_t)v * 1024 + part * lo_part + q * 512,
+                                                     reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                                         stage + C::XPART + part * C::WPART + v * 2048 + q * 1024),
+                                                     16, 0, 0);
+        };
+        auto produce = [&](int slot) {
+            const unsigned stage = (unsigned)(size_t)ring + slot * C::STAGE;
+            if (C::RING_BIAS && p_ks >= nks) {
+                // bias stage i = p_ks - nks: instruction q of wave part v covers the rows rho = 2q, 2q + 1 (g = rho >> 2,
+                // jj = rho & 3) of [v][8 rows][128 vertices]: filter 64 v + 32 (i >> 2) + acc_row(4 (i & 3) + jj, g)
+                const int i = p_ks - nks;
+                int m = item_mt(p_it) * 128 + 4 * c;
+                if (m >= a.Mp) m = 0;
+#pragma unroll
+                for (int u = 0; u < C::NDMA1; ++u) {
+                    const int uu = u & 7;                          // (beyond 8: padding, re-reads of the first ones into the unused W part)
+                    const int j = uu >> 2, q = uu & 3;
+                    const int v = 2 * pw + j;
+                    const int rho = 2 * q + g;
+                    int fo = item_z(p_it) * (NW * 64) + 64 * v + 32 * (i >> 2) + acc_row(4 * (i & 3) + (rho & 3), rho >> 2);
+                    if (fo >= a.Fout) fo = a.Fout - 1;
+                    __builtin_amdgcn_global_load_lds(a.bias + (size_t)fo * a.Mp + m,
+                                                     reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                                         u < 8 ? stage + v * 4096 + q * 1024 : stage + 16384 + pw * 4096 + q * 1024), 16, 0, 0);
+                }
+                if (++p_ks == nks + nbias) {
+                    p_ks = 0;
+                    if (p_it + Lw < nmine) p_it += Lw;
+                    producer_item();
+                }
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int v = 2 * pw + j;
+#pragma unroll
+                for (int q = 0; q < C::NXDMA; ++q) {
+                    // rows beyond Fin*K re-read the last plane (finite data) against zero weights
+                    const bool live = pf[j][q] < a.Fin;
+                    const int fin = live ? pf[j][q] : a.Fin - 1, k = live ? pk[j][q] : a.K - 1;
+                    const float* src = X16 ? p_base + (((size_t)k * a.slab + (size_t)fin * a.Mp) >> 1)
+                                           : p_base + (size_t)k * a.slab + (size_t)fin * a.Mp;
+                    __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                                              stage + (X16 ? v * 1024 : (4 * v + 2 * q) * 512)), 16, 0, 0);
+                    pk[j][q] += s16k;
+                    pf[j][q] += s16f;
+                    if (pk[j][q] >= a.K) { pk[j][q] -= a.K; ++pf[j][q]; }
+                }
+                w_dma(stage, v);
+            }
+            if (NW > 4 && pw == 0) w_dma(stage, 4);
+            p_w += w_step;
+            if (++p_ks == nks + nbias) {
+                p_ks = 0;
+                if (p_it + Lw < nmine) p_it += Lw;                  // after the last item: harmless re-reads
+                producer_item();
+            }
+        };
+        int pslot = 0;
 #pragma unroll 1
-    for (int d = 0; d < C::DEPTH; ++d) { produce(pslot); pslot = pslot + 1 == C::NSTAGE ? 0 : pslot + 1; }
-    int cslot = 0;
+        for (int d = 0; d < C::DEPTH; ++d) { produce(pslot); pslot = pslot + 1 == C::NSTAGE ? 0 : pslot + 1; }
+        const long long steps = (long long)((nmine - lw + Lw - 1) / Lw) * (nks + nbias);
+#pragma unroll 1
+        for (long long st = 0; st < steps; ++st) {
+            produce(pslot);
+            pslot = pslot + 1 == C::NSTAGE ? 0 : pslot + 1;
+            // this wave's part of the stage about to be consumed has landed ...
+            if (pw == 0) wait_vmcnt<C::DEPTH * C::NDMA0>(); else wait_vmcnt<C::DEPTH * C::NDMA1>();
+            CG_BSTAMP(st / (nks + nbias) == 2, (int)(st % (nks + nbias)));
+            __builtin_amdgcn_s_barrier();                      // ... and the other producer's (no fence: it would drain the queue)
+        }
+        wait_vmcnt<0>();                                           // the run-ahead DMAs of the last item
+        return;
+    }
 
+    // ---- compute waves ------------------------------------------------------------------------------------------------
+    int cslot = 0;
     for (int it = lw; it < nmine; it += Lw) {
         const int fo0 = (item_z(it) * NW + wave) * 64;
         const int b = item_b(it);
@@ -181,17 +273,27 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
 
 #pragma unroll 1
         for (int ks = 0; ks < nks; ++ks) {
-            produce(pslot);
-            pslot = pslot + 1 == C::NSTAGE ? 0 : pslot + 1;
-            // this wave's part of stage `cslot` has landed
-            if (NW > 4 && wave >= 4) wait_vmcnt<C::DEPTH * C::NDMA_W>(); else wait_vmcnt<C::DEPTH * C::NDMA>();
-            __builtin_amdgcn_s_barrier();                      // ... and everybody else's
-            const unsigned xb = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + g * 4096 + c * 16;
-            const unsigned ab = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + 8192 + (64 * wave + c) * 32 + 16 * g;
+            __builtin_amdgcn_s_barrier();                      // the producers have seen stage `cslot` land
+            CG_BSTAMP(it == lw + 2 * Lw, ks);
+            const unsigned xb = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + (X16 ? g * 2048 + c * 8 : g * 4096 + c * 16);
+            const unsigned ab = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + C::XPART + (64 * wave + c) * 32 + 16 * g;
             const unsigned ab2 = ab + C::WPART;                // the lo image (PASSES == 3)
             f32x4 x[8];
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x2 xh[8];                                       // X16: rows 8g..8g+7, vertices 4c..4c+3 as bf16
             i32x4 ar[2 * C::PARTS];
-            if (PASSES == 3) {
+            if (X16) {
+                asm volatile(
+                    "ds_read_b64 %0, %10\n ds_read_b64 %1, %10 offset:256\n ds_read_b64 %2, %10 offset:512\n"
+                    "ds_read_b64 %3, %10 offset:768\n ds_read_b64 %4, %10 offset:1024\n ds_read_b64 %5, %10 offset:1280\n"
+                    "ds_read_b64 %6, %10 offset:1536\n ds_read_b64 %7, %10 offset:1792\n"
+                    "ds_read_b128 %8, %11\n ds_read_b128 %9, %11 offset:1024\n s_waitcnt lgkmcnt(0)"
+                    : "=&v"(xh[0]), "=&v"(xh[1]), "=&v"(xh[2]), "=&v"(xh[3]), "=&v"(xh[4]), "=&v"(xh[5]), "=&v"(xh[6]), "=&v"(xh[7]),
+                      "=&v"(ar[0]), "=&v"(ar[1])
+                    : "v"(xb), "v"(ab)
+                    : "memory");
+            } else if (PASSES == 3) {
                 asm volatile(
                     "ds_read_b128 %0, %12\n ds_read_b128 %1, %12 offset:512\n ds_read_b128 %2, %12 offset:1024\n"
                     "ds_read_b128 %3, %12 offset:1536\n ds_read_b128 %4, %12 offset:2048\n ds_read_b128 %5, %12 offset:2560\n"
@@ -223,11 +325,20 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 bf16x8 bh, bl;
+                if (X16) {
+                    // operand element i = row 8g + i at vertex 4c + r: half (r & 1) of dword (r >> 1) of that row's four
+                    u32x4 t;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        t[j] = __builtin_amdgcn_perm(xh[2 * j + 1][r >> 1], xh[2 * j][r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+                    bh = __builtin_bit_cast(bf16x8, t);
+                } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float v = x[i][r];
                     bh[i] = (__bf16)v;
                     if (PASSES == 3) bl[i] = (__bf16)(v - (float)bh[i]);
+                }
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -240,12 +351,86 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
             }
         }
 
-        if (fo0 < a.Fout) {
+        CG_BSTAMP(it == lw + 2 * Lw, 40);
+        // ---- epilogue ------------------------------------------------------------------------------------------------
+        // rows of this lane: fo0 + 32 t + acc_row(j, g).  The gradient wrt the stack scatters row fo to plane
+        // (fo % out_K, b, fo / out_K): quotient and remainder are carried along the rows (steps of 1 and 5: one division per item)
+        const int oF = a.out_K > 0 ? a.Fout / a.out_K : 0;
+        int pq = 0, pr = 0;
+        if (a.out_K > 0) { pq = (fo0 + 4 * g) / a.out_K; pr = (fo0 + 4 * g) - pq * a.out_K; }
+        const int q1 = a.out_K > 0 ? 1 / a.out_K : 0, r1 = a.out_K > 0 ? 1 % a.out_K : 0;
+        const int q5 = a.out_K > 0 ? 5 / a.out_K : 0, r5 = a.out_K > 0 ? 5 % a.out_K : 0;
+        auto plane_of_row = [&]() -> long long {
+            return a.out_K > 0 ? ((long long)pr * a.B + b) * oF + pq : -1;
+        };
+        auto next_row = [&](int d) {                               // d = 1 or 5 rows further
+            if (a.out_K > 0) {
+                pq += d == 1 ? q1 : q5;
+                pr += d == 1 ? r1 : r5;
+                if (pr >= a.out_K) { pr -= a.out_K; ++pq; }
+            }
+        };
+        // One row of the tile.  pool == 1 (every wide layer of the reference's networks, and the gradient wrt the stack) takes a
+        // lean path: fwd_epilogue_row carries every pooling variant behind run-time branches -- ~430 instructions per row in the
+        // binary, and 780 cycles per row measured (phase stamps: 25k of an item's 44k cycles in the gradient wrt the stack).
+        const bool lean = a.pool == 1;
+        const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+        const size_t mrow = (size_t)(a.Mpo >> 2);
+        auto emit_rows = [&](auto lean_tag) {
+        constexpr bool LEAN = decltype(lean_tag)::value;
+        auto put_row = [&](int t, int j, float4 bbv, bool have_bb) {
+            const int fo = fo0 + 32 * t + acc_row(j, g);
+            float v[4] = {acc[t][0][j], acc[t][1][j], acc[t][2][j], acc[t][3][j]};
+            const long long plane = plane_of_row();
+            if (!LEAN) {
+                fwd_epilogue_row(a, b, fo, v, n0, valid, c, have_bb, bbv, plane);
+                return;
+            }
+            if (a.bias_kind == CHEBGCN_BIAS_FILTER) {
+                // two scalar loads (the filter of either half-wave): no entry in the vector-memory queue behind the stores
+                const int fb = __builtin_amdgcn_readfirstlane(fo0 + 32 * t + acc_row(j, 0));
+                const float b0 = a.bias[fb < a.Fout ? fb : a.Fout - 1], b1 = a.bias[fb + 4 < a.Fout ? fb + 4 : a.Fout - 1];
+                const float bb = g ? b1 : b0;
+                bbv = make_float4(bb, bb, bb, bb);
+            } else if (!have_bb) {
+                bbv = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            v[0] = fmaxf(v[0] + bbv.x, relu_floor); v[1] = fmaxf(v[1] + bbv.y, relu_floor);
+            v[2] = fmaxf(v[2] + bbv.z, relu_floor); v[3] = fmaxf(v[3] + bbv.w, relu_floor);
+            if (fo < a.Fout && valid) {
+                const size_t pl = plane >= 0 ? (size_t)plane : (size_t)b * a.Fout + fo;
+                if (a.out) *reinterpret_cast<float4*>(a.out + pl * a.Mpo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.relu_mask)
+                    a.relu_mask[((size_t)b * a.Fout + fo) * mrow + (n0 >> 2)] =
+                        (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
+            }
+        };
+        const bool ring_bias = C::RING_BIAS && a.bias_kind == CHEBGCN_BIAS_VERTEX;
+        if (ring_bias) {
+            // the bias rows come through the ring (see Bf16Cfg): stage 4t + i holds the rows j = 4i..4i+3 of tile t
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_s_barrier();
+                    const unsigned bbase = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + wave * 4096 + g * 2048 + c * 16;
+                    f32x4 bq[4];
+                    asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:512\n ds_read_b128 %2, %4 offset:1024\n"
+                                 "ds_read_b128 %3, %4 offset:1536\n s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]) : "v"(bbase) : "memory");
+                    cslot = cslot + 1 == C::NSTAGE ? 0 : cslot + 1;
+                    CG_BSTAMP(it == lw + 2 * Lw, 41 + 4 * t + i);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        put_row(t, 4 * i + jj, make_float4(bq[jj][0], bq[jj][1], bq[jj][2], bq[jj][3]), true);
+                        next_row(jj == 3 ? 5 : 1);
+                    }
+                }
+        } else if (fo0 < a.Fout) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                // the per-vertex bias rows of the tile are requested together (one round trip): all 16 with the
-                // whole register file (NW = 4), 4 at a time where two waves share a SIMD (NW = 5)
-                constexpr int JB = NW > 4 ? 4 : 16;
+                // a per-vertex bias without the ring (five compute waves): four rows per round trip
+                constexpr int JB = 4;
                 const bool vb = a.bias_kind == CHEBGCN_BIAS_VERTEX;
 #pragma unroll
                 for (int j0 = 0; j0 < 16; j0 += JB) {
@@ -260,15 +445,16 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
                     }
 #pragma unroll
                     for (int j = 0; j < JB; ++j) {
-                        const int fo = fo0 + 32 * t + acc_row(j0 + j, g);
-                        float v[4] = {acc[t][0][j0 + j], acc[t][1][j0 + j], acc[t][2][j0 + j], acc[t][3][j0 + j]};
-                        fwd_epilogue_row(a, b, fo, v, n0, valid, c, vb, vb ? bb[j] : make_float4(0.f, 0.f, 0.f, 0.f));
+                        put_row(t, j0 + j, vb ? bb[j] : make_float4(0.f, 0.f, 0.f, 0.f), vb);
+                        next_row(((j0 + j) & 3) == 3 ? 5 : 1);
                     }
                 }
             }
         }
+        };      // emit_rows
+        if (lean) emit_rows(std::true_type{}); else emit_rows(std::false_type{});
+        CG_BSTAMP(it == lw + 2 * Lw, 50);
     }
-    wait_vmcnt<0>();                                           // the run-ahead DMAs of the last item
 }
 
 // k-steps of 16 reduction rows
@@ -433,14 +619,25 @@ contract_bwd_w_bf16_kernel(BwdWBf16Args a) {
 // 128-byte line it touches is an L2 hit a moment later.  One barrier per chunk; DMA waits are counted
 // by hand and the operands are read in asm blocks (compiler-visible LDS reads would wait for every DMA
 // in flight).
-constexpr int BWW_ROWS = 576;                    // 320 stack rows + 256 dy rows
-constexpr int BWW_BUF = BWW_ROWS * 64;           // bytes per ring buffer
+//
+// DY16: dy arrives as bf16 [B][Fout][Mp] (chebgcn_relu_grad_bf16 wrote it: the one-pass kernel rounds dy to bf16 anyway, so the
+// results are bit-identical) -- half the bytes of the larger operand.  Its ring rows are 32 B (16 vertices): eight DMA
+// instructions per chunk instead of sixteen, piece p of row r at position p ^ ((r >> 3) & 1), and the 16-byte operand read IS
+// the matrix operand (no conversion).
+// a ring buffer: 320 stack rows + 256 dy rows
+constexpr int BWW_DYOFF = 320 * 64;              // byte offset of the dy rows in a ring buffer
+template <bool DY16> constexpr int bww_buf() { return BWW_DYOFF + 256 * (DY16 ? 32 : 64); }   // bytes per ring buffer
+constexpr int BWW_BUF = bww_buf<false>();
 constexpr int BWW_NBUF = 4;
 
-template <int PASSES>
+template <int PASSES, bool DY16 = false>
 __global__ void __launch_bounds__(512)
 contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
-    extern __shared__ __attribute__((aligned(16))) char ring[];   // [BWW_NBUF][BWW_BUF]
+    static_assert(!DY16 || PASSES == 1, "a bf16 dy has no low part");
+    constexpr int BUF = bww_buf<DY16>();
+    constexpr int NINS = DY16 ? 28 : 36;                          // DMA instructions per chunk (1 KB each)
+    constexpr int NU = DY16 ? 4 : 5;                              // ... per wave at most
+    extern __shared__ __attribute__((aligned(16))) char ring[];   // [BWW_NBUF][BUF]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wy = wave >> 2, wz = wave & 3;
@@ -457,10 +654,12 @@ contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
 
     // DMA instruction n = wave + 8u (n < 36) fills ring rows 16n..16n+15: lane l -> row 16n + l/4,
     // position l%4, source piece (l%4) ^ ((row >> 2) & 3) = (l%4) ^ ((l >> 4) & 3) for every n
+    // (DY16: instruction n >= 20 fills the dy rows 32(n-20)..+31: lane l -> row 32(n-20) + l/2, position l%2, source piece
+    // (l%2) ^ ((row >> 3) & 1) = (l%2) ^ ((l >> 4) & 1))
     const int spiece = (lane & 3) ^ ((lane >> 4) & 3);
-    const float* rsrc[5];
+    const float* rsrc[NU];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int n = wave + 8 * u;
         const int R = 16 * n + (lane >> 2);
         if (n < 20) {
@@ -468,9 +667,14 @@ contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
             if (kk >= a.FinK) kk = 0;                   // rows beyond Fin*K: dropped by the final scatter
             const int fin = kk / a.K, k = kk - fin * a.K;
             rsrc[u] = a.stack + (size_t)k * a.slab + (size_t)fin * a.Mp + 4 * spiece;
+        } else if (DY16) {
+            int fo = col0 + 32 * (n - 20) + (lane >> 1);
+            if (fo >= a.Fout || n >= NINS) fo = 0;
+            // (addresses in units of float: a bf16 plane is Mp/2 floats long, a piece of eight vertices four floats)
+            rsrc[u] = a.dy + ((size_t)fo * a.Mp >> 1) + 4 * ((lane & 1) ^ ((lane >> 4) & 1));
         } else {
             int fo = col0 + (R - 320);
-            if (fo >= a.Fout || n >= 36) fo = 0;
+            if (fo >= a.Fout || n >= NINS) fo = 0;
             rsrc[u] = a.dy + (size_t)fo * a.Mp + 4 * spiece;
         }
     }
@@ -479,12 +683,13 @@ contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
     auto issue = [&](int ch, int slot) {
         const int b = ch / a.nchunks_m;
         const int m0 = (ch - b * a.nchunks_m) * 16;
-        const size_t so = (size_t)b * a.Fin * a.Mp + m0, dof = (size_t)b * a.Fout * a.Mp + m0;
-        const unsigned base = (unsigned)(size_t)ring + slot * BWW_BUF;
+        const size_t so = (size_t)b * a.Fin * a.Mp + m0;
+        const size_t dof = DY16 ? ((size_t)b * a.Fout * a.Mp + m0) >> 1 : (size_t)b * a.Fout * a.Mp + m0;
+        const unsigned base = (unsigned)(size_t)ring + slot * BUF;
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int n = wave + 8 * u;
-            if (n < 36) {
+            if (n < NINS) {
                 const float* src = rsrc[u] + (n < 20 ? so : dof);
                 __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(base + n * 1024),
                                                  16, 0, 0);
@@ -500,27 +705,32 @@ contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
     const int sw = (c >> 2) & 3;
     const unsigned offA0 = (wy * 5) * 2048 + c * 64 + 16 * ((2 * g) ^ sw);
     const unsigned offA1 = (wy * 5) * 2048 + c * 64 + 16 * ((2 * g + 1) ^ sw);
-    const unsigned offB0 = 320 * 64 + (wz * 2) * 2048 + c * 64 + 16 * ((2 * g) ^ sw);
-    const unsigned offB1 = 320 * 64 + (wz * 2) * 2048 + c * 64 + 16 * ((2 * g + 1) ^ sw);
+    const unsigned offB0 = DY16 ? BWW_DYOFF + (wz * 2) * 1024 + c * 32 + 16 * (g ^ ((c >> 3) & 1))
+                                : BWW_DYOFF + (wz * 2) * 2048 + c * 64 + 16 * ((2 * g) ^ sw);
+    const unsigned offB1 = BWW_DYOFF + (wz * 2) * 2048 + c * 64 + 16 * ((2 * g + 1) ^ sw);
 
     int slot = 0;
 #pragma unroll 1
     for (int ch = ch0; ch < ch1; ++ch) {
         // this wave's part of chunk `ch` is (BWW_NBUF-2) chunks of DMAs old
-        if (wave < 4) wait_vmcnt<2 * 5>(); else wait_vmcnt<2 * 4>();
+        if (wave < 4) wait_vmcnt<2 * NU>(); else wait_vmcnt<2 * (NU - 1)>();
         __builtin_amdgcn_s_barrier();                    // everybody's part landed; everybody is done with the buffer refilled next
         {
             const int nx = ch + BWW_NBUF - 1;
             issue(nx < ch1 ? nx : ch1 - 1, (slot + BWW_NBUF - 1) & (BWW_NBUF - 1));
         }
-        const unsigned buf = (unsigned)(size_t)ring + slot * BWW_BUF;
+        const unsigned buf = (unsigned)(size_t)ring + slot * BUF;
         slot = (slot + 1) & (BWW_NBUF - 1);
         const int m0 = (ch % a.nchunks_m) * 16;
         const bool tail = m0 + 16 > a.M;
         const int nlive = a.M - m0 - 8 * g;             // vertices of this lane's eight that exist (tail chunks)
 
         f32x4 rb[4];
-        {
+        if (DY16) {
+            const unsigned b0 = buf + offB0;
+            asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:1024\n s_waitcnt lgkmcnt(0)"
+                         : "=&v"(rb[0]), "=&v"(rb[1]) : "v"(b0) : "memory");
+        } else {
             const unsigned b0 = buf + offB0, b1 = buf + offB1;
             asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %4 offset:2048\n"
                          "ds_read_b128 %3, %5 offset:2048\n s_waitcnt lgkmcnt(0)"
@@ -539,8 +749,19 @@ contract_bwd_w_bf16_wide_kernel(BwdWBf16Args a, int total_chunks) {
             }
         };
         bf16x8 bh[2], bl[2];
-        split(rb[0], rb[1], bh[0], bl[0]);
-        split(rb[2], rb[3], bh[1], bl[1]);
+        if (DY16) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bh[u] = __builtin_bit_cast(bf16x8, rb[u]);
+                if (tail) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bh[u][i] = i < nlive ? bh[u][i] : (__bf16)0.f;
+                }
+            }
+        } else {
+            split(rb[0], rb[1], bh[0], bl[0]);
+            split(rb[2], rb[3], bh[1], bl[1]);
+        }
 
         f32x4 ra[10];
         {
@@ -666,7 +887,7 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
 
 using namespace chebgcn;
 
-static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw);
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw, bool x16 = false);
 
 extern "C" size_t chebgcn_contract_fwd_bf16_workspace(int Fin, int K, int Fout) {
     if (Fin <= 0 || K <= 0 || Fout <= 0) return 0;
@@ -707,7 +928,7 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
 }
 
 // the packed operand is in `workspace`; `a` describes the rows, the planes and the epilogue
-static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw) {
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw, bool x16) {
     const int B = a.B, M = a.M, Fout = a.Fout;
     const int G = nw * 64;                               // filters per work item
     const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + G - 1) / G * G;
@@ -722,22 +943,27 @@ static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, h
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
     }
-    const dim3 grid(nitems < cus ? nitems : cus);       // one workgroup per CU (128 accumulator registers per lane)
-#define CG_BF16_LAUNCH(P, NW)                                                                                      \
+
+#define CG_BF16_LAUNCH_X(P, NW, X, TAG)                                                                            \
     do {                                                                                                           \
-        constexpr int lds = Bf16Cfg<P, NW>::NSTAGE * Bf16Cfg<P, NW>::STAGE;                                        \
-        note_dispatch_more("contract_fwd_bf16_kernel<" #P "," #NW ">");                                            \
-        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_fwd_bf16_kernel<P, NW>),                 \
+        constexpr int lds = Bf16Cfg<P, NW, X>::NSTAGE * Bf16Cfg<P, NW, X>::STAGE;                                  \
+        const dim3 grid(nitems < cus ? nitems : cus);           /* one persistent workgroup per CU */              \
+        note_dispatch_more("contract_fwd_bf16_kernel<" #P "," #NW TAG ">");                                        \
+        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_fwd_bf16_kernel<P, NW, X>),              \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                              \
-        hipLaunchKernelGGL((contract_fwd_bf16_kernel<P, NW>), grid, dim3(NW * 64), lds, stream, a,                 \
+        hipLaunchKernelGGL((contract_fwd_bf16_kernel<P, NW, X>), grid, dim3((NW + 2) * 64), lds, stream, a,              \
                            (const __bf16*)workspace, nks, FoutP, ntm, nitems);                                     \
     } while (0)
-    if (nw == 5) {
+#define CG_BF16_LAUNCH(P, NW) CG_BF16_LAUNCH_X(P, NW, false, "")
+    if (x16) {
+        if (nw == 5) CG_BF16_LAUNCH_X(1, 5, true, ",x16"); else CG_BF16_LAUNCH_X(1, 4, true, ",x16");
+    } else if (nw == 5) {
         if (passes == 3) CG_BF16_LAUNCH(3, 5); else CG_BF16_LAUNCH(1, 5);
     } else {
         if (passes == 3) CG_BF16_LAUNCH(3, 4); else CG_BF16_LAUNCH(1, 4);
     }
 #undef CG_BF16_LAUNCH
+#undef CG_BF16_LAUNCH_X
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
@@ -757,10 +983,23 @@ extern "C" size_t chebgcn_contract_bwd_x_bf16_workspace(int Fin, int K, int Fout
     return 2 * nks * RowsP * 16 * sizeof(uint16_t);
 }
 
+static int bwd_x_bf16_impl(const float* dy, bool dy16, const float* W, float* gstack, int B, int M, int Fin, int K, int Fout,
+                           int passes, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 extern "C" int chebgcn_contract_bwd_x_bf16(const float* dy, const float* W, float* gstack, int B, int M, int Fin, int K,
                                            int Fout, int passes, void* workspace, size_t workspace_bytes,
                                            chebgcn_stream stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+    return bwd_x_bf16_impl(dy, false, W, gstack, B, M, Fin, K, Fout, passes, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int chebgcn_contract_bwd_x_bf16_dy16(const uint16_t* dy16, const float* W, float* gstack, int B, int M, int Fin, int K,
+                                                int Fout, void* workspace, size_t workspace_bytes, chebgcn_stream stream_) {
+    return bwd_x_bf16_impl(reinterpret_cast<const float*>(dy16), true, W, gstack, B, M, Fin, K, Fout, 1, workspace, workspace_bytes,
+                           (hipStream_t)stream_);
+}
+
+static int bwd_x_bf16_impl(const float* dy, bool dy16, const float* W, float* gstack, int B, int M, int Fin, int K, int Fout,
+                           int passes, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     CG_REQUIRE(dy && W && gstack && workspace, "contract_bwd_x_bf16: NULL argument");
     CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0 && B <= 65535, "contract_bwd_x_bf16: bad shape");
     CG_REQUIRE(passes == 1 || passes == 3, "contract_bwd_x_bf16: passes must be 1 (bf16) or 3 (split bf16), got %d", passes);
@@ -781,7 +1020,7 @@ extern "C" int chebgcn_contract_bwd_x_bf16(const float* dy, const float* W, floa
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
                        a.FinK, a.Fout, nks, FoutP, passes == 3 ? 2 : 1, Fout);
     CG_HIP(hipGetLastError());
-    return launch_contract_bf16(a, passes, workspace, stream, nw);
+    return launch_contract_bf16(a, passes, workspace, stream, nw, dy16);
 }
 
 extern "C" size_t chebgcn_contract_bwd_w_bf16_workspace(int B, int M, int Fin, int K, int Fout) {
@@ -790,10 +1029,31 @@ extern "C" size_t chebgcn_contract_bwd_w_bf16_workspace(int B, int M, int Fin, i
     return ((size_t)p.gx + BWB_SPLIT) * p.gy * p.gz * p.per * sizeof(float);   // partials + stage
 }
 
+static int bwd_w_bf16_impl(const float* stack, const float* dy, bool dy16, float* dW, void* workspace, size_t workspace_bytes,
+                           int B, int M, int Fin, int K, int Fout, int passes, hipStream_t stream);
+
 extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, float* dW, void* workspace,
                                            size_t workspace_bytes, int B, int M, int Fin, int K, int Fout, int passes,
                                            chebgcn_stream stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+    return bwd_w_bf16_impl(stack, dy, false, dW, workspace, workspace_bytes, B, M, Fin, K, Fout, passes, (hipStream_t)stream_);
+}
+
+extern "C" int chebgcn_bf16_dy16_supported(int B, int M, int Fin, int K, int Fout) {
+    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
+    return bwb_plan(B, M, Fin, K, Fout).wide ? 1 : 0;
+}
+
+extern "C" int chebgcn_contract_bwd_w_bf16_dy16(const float* stack, const uint16_t* dy16, float* dW, void* workspace,
+                                                size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
+                                                chebgcn_stream stream_) {
+    CG_REQUIRE(chebgcn_bf16_dy16_supported(B, M, Fin, K, Fout),
+               "contract_bwd_w_bf16_dy16: only for wide layers (Fin*K > 160 and Fout > 64), got Fin*K=%d Fout=%d", Fin * K, Fout);
+    return bwd_w_bf16_impl(stack, reinterpret_cast<const float*>(dy16), true, dW, workspace, workspace_bytes, B, M, Fin, K, Fout, 1,
+                           (hipStream_t)stream_);
+}
+
+static int bwd_w_bf16_impl(const float* stack, const float* dy, bool dy16, float* dW, void* workspace, size_t workspace_bytes,
+                           int B, int M, int Fin, int K, int Fout, int passes, hipStream_t stream) {
     CG_REQUIRE(stack && dy && dW && workspace, "contract_bwd_w_bf16: NULL argument");
     CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w_bf16: bad shape");
     CG_REQUIRE(passes == 1 || passes == 3, "contract_bwd_w_bf16: passes must be 1 (bf16) or 3 (split bf16), got %d", passes);
@@ -811,15 +1071,21 @@ extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, 
         const size_t ldsw = (size_t)BWW_NBUF * BWW_BUF;
         const long long total = (long long)B * a.nchunks_m;
         CG_REQUIRE(total < (1ll << 31), "contract_bwd_w_bf16: too many chunks");
-        note_dispatch(passes == 3 ? "contract_bwd_w_bf16_wide_kernel<3>" : "contract_bwd_w_bf16_wide_kernel<1>");
-        if (passes == 3) {
+        note_dispatch(dy16 ? "contract_bwd_w_bf16_wide_kernel<1,dy16>"
+                           : passes == 3 ? "contract_bwd_w_bf16_wide_kernel<3>" : "contract_bwd_w_bf16_wide_kernel<1>");
+        if (dy16) {
+            const size_t lds16 = (size_t)BWW_NBUF * bww_buf<true>();
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_wide_kernel<1, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+            hipLaunchKernelGGL((contract_bwd_w_bf16_wide_kernel<1, true>), grid, dim3(512), lds16, stream, a, (int)total);
+        } else if (passes == 3) {
             CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_wide_kernel<3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-            hipLaunchKernelGGL(contract_bwd_w_bf16_wide_kernel<3>, grid, dim3(512), ldsw, stream, a, (int)total);
+            hipLaunchKernelGGL((contract_bwd_w_bf16_wide_kernel<3>), grid, dim3(512), ldsw, stream, a, (int)total);
         } else {
             CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_bwd_w_bf16_wide_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-            hipLaunchKernelGGL(contract_bwd_w_bf16_wide_kernel<1>, grid, dim3(512), ldsw, stream, a, (int)total);
+            hipLaunchKernelGGL((contract_bwd_w_bf16_wide_kernel<1>), grid, dim3(512), ldsw, stream, a, (int)total);
         }
     }
     const size_t lds = (size_t)(p.rt + p.ct) * 32 * BWB_ROW * sizeof(float);
@@ -846,3 +1112,9 @@ extern "C" int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, 
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
+
+#ifdef CG_EXPERIMENT
+extern "C" int chebgcn_debug_stampsb(long long* out) {      // CG_X & 64 builds only (tools/kbench.py --stamps)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(chebgcn::g_dbgb), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : -1;
+}
+#endif

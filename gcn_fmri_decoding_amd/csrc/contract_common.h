@@ -39,8 +39,10 @@ struct FwdArgs {
 // store; `argmax` receives the arg-max byte (max pooling) or the ReLU mask (average pooling).
 // `bbv`: the per-vertex bias of this row when the caller fetched it ahead (have_bb), so that the
 // rows of a tile do not pay one memory round trip each.
+// `plane`: index of the output plane when the caller tracks it (out_K scatter without the divisions), else -1.
 __device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo, float (&v)[4], int n0, bool valid,
-                                                 int c, bool have_bb = false, float4 bbv = make_float4(0.f, 0.f, 0.f, 0.f)) {
+                                                 int c, bool have_bb = false, float4 bbv = make_float4(0.f, 0.f, 0.f, 0.f),
+                                                 long long plane = -1) {
     const bool fo_ok = fo < a.Fout;
     const int p = a.pool;
     const int lanes_per_win = p > 4 ? (p >> 2) : 1;     // lanes sharing one pooling window
@@ -61,8 +63,9 @@ __device__ __forceinline__ void fwd_epilogue_row(const FwdArgs& a, int b, int fo
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
     }
     const int foc = fo_ok ? fo : 0;
-    float* orow = a.out + (a.out_K > 0 ? ((size_t)(foc % a.out_K) * a.B * (a.Fout / a.out_K) + (size_t)b * (a.Fout / a.out_K) + foc / a.out_K)
-                                       : ((size_t)b * a.Fout + foc)) * a.Mpo;
+    float* orow = a.out + (plane >= 0 ? (size_t)plane
+                           : a.out_K > 0 ? ((size_t)(foc % a.out_K) * a.B * (a.Fout / a.out_K) + (size_t)b * (a.Fout / a.out_K) + foc / a.out_K)
+                                         : ((size_t)b * a.Fout + foc)) * a.Mpo;
     uint8_t* arow = a.argmax ? a.argmax + ((size_t)b * a.Fout + (fo_ok ? fo : 0)) * a.Mpo : nullptr;
     if (p == 1) {
         if (fo_ok && valid) {

@@ -82,7 +82,9 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
 // one of four interleaved subsets of the batch; fixed-order LDS sum of the four subsets.
 // NP = 4 subsets of the batch x 64 quads per workgroup, or (small graphs: an atlas-sized layer would give the chip 64 workgroups
 // that each walk the batch in 8 serial rounds) 16 subsets x 16 quads.
-template <int BIAS, int NP = 4>
+// DY16: the gated gradient is written as bf16 (RNE), [B][F][Mp] -- the operand of the bf16 contraction gradients, which
+// round it to bf16 anyway (chebgcn_relu_grad_bf16)
+template <int BIAS, int NP = 4, bool DY16 = false>
 __global__ void __launch_bounds__(256)
 bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dy,
                       float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F,
@@ -106,7 +108,13 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
             const int bits = mp[(size_t)b * F * Mq];
             const float4 d = make_float4((bits & 1) ? g.x : 0.f, (bits & 2) ? g.y : 0.f, (bits & 4) ? g.z : 0.f,
                                          (bits & 8) ? g.w : 0.f);
-            if (dy) *reinterpret_cast<float4*>(dy + ((size_t)b * F + f) * Mp + 4 * q) = d;
+            if (DY16) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                const bf16x4 h = {(__bf16)d.x, (__bf16)d.y, (__bf16)d.z, (__bf16)d.w};
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dy) + ((size_t)b * F + f) * Mp + 4 * q) = h;
+            } else if (dy) {
+                *reinterpret_cast<float4*>(dy + ((size_t)b * F + f) * Mp + 4 * q) = d;
+            }
             sum.x += d.x; sum.y += d.y; sum.z += d.z; sum.w += d.w;
         }
         const int m = 4 * q;                            // the padding of the plane takes no gradient
@@ -406,6 +414,45 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
 #undef CG_BRELU_P
 #undef CG_BRELU
     }
+    CG_HIP(hipGetLastError());
+    if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        note_dispatch_more("bias_filter_reduce_kernel");
+        hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
+        CG_HIP(hipGetLastError());
+    }
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_relu_grad_bf16(const float* dout, const uint8_t* relu_mask, uint16_t* dy16, float* dbias, int bias_kind,
+                                      int B, int M, int F, void* workspace, size_t workspace_bytes, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(dout && relu_mask && dy16, "relu_grad_bf16: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "relu_grad_bf16: bad shape");
+    CG_REQUIRE(bias_kind >= 0 && bias_kind <= 2 && (bias_kind == CHEBGCN_BIAS_NONE || dbias), "relu_grad_bf16: dbias is NULL");
+    const int Mp = plane_stride(M);
+    int parts = 0;
+    const int nblk = brelu_bwd_blocks(M, F, 1, 1, true, &parts);
+    float* fpart = nullptr;
+    if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        CG_REQUIRE(workspace && workspace_bytes >= (size_t)F * nblk * sizeof(float),
+                   "relu_grad_bf16: the per-filter bias gradient needs a workspace of chebgcn_brelu_pool_bwd_workspace() bytes");
+        fpart = static_cast<float*>(workspace);
+    }
+    const dim3 grid(nblk, F);
+#define CG_RG16(BK)                                                                                                         \
+    do {                                                                                                                    \
+        note_dispatch(parts == 16 ? "bias_grad_relu_kernel<" #BK ",16,bf16>" : "bias_grad_relu_kernel<" #BK ",4,bf16>");    \
+        if (parts == 16)                                                                                                    \
+            hipLaunchKernelGGL((bias_grad_relu_kernel<BK, 16, true>), grid, dim3(256), 0, stream, dout, relu_mask,          \
+                               reinterpret_cast<float*>(dy16), dbias, fpart, B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);      \
+        else                                                                                                                \
+            hipLaunchKernelGGL((bias_grad_relu_kernel<BK, 4, true>), grid, dim3(256), 0, stream, dout, relu_mask,           \
+                               reinterpret_cast<float*>(dy16), dbias, fpart, B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);      \
+    } while (0)
+    if (bias_kind == CHEBGCN_BIAS_FILTER) CG_RG16(CHEBGCN_BIAS_FILTER);
+    else if (bias_kind == CHEBGCN_BIAS_VERTEX) CG_RG16(CHEBGCN_BIAS_VERTEX);
+    else CG_RG16(CHEBGCN_BIAS_NONE);
+#undef CG_RG16
     CG_HIP(hipGetLastError());
     if (bias_kind == CHEBGCN_BIAS_FILTER) {
         note_dispatch_more("bias_filter_reduce_kernel");

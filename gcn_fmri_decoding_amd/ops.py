@@ -72,6 +72,7 @@ class KernelTimers:
 
 
 timers = None
+bf16_dy16 = True             # 'bf16' wide layers: dy handed to the two contraction gradients as bf16 (chebgcn_relu_grad_bf16); same results
 fold_relu_grad = True        # pool == 1 layers: ReluGrad inside chebgcn_contract_bwd_*_relu (False: separate brelu_pool_bwd pass)
 # atlas-sized graphs: recurrence + contraction (and the gradient wrt the input) as one on-chip launch per layer
 fused_small = os.environ.get('CHEBGCN_FUSED_SMALL', '1') != '0' 
@@ -469,6 +470,8 @@ class ChebConv(torch.autograd.Function):
             else:
                 dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
         Mo = M // pool
+        dy16 = bool(bf16_dy16 and not fold and ctx.precision == 'bf16' and pool == 1 and relu and argmax is not None
+                    and lib.chebgcn_bf16_dy16_supported(B, M, Fin, K, Fout))
         if fold:
             # ReluGrad folded into the two contraction gradients (chebgcn_contract_bwd_*_relu read gout and the
             # mask); what is left of this pass is the bias reduction, which writes nothing but dbias
@@ -485,6 +488,14 @@ class ChebConv(torch.autograd.Function):
                     _lib.check(_launch('bias_grad', B * Fout * M * (4.0 + 0.25), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
                         _p(gout), None, _p(mask), None, _p(dbias), bias_kind, B, M, Fout, 1, pool_kind, 1, _p(bws), nbws,
                         _stream())), 'brelu_pool_bwd')
+        elif dy16:
+            # one-pass bf16 gradients of a wide layer: the ReluGrad pass writes dy as bf16 -- what the matrix cores would round it
+            # to anyway (bit-identical results), half the bytes of the largest operand of both gradients
+            dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.bfloat16, device=dev), None
+            bk = bias_kind if dbias is not None else BIAS_NONE
+            bws, nbws = _brelu_bwd_ws(B, M, Fout, 1, bk, dev)
+            _lib.check(_launch('relu_grad_bf16', B * Fout * M * (6.0 + 0.25), 0.0, lambda: lib.chebgcn_relu_grad_bf16(
+                _p(gout), _p(argmax), _p(dy), _p(dbias), bk, B, M, Fout, _p(bws), nbws, _stream())), 'relu_grad_bf16')
         else:
             dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev), None
             # with the ReLU mask of a pool == 1 layer `out` is not read (a byte per four vertices instead)
@@ -509,7 +520,10 @@ class ChebConv(torch.autograd.Function):
                 dW = torch.empty((Fin * K, Fout), dtype=torch.float32, device=dev)
 
             def launch_bwd_w():
-                if passes:
+                if dy16:
+                    call = lambda: lib.chebgcn_contract_bwd_w_bf16_dy16(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
+                                                                        K, Fout, _stream())
+                elif passes:
                     call = lambda: lib.chebgcn_contract_bwd_w_bf16(_p(stack), _p(dy), _p(dW), _p(ws), ws.numel(), B, M, Fin,
                                                                    K, Fout, passes, _stream())
                 elif fold and mean:
@@ -548,9 +562,13 @@ class ChebConv(torch.autograd.Function):
                 nws = lib.chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout)
                 wsx = _workspace(nws, dev, 'bwd_x_bf16')                  # its own: bwd_w may be running beside it
                 what = 'contract_bwd_x_' + ctx.precision
-                _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout,
-                                   lambda: lib.chebgcn_contract_bwd_x_bf16(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout,
-                                                                           passes, _p(wsx), nws, _stream())), what)
+                if dy16:
+                    call = lambda: lib.chebgcn_contract_bwd_x_bf16_dy16(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout, _p(wsx), nws,
+                                                                        _stream())
+                else:
+                    call = lambda: lib.chebgcn_contract_bwd_x_bf16(_p(dy), _p(Wc), _p(gstack), B, M, Fin, K, Fout, passes,
+                                                                   _p(wsx), nws, _stream())
+                _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout, call), what)
             elif fold and mean:
                 _lib.check(_launch('contract_bwd_x', 4.0 * B * M * (Fin * K + 1), 2.0 * B * M * Fin * K * Fout,
                                    lambda: lib.chebgcn_contract_bwd_x_relu_mean(_p(dy), _p(mask), _p(Wc), _p(gstack), B, M, Fin,

@@ -153,6 +153,25 @@ int chebgcn_contract_bwd_w_bf16(const float* stack, const float* dy, float* dW, 
                                 size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
                                 int passes, chebgcn_stream stream);
 
+/* ---- the same two gradients with dy handed over as bf16 (one-pass arithmetic, wide layers).
+ * The one-pass kernels round dy to bf16 before it meets the matrix cores; when the ReluGrad pass that produces dy
+ * (models_gcn.py:619-629 under TF autodiff) writes it as bf16 in the first place, the largest operand of both gradients is half
+ * the bytes and the results are BIT-IDENTICAL to chebgcn_contract_bwd_*_bf16(passes = 1) on the fp32 dy.
+ *   chebgcn_relu_grad_bf16: dy16[b][o][m] = bf16( relu_mask bit ? dout[b][o][m] : 0 ), planes [B][F][Mp(M)] of 2-byte
+ *       elements, and the bias gradient (fp32, fixed-order sums) in the same pass; relu_mask as chebgcn_contract_fwd(_bf16)
+ *       wrote it for a pool == 1 ReLU layer; workspace as for chebgcn_brelu_pool_bwd.
+ *   chebgcn_bf16_dy16_supported: 1 where both gradients below take this operand (layers wide enough for the one-pass weight
+ *       gradient: Fin*K > 160 and Fout > 64), else 0 -- callers then keep the fp32 dy.
+ *   workspaces: chebgcn_contract_bwd_w_bf16_workspace / chebgcn_contract_bwd_x_bf16_workspace. */
+int chebgcn_relu_grad_bf16(const float* dout, const uint8_t* relu_mask, uint16_t* dy16, float* dbias, int bias_kind,
+                           int B, int M, int F, void* workspace, size_t workspace_bytes, chebgcn_stream stream);
+int chebgcn_bf16_dy16_supported(int B, int M, int Fin, int K, int Fout);
+int chebgcn_contract_bwd_w_bf16_dy16(const float* stack, const uint16_t* dy16, float* dW, void* workspace,
+                                     size_t workspace_bytes, int B, int M, int Fin, int K, int Fout,
+                                     chebgcn_stream stream);
+int chebgcn_contract_bwd_x_bf16_dy16(const uint16_t* dy16, const float* W, float* gstack, int B, int M, int Fin,
+                                     int K, int Fout, void* workspace, size_t workspace_bytes, chebgcn_stream stream);
+
 /* ---- bias + ReLU + pooling on their own (b1relu / b2relu / mpool1 / apool1 called
  * separately, models_gcn.py:619-648); same conventions as the epilogue of contract_fwd.
  * x: [B][F][Mp(M)] -> out: [B][F][Mp(M/pool)]. */

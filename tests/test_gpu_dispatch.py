@@ -531,3 +531,125 @@ def test_fused_atlas_layer_vs_oracle(ops, dev, lib, N, B, Fin, K, Fout, bias_kin
     got['dx'] = np.abs(d - dx_ref).max() / np.abs(dx_ref).max()
     assert got['dx'] <= GREL, 'dx: %.3e' % got['dx']
     record_measured('fused_atlas_layer_vs_oracle[%d,%d,%d,%d,%d]' % (N, B, Fin, K, Fout), **got)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16 gradients of wide layers with dy handed over as bf16 (chebgcn_relu_grad_bf16 + chebgcn_contract_bwd_*_bf16_dy16)
+BF16_REL = 1e-2
+
+
+@pytest.mark.parametrize('B,M,Fin,K,Fout,bias_kind', [
+    (2, 500, 70, 5, 300, 1),         # 2 x 2 workgroup tiles of the one-pass weight gradient (350 rows, 300 columns); per-filter bias
+    (3, 77, 33, 5, 65, 2),           # ragged tiles, chunks of 16 vertices with a tail of 13; per-vertex bias
+    (70, 40, 60, 5, 256, 0),         # more windows than vertex chunks per window; no bias
+    (2, 300, 120, 5, 80, 2),         # 600 rows: bwd_x on five waves with two groups of 320
+    (4, 10466, 60, 5, 256, 2)])      # BASELINE configs[4] (batch 4 of 64)
+def test_bf16_dy16_gradients(ops, dev, lib, B, M, Fin, K, Fout, bias_kind):
+    """ReluGrad writing dy as bf16 and the two one-pass bf16 contraction gradients reading it (models_gcn.py:616, 619-629 under
+    TF autodiff): BIT-IDENTICAL to the fp32-dy path (chebgcn_brelu_pool_bwd + chebgcn_contract_bwd_*_bf16, passes = 1), and
+    within the bf16 bound of float64 products of the same operands.  Pads of every plane are NaN."""
+    from gcn_fmri_decoding_amd import _lib
+    assert lib.chebgcn_bf16_dy16_supported(B, M, Fin, K, Fout) == 1
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B * 1000 + M + Fout)
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    gout = torch.randn((B, Fout, Mp), generator=gen, device=dev)
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * 0.2
+    keep = torch.rand((B, Fout, Mp), generator=gen, device=dev) > 0.4
+    stack[..., M:] = float('nan')
+    gout[..., M:] = float('nan')
+    mask = (keep.reshape(B, Fout, Mp // 4, 4).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8, device=dev)).sum(-1).to(torch.uint8).contiguous()
+    bshape = {0: None, 1: (Fout,), 2: (Fout, Mp)}[bias_kind]
+    nb = lib.chebgcn_brelu_pool_bwd_workspace(B, M, Fout, 1, bias_kind)
+    bws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+
+    # ---- fp32-dy path (what the round-3 layer ran)
+    dy32 = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    db32 = torch.full(bshape, float('nan'), device=dev) if bshape else None
+    _lib.check(lib.chebgcn_brelu_pool_bwd(P(gout), None, P(mask), P(dy32), P(db32), bias_kind, B, M, Fout, 1, 0, 1, P(bws), nb, stream()), 'brelu_pool_bwd')
+    nw = lib.chebgcn_contract_bwd_w_bf16_workspace(B, M, Fin, K, Fout)
+    ws = torch.empty(nw, dtype=torch.uint8, device=dev)
+    dW32 = torch.full((Fin * K, Fout), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_w_bf16(P(stack), P(dy32), P(dW32), P(ws), nw, B, M, Fin, K, Fout, 1, stream()), 'bwd_w_bf16')
+    assert _lib.last_dispatch().startswith('contract_bwd_w_bf16_wide_kernel<1> + ')
+    nx = lib.chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout)
+    wsx = torch.empty(nx, dtype=torch.uint8, device=dev)
+    gs32 = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_x_bf16(P(dy32), P(W), P(gs32), B, M, Fin, K, Fout, 1, P(wsx), nx, stream()), 'bwd_x_bf16')
+    nw5 = (Fin * K + 319) // 320 * 320 < (Fin * K + 255) // 256 * 256
+    assert _lib.last_dispatch() == 'pack_w_bf16_kernel<transposed> + contract_fwd_bf16_kernel<1,%d>' % (5 if nw5 else 4)
+
+    # ---- bf16-dy path
+    dy16 = torch.full((B, Fout, Mp), float('nan'), dtype=torch.bfloat16, device=dev)
+    db16 = torch.full(bshape, float('nan'), device=dev) if bshape else None
+    _lib.check(lib.chebgcn_relu_grad_bf16(P(gout), P(mask), P(dy16), P(db16), bias_kind, B, M, Fout, P(bws), nb, stream()), 'relu_grad_bf16')
+    assert 'bias_grad_relu_kernel<' in _lib.last_dispatch() and ',bf16>' in _lib.last_dispatch()
+    dW16 = torch.full((Fin * K, Fout), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_w_bf16_dy16(P(stack), P(dy16), P(dW16), P(ws), nw, B, M, Fin, K, Fout, stream()), 'bwd_w_bf16_dy16')
+    assert _lib.last_dispatch().startswith('contract_bwd_w_bf16_wide_kernel<1,dy16> + ')
+    gs16 = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_x_bf16_dy16(P(dy16), P(W), P(gs16), B, M, Fin, K, Fout, P(wsx), nx, stream()), 'bwd_x_bf16_dy16')
+    assert _lib.last_dispatch() == 'pack_w_bf16_kernel<transposed> + contract_fwd_bf16_kernel<1,%d,x16>' % (5 if nw5 else 4)
+    torch.cuda.synchronize()
+
+    assert torch.equal(dy16[..., :M], dy32[..., :M].to(torch.bfloat16)), 'dy16 is not the RNE rounding of the fp32 dy'
+    if db32 is not None:
+        v = (slice(None), slice(0, M)) if bias_kind == 2 else (slice(None),)
+        assert torch.equal(db16[v], db32[v]), 'bias gradient differs'
+    assert torch.equal(dW16, dW32), 'weight gradient differs from the fp32-dy path: max %.3e' % float((dW16 - dW32).abs().max())
+    assert torch.equal(gs16[..., :M], gs32[..., :M]), 'stack gradient differs from the fp32-dy path'
+
+    # ---- against float64 products of the same operands
+    d64 = (gout[..., :M] * keep[..., :M]).double()
+    refw = stack[..., :M].double().permute(2, 0, 1, 3).reshape(Fin * K, B * M) @ d64.permute(1, 0, 2).reshape(Fout, B * M).T
+    refx = torch.einsum('ro,bom->rbm', W.double(), d64).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    e_w, e_x = rel_err(dW16, refw), rel_err(gs16[..., :M], refx)
+    record_measured('bf16_dy16_gradients[%d,%d,%d,%d,%d]' % (B, M, Fin, K, Fout), bwd_w=e_w, bwd_x=e_x)
+    assert e_w <= BF16_REL and e_x <= BF16_REL, 'bwd_w %.3e, bwd_x %.3e' % (e_w, e_x)
+    assert e_w > 1e-6 and e_x > 1e-6, 'suspiciously exact: is an fp32 kernel running?'
+
+
+def test_bf16_layer_takes_the_dy16_path(ops, dev, lib):
+    """A wide ReLU layer in 'bf16' precision: ChebConv.backward hands dy over as bf16 (the kernels are named), and every
+    gradient is bit-identical to the same layer with ``ops.bf16_dy16 = False``."""
+    import scipy.sparse
+    from gcn_fmri_decoding_amd import _lib, graph
+    rs = np.random.RandomState(4)
+    N = 900
+    A = scipy.sparse.random(N, N, density=6.0 / N, random_state=rs, format='csr', dtype=np.float32)
+    A = A + A.T
+    A.setdiag(0)
+    A.eliminate_zeros()
+    L = graph.laplacian(A.tocsr(), normalized=True)
+    g = ops.Graph(L, dev)
+    M = L.shape[0]
+    B, Fin, K, Fout = 3, 40, 5, 96
+    x = rs.randn(B, Fin, g.Mp).astype(np.float32)
+    x[..., M:] = 0
+    W = torch.as_tensor((rs.randn(Fin * K, Fout) * 0.1).astype(np.float32)).to(dev)
+    b = torch.as_tensor((rs.randn(Fout, g.Mp) * 0.1).astype(np.float32)).to(dev)
+    gout = torch.zeros((B, Fout, g.Mp), device=dev)
+    gout[..., :M] = torch.as_tensor(rs.randn(B, Fout, M).astype(np.float32)).to(dev)
+    grads, logs = {}, {}
+    old = ops.bf16_dy16
+    try:
+        for flag in (True, False):
+            ops.bf16_dy16 = flag
+            xs = torch.as_tensor(x).to(dev).requires_grad_(True)
+            Wp, bp = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            out = ops.cheb_conv(xs, Wp, bp, g, K, relu=True, bias_kind=ops.BIAS_VERTEX, precision='bf16')
+            _lib.dispatch_log = []
+            out.backward(gout)
+            torch.cuda.synchronize()
+            logs[flag] = dict(_lib.dispatch_log)
+            _lib.dispatch_log = None
+            grads[flag] = (xs.grad[..., :M].clone(), Wp.grad.clone(), bp.grad[..., :M].clone())
+    finally:
+        ops.bf16_dy16 = old
+        _lib.dispatch_log = None
+    assert 'relu_grad_bf16' in logs[True] and ',bf16>' in logs[True]['relu_grad_bf16']
+    assert 'dy16' in logs[True]['contract_bwd_w_bf16'] and 'x16' in logs[True]['contract_bwd_x_bf16']
+    assert 'brelu_pool_bwd' in logs[False] and 'dy16' not in logs[False]['contract_bwd_w_bf16']
+    for name, a, c in zip(('dx', 'dW', 'dbias'), grads[True], grads[False]):
+        assert torch.equal(a, c), '%s differs between the bf16-dy and the fp32-dy layer' % name

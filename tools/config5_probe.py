@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] (one wide layer, forward + backward in fp32 / bf16 / split bf16) alone: bench.config5_leg without the
+rest of bench.py.  CHEBGCN_LIB selects a library variant (tools/bbuild.sh)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import bench
+    from gcn_fmri_decoding_amd import graph, ops
+    dev = torch.device('cuda:0')
+    Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
+    L = Ls[0]
+    g = ops.Graph(graph.permute(L, graph.length_order(L)), dev)
+    out = bench.config5_leg(g, 64, 60, 5, 256, int(os.environ.get('STEPS', 10)))
+    for p in ('f32', 'bf16', 'bf16x3'):
+        leg = out[p]
+        print('%-7s %.3f ms/step  %s' % (p, leg['ms_per_step'], json.dumps(leg.get('rel_err_vs_f32'))))
+        for k, v in leg['kernels'].items():
+            print('      %-24s %.4f ms  %6.0f GB/s' % (k, v['avg_ms'], v['GBps']))
+
+
+if __name__ == '__main__':
+    main()

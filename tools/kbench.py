@@ -48,7 +48,7 @@ def main():
     import ctypes
     handle = ctypes.CDLL(_lib.LIB_PATH)
     tune = getattr(handle, 'chebgcn_tune', None)          # experiment builds only (tools/xbuild.sh, CHEBGCN_LIB=...)
-    if tune is None and (args.wide or args.stagger or args.stamps):
+    if tune is None and (args.wide or args.stagger or (args.stamps and not hasattr(handle, 'chebgcn_debug_stampsb'))):
         raise SystemExit('--wide / --stagger / --stamps need an experiment build (tools/xbuild.sh)')
     if tune is not None:
         tune(3, args.wide)
@@ -86,6 +86,7 @@ def main():
         bias = torch.randn(Fout, Mp, device=dev)
         out = torch.empty(B, Fout, Mp, device=dev)
         dy = torch.randn(B, Fout, Mp, device=dev)
+        dy16 = dy.to(torch.bfloat16)
         dbias = torch.empty(Fout, Mp, device=dev)
         dW = torch.empty(Fin * K, Fout, device=dev)
         ws = torch.empty(lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout), dtype=torch.uint8, device=dev)
@@ -137,6 +138,17 @@ def main():
             'contract_bwd_x_bf16x3': (lambda: lib.chebgcn_contract_bwd_x_bf16(P(dy), P(W), P(gstack), B, M, Fin, K, Fout, 3, P(wsx16),
                                                                               wsx16.numel(), st),
                                       4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            # wide bf16 layers: ReluGrad writes dy as bf16, the two gradients read it (same results as the fp32-dy entries above)
+            'relu_grad_bf16': (lambda: lib.chebgcn_relu_grad_bf16(P(dy), P(mask), P(dy16), P(dbias), 2, B, M, Fout, None, 0, st),
+                               B * Fout * M * 6.25, 0.0),
+            'brelu_pool_bwd_mask': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), None, P(mask), P(out), P(dbias), 2, B, M, Fout, 1, 0, 1,
+                                                                       None, 0, st), B * Fout * M * 8.25, 0.0),
+            'contract_bwd_w_bf16_dy16': (lambda: lib.chebgcn_contract_bwd_w_bf16_dy16(P(stack), P(dy16), P(dW), P(wsw16), wsw16.numel(),
+                                                                                      B, M, Fin, K, Fout, st),
+                                         4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
+            'contract_bwd_x_bf16_dy16': (lambda: lib.chebgcn_contract_bwd_x_bf16_dy16(P(dy16), P(W), P(gstack), B, M, Fin, K, Fout,
+                                                                                      P(wsx16), wsx16.numel(), st),
+                                         4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
             'brelu_pool_bwd': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), P(out), None, P(dx) if Fin == Fout else P(out),
                                                                   P(dbias), 2, B, M, Fout, 1, 0, 1, None, 0, st),
                                4.0 * B * Fout * 3 * M, 0.0),
@@ -149,17 +161,20 @@ def main():
                      'min_ms': best, 'GBps': nbytes / med / 1e6, 'frac_hbm': nbytes / med / 1e6 / 8000.0,
                      'TFLOPs': flops / med / 1e9}
                 results.append(r)
-                if args.stamps and name.startswith('recurrence'):
+                if args.stamps and (name.startswith('recurrence') or (hasattr(handle, 'chebgcn_debug_stampsb') and 'bf16' in name)):
                     buf = (ctypes.c_longlong * (16 * 64))()
-                    assert (handle.chebgcn_debug_stampso if g.query(12) else handle.chebgcn_debug_stamps4 if g.query(6) == 4 and g.query(7) > 2048 else handle.chebgcn_debug_stamps)(buf) == 0
+                    if not name.startswith('recurrence'):
+                        assert handle.chebgcn_debug_stampsb(buf) == 0       # tools/bbuild.sh x64 "-DCG_EXPERIMENT=1 -DCG_X=64"
+                    else:
+                        assert (handle.chebgcn_debug_stampso if g.query(12) else handle.chebgcn_debug_stamps4 if g.query(6) == 4 and g.query(7) > 2048 else handle.chebgcn_debug_stamps)(buf) == 0
                     t = np.array(buf, dtype=np.int64).reshape(16, 64)
-                    t0 = t[:, 0][t[:, 0] > 0].min()
+                    t0 = t[t > 0].min()
                     print('   stamps (cycle counter ticks since the first wave entered the group), one row per wave:')
                     ids = [i for i in range(64) if (t[:, i] > 0).any()]
                     print('   id   ' + ' '.join('%7d' % i for i in ids))
                     for w in range(16):
-                        if t[w, 0] > 0:
-                            print('   w%-3d ' % w + ' '.join('%7d' % (t[w, i] - t0) for i in ids))
+                        if (t[w] > 0).any():
+                            print('   w%-3d ' % w + ' '.join('%7d' % (t[w, i] - t0 if t[w, i] > 0 else -1) for i in ids))
                 print('%-16s B=%-4d abl=%-2d  %8.3f ms (min %7.3f)  %7.0f GB/s  %5.1f%% of 8 TB/s  %6.1f TFLOP/s   %s'
                       % (name, B, abl, med, best, r['GBps'], 100 * r['frac_hbm'], r['TFLOPs'], _lib.last_dispatch()), flush=True)
     if args.json:

@@ -13,7 +13,7 @@ python3 tools/kbench.py --planes 2 --B 64 256 --kernels recurrence_fwd recurrenc
 # the kernels of rounds 1-3 (the caller's vertex numbering: four planes at batch 256, two at batch 64) beside the ordered ones
 python3 tools/kbench.py --order reference --B 64 256 --kernels recurrence_fwd recurrence_fwd_inplace recurrence_bwd > $out/kbench_reference_order.txt 2>&1
 python3 tools/kbench.py --B 64 256 --fin 64 --K 25 --kernels recurrence_fwd_inplace recurrence_bwd --iters 30 > $out/kbench_config4.txt 2>&1
-python3 tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 --iters 10 > $out/kbench_config5.txt 2>&1
+python3 tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --kernels contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 brelu_pool_bwd_mask relu_grad_bf16 contract_bwd_w_bf16_dy16 contract_bwd_x_bf16_dy16 --iters 10 > $out/kbench_config5.txt 2>&1
 bash tools/pmc_traffic.sh refresh > $out/traffic.log 2>&1
 cp gpurun_out/traffic_refresh/traffic_raw.json $out/ 2>/dev/null
 bash tools/pmc_mfma.sh refresh > $out/mfma.txt 2>&1
@@ -36,7 +36,7 @@ for kern in recurrence_fwd_inplace recurrence_bwd; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof4 -o c4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 64 --fout 64 --K 25 --iters 10 --kernels contract_fwd contract_bwd_w contract_bwd_x > $out/prof4.log 2>&1
 find $out/prof4 -name "*kernel_stats.csv" -exec cp {} $out/config4_kernel_stats.csv \;
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -o c5 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 5 --kernels recurrence_fwd_inplace contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 > $out/prof5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof5 -o c5 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 64 --fin 60 --fout 256 --K 5 --iters 5 --kernels recurrence_fwd_inplace contract_fwd contract_fwd_bf16 contract_fwd_bf16x3 contract_bwd_w contract_bwd_w_bf16 contract_bwd_w_bf16x3 contract_bwd_x contract_bwd_x_bf16 contract_bwd_x_bf16x3 relu_grad_bf16 contract_bwd_w_bf16_dy16 contract_bwd_x_bf16_dy16 > $out/prof5.log 2>&1
 find $out/prof5 -name "*kernel_stats.csv" -exec cp {} $out/config5_kernel_stats.csv \;
 # the north-star shape (K = 5, Fin = 32, batch 256): one program per entry, so that the in-place forward, the forward with the
 # copy of x and the adjoint each have their own average (the first two are the same kernel)
