@@ -164,6 +164,7 @@ constexpr int RING = CG_FWD_RING;
 #ifndef CG_LB_RING
 #define CG_LB_RING 3
 #endif
+template <bool LEAN>       // LEAN: pool == 1, no out_K scatter (the launcher's choice): the row epilogue without the pooling variants
 __global__ void __launch_bounds__(256, CG_LB_RING)
 contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
     extern __shared__ __align__(16) unsigned char ring_smem[];
@@ -255,7 +256,11 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
     FwdArgs ae = a;                                  // the row epilogue below runs without a bias of its own
     ae.bias_kind = CHEBGCN_BIAS_NONE;
     // ---- epilogue: bias, relu, pool, store ----------------------------------------------
+    // pool == 1 (every layer of the benchmark network) takes a lean row: fwd_epilogue_row carries every pooling variant
+    // behind run-time branches, ~400 instructions per row in the binary
     float ms[4] = {0.f, 0.f, 0.f, 0.f};              // mean_out: sum over this lane's 16 filter rows (after bias + ReLU)
+    const float relu_floor = a.relu ? 0.f : -__builtin_inff();
+    const size_t mrow = (size_t)(a.Mpo >> 2);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int fo = acc_row(j, h);
@@ -270,7 +275,19 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
             v[2] += vb ? bb.z : (fbk && fo_ok) ? f : 0.f;
             v[3] += vb ? bb.w : (fbk && fo_ok) ? f : 0.f;
         }
-        fwd_epilogue_row(ae, b, fo, v, n0, valid, c);
+        if (LEAN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], relu_floor);
+            if (fo < a.Fout && valid) {
+                const size_t row = (size_t)b * a.Fout + fo;
+                if (a.out) *reinterpret_cast<float4*>(a.out + row * a.Mpo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.relu_mask)
+                    a.relu_mask[row * mrow + (n0 >> 2)] =
+                        (uint8_t)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
+            }
+        } else {
+            fwd_epilogue_row(ae, b, fo, v, n0, valid, c);
+        }
         if (j + RING < 16) bv[j % RING] = bias_row(j + RING);
         if (fo < a.Fout) { ms[0] += v[0]; ms[1] += v[1]; ms[2] += v[2]; ms[3] += v[3]; }
     }
@@ -913,8 +930,13 @@ extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const fl
         // whole ring rounds of row pairs; W and the row offsets of the padded rows in LDS (136 bytes per row)
         const int nrows_pad = ((a.FinK + 2 * RING - 1) / (2 * RING)) * (2 * RING);
         if ((size_t)nrows_pad * 136 <= 48 * 1024 && RING <= 8 && (bias_kind != CHEBGCN_BIAS_FILTER || Fout >= 4)) {
-            note_dispatch("contract_fwd_ring_kernel");
-            hipLaunchKernelGGL(contract_fwd_ring_kernel, grid, dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
+            if (a.pool == 1 && a.out_K == 0) {
+                note_dispatch("contract_fwd_ring_kernel");
+                hipLaunchKernelGGL(contract_fwd_ring_kernel<true>, grid, dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
+            } else {
+                note_dispatch("contract_fwd_ring_kernel<pool>");
+                hipLaunchKernelGGL(contract_fwd_ring_kernel<false>, grid, dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
+            }
             CG_HIP(hipGetLastError());
             return CHEBGCN_OK;
         }
@@ -953,7 +975,7 @@ extern "C" int chebgcn_contract_fwd_mean(const float* stack, const float* W, con
     a.slab = (size_t)B * Fin * a.Mp;
     const int nrows_pad = ring_rows(a.FinK);
     note_dispatch("contract_fwd_ring_kernel<mean>");
-    hipLaunchKernelGGL(contract_fwd_ring_kernel, dim3((M + 511) / 512, B, 1), dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
+    hipLaunchKernelGGL(contract_fwd_ring_kernel<true>, dim3((M + 511) / 512, B, 1), dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
