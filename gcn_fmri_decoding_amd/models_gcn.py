@@ -463,8 +463,20 @@ class base_model(object):
         streams like kernels, forked from and joined to the capture stream) and replayed with it; on other backends
         (gloo) the step stays eager.  While per-kernel event timers are set (``ops.timers``) the step runs eagerly too."""
         self._step_graph_on = bool(on)
-        self._sg = None
+        self._drop_step_graph()
         self._sg_warm = 0
+
+    def _drop_step_graph(self):
+        sg = getattr(self, '_sg', None)
+        if sg is not None and sg.get('cache_keys'):
+            ops.drop_cache_keys(sg['cache_keys'])       # scratch from the graph's private pool (ops.drop_cache_keys)
+        self._sg = None
+
+    def __del__(self):
+        try:
+            self._drop_step_graph()
+        except Exception:
+            pass
 
     def _train_step_graphed(self, x_storage, labels):
         x_storage = self._to_internal(x_storage)
@@ -476,6 +488,7 @@ class base_model(object):
                 loss_average = self._step_body(x_storage, labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
                 self.global_step += 1
                 return self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum), loss_average
+            self._drop_step_graph()
             sg = self._sg = self._capture_step(x_storage, labels)
         if sg['x'].data_ptr() != x_storage.data_ptr():
             sg['x'].copy_(x_storage)
@@ -498,9 +511,11 @@ class base_model(object):
             self._loss_ema = torch.zeros((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
+        before = ops.cache_keys()
         with torch.cuda.graph(graph):
             sg['loss_average'] = self._step_body(sg['x'], sg['labels'], sg['lr_t'], sg['ema_c'][0])
         sg['graph'] = graph
+        sg['cache_keys'] = ops.cache_keys() - before       # scratch allocated on the capture streams: it dies with this graph
         return sg
 
     def _apply_adam(self, grad_scale=1.0, lr_t=None):

@@ -277,6 +277,19 @@ def _mean_grad_buffer(B, Mp, device):
     return buf
 
 
+def cache_keys():
+    """Keys of the per-stream scratch caches above (workspaces, the fused last layer's gradient buffer)."""
+    return {('ws',) + k for k in _workspaces} | {('mg',) + k for k in _mean_grad_buffers}
+
+
+def drop_cache_keys(keys):
+    """Forget scratch buffers -- those a captured step allocated from its graph's private pool on its capture streams
+    (cgcnn.enable_step_graph records them): kept here they would pin that pool after the graph is gone, and a later capture
+    on the same stream would be handed a buffer of a destroyed graph."""
+    for k in keys:
+        (_workspaces if k[0] == 'ws' else _mean_grad_buffers).pop(tuple(k[1:]), None)
+
+
 def _brelu_bwd_ws(B, M, F, pool, bias_kind, device):
     """Scratch of chebgcn_brelu_pool_bwd: the per-workgroup partials of a per-filter (b1relu) bias gradient."""
     n = _lib.lib().chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, bias_kind)

@@ -23,6 +23,11 @@ bash tools/pmc_sq.sh refresh_ord --B 256 --iters 3 --kernels recurrence_fwd_inpl
 if [ -f build_x/libchebgcn_x64.so ]; then
   CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_x64.so python3 tools/kbench.py --B 256 --kernels recurrence_fwd_inplace recurrence_bwd --stamps > $out/stampso.txt 2>&1
 fi
+# the bf16 contraction kernels of config 5 (build_x/libchebgcn_b64.so: tools/bbuild.sh b64 "-DCG_EXPERIMENT=1 -DCG_X=64")
+if [ -f build_x/libchebgcn_b64.so ]; then
+  CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_b64.so python3 tools/kbench.py --stamps --B 64 --fin 60 --fout 256 --K 5 --iters 10 --kernels contract_fwd_bf16 contract_bwd_x_bf16_dy16 > $out/stampsb.txt 2>&1
+fi
+python3 tools/config5_probe.py > $out/config5_layer.txt 2>&1
 python3 tools/fused_check.py > $out/fused_small_check.txt 2>&1
 cp gpurun_out/pmcmfma_refresh/available.txt $out/mfma_counters_available.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
