@@ -33,6 +33,16 @@
 #include "contract_common.h"
 
 namespace chebgcn {
+#ifndef CG_X
+#define CG_X 0               // 64: in-kernel phase stamps (tools/fbuild.sh, tools/fused_check.py --stamps); 0 in production
+#endif
+__device__ long long g_dbgf[16 * 64];
+// workgroup 37: 0 start, 1 operator row in registers, 2 W in LDS, 3 input planes, 4 image of T_0, 5.. after each step, 40 results out
+#define CG_FSTAMP(id)                                                                         \
+    do {                                                                                      \
+        if ((CG_X & 64) && (id) < 64 && lane == 0 && blockIdx.x == 37)                        \
+            g_dbgf[wave * 64 + (id)] = (long long)__builtin_readcyclecounter();               \
+    } while (0)
 namespace {
 
 constexpr int FS_MAXLEN = 20;        // operator entries per row held in registers
@@ -80,6 +90,7 @@ fused_layer_kernel(FusedArgs a) {
     const int v = wave * 32 + c;
     const bool vok = v < a.M;
     const int Mq = a.Mp >> 2;
+    CG_FSTAMP(0);
     const int sp = NS > 1 ? (int)(blockIdx.x % NS) : 0;                      // uniform
     const int sp4 = 4 * sp;
     // A plane access is a UNIFORM base (window, slab, plane index without h: scalar registers) plus ONE per-lane offset (the h
@@ -113,6 +124,7 @@ fused_layer_kernel(FusedArgs a) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = max(lmax, __shfl_xor(lmax, d));
     const int lenw = __builtin_amdgcn_readfirstlane(lmax);          // the wave's longest row (uniform)
+    CG_FSTAMP(1);
 
     // ---- W -> LDS, arranged for the A operand of the product this kernel runs ---------------------------------------------
     // forward:  Ws[k][q][fout] = W[plane(q) * K + k][fout], q = i + PL h' the in-plane index of the B operand's lane half;
@@ -132,6 +144,7 @@ fused_layer_kernel(FusedArgs a) {
         Ws[idx] = (fin < a.Fin && fo < a.Fout) ? a.W[(size_t)(fin * a.K + k) * a.Fout + fo] : 0.f;
     }
     __syncthreads();
+    CG_FSTAMP(2);
 
     const unsigned hoff = (unsigned)h * (PL * 4u);
     const unsigned own = (unsigned)v * (FS_ROW * 4u) + hoff;                   // this lane's PL floats of the image
@@ -225,6 +238,7 @@ fused_layer_kernel(FusedArgs a) {
                 }
             }
         }
+        CG_FSTAMP(3);
         float cur[PL], prev[PL];
         f32x16 yacc;
 #pragma unroll
@@ -247,11 +261,13 @@ fused_layer_kernel(FusedArgs a) {
         }
         put_image(cur);
         __syncthreads();                                                  // the image of T_0 / c_{K-1}
+        CG_FSTAMP(4);
         for (int step = 1; step < a.K; ++step) {
             const bool last = step == a.K - 1;
             const float f = ADJ ? (last ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
             float g[PL];
             gather(g);
+            CG_FSTAMP(20 + step);
             float nw[PL];
             if (!ADJ) {
 #pragma unroll
@@ -276,6 +292,7 @@ fused_layer_kernel(FusedArgs a) {
                 yacc = product_fwd(step, cur, yacc);
             }
             if (!last) __syncthreads();                                   // the image of T_k / c_j
+            CG_FSTAMP(4 + step);
         }
         // ---- results --------------------------------------------------------------------------------------------------------
         if (!ADJ && NS > 1) {
@@ -314,6 +331,7 @@ fused_layer_kernel(FusedArgs a) {
             for (int i = 0; i < PL; ++i)
                 if (i < n) (dx + (size_t)ps<PL>(i) * mp)[lsoff] = cur[i];
         }
+        CG_FSTAMP(40);
         // (the next window overwrites the image: every gather of the last step is behind the barrier of that step; with
         // K = 1 nothing ever read the image)
     }
@@ -440,3 +458,9 @@ extern "C" int chebgcn_fused_layer_bwd_x(const chebgcn_graph* g, const float* do
     a.slab = (size_t)B * Fin * g->Mp;
     return fs_dispatch<true>(a, g->num_cus, fs_split(B, g->num_cus), (hipStream_t)stream_);
 }
+
+#ifdef CG_EXPERIMENT
+extern "C" int chebgcn_debug_stampsf(long long* out) {      // CG_X & 64 builds only (tools/fused_check.py --stamps)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(chebgcn::g_dbgf), sizeof(long long) * 16 * 64) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -350,6 +350,8 @@ def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K, ordered):
     recurrence, Fin=32, batch 256, M=10466 -- cheb4_kernel<10240,20,6,512,false/true>), checked at
     full size through what does not need a 1.7 GB oracle run:
     * planes drawn from all over the batch agree with the CPU oracle for every order k (1e-5);
+    * EVERY plane of every order, and every plane of the adjoint, against the same recurrence in float64 on the GPU
+      (torch.sparse, tied to the oracle on three planes at 1e-12): 1e-5 / 2e-5 of the plane's own maximum;
     * in place (T_0 already in slab 0, as the model runs it) and with the copy of x: the same bits;
     * the adjoint identity  sum_k <T_k(L~) x, G_k> = <x, recurrence_bwd(G)>  over ALL 8192 planes
       (float64 sums of fp32 results, 1e-5 of the magnitude sum);
@@ -398,12 +400,57 @@ def test_northstar_launch_properties(ops, dev, bench_graph, B, Fin, K, ordered):
         for k in range(K):
             close(stack[k, b, f, :M].cpu().numpy(), T[k], what='plane (%d,%d) order %d' % (b, f, k))
 
-    # adjoint identity over the whole launch
+    # EVERY plane and order against the same recurrence in float64 on the GPU (torch.sparse CSR x dense: an implementation that
+    # shares nothing with the library), after that float64 recurrence has itself been tied to the CPU oracle on the planes
+    # above; the bound holds PER PLANE (max over the plane's vertices), not for the tensor as a whole
+    L64 = Lr.astype(np.float64).tocsr()
+    Ld = torch.sparse_csr_tensor(torch.as_tensor(L64.indptr.astype(np.int64)), torch.as_tensor(L64.indices.astype(np.int64)),
+                                 torch.as_tensor(L64.data), size=L64.shape).to(dev)
+    X = x[:, :, :M].double().reshape(B * Fin, M).t().contiguous()                       # [M, planes]
+    T64 = [X, torch.sparse.mm(Ld, X)]
+    for k in range(2, K):
+        T64.append(2 * torch.sparse.mm(Ld, T64[-1]) - T64[-2])
+    for (b, f) in [(0, 0), (B // 2, 5), (B - 1, Fin - 1)]:
+        xv = x[b, f, :M].cpu().numpy().astype(np.float64)
+        t0, t1 = xv, L64 @ xv
+        for k in range(2, K):
+            t0, t1 = t1, 2 * (L64 @ t1) - t0
+        ref = t1 if K > 1 else t0
+        got = T64[K - 1][:, b * Fin + f].cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), 'float64 torch recurrence differs from the oracle'
+    worst = 0.0
+    for k in range(K):
+        got = stack[k, :, :, :M].reshape(B * Fin, M).double()
+        ref = T64[k].t()
+        per_plane = (got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
+        worst = max(worst, float(per_plane.max()))
+        assert float(per_plane.max()) <= REL, 'order %d: plane %d is %.3e from float64' % (k, int(per_plane.argmax()), float(per_plane.max()))
+    del X
+
+    # adjoint over the whole launch: every plane of dx against the float64 Clenshaw recurrence with L~^T
     G = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
     G[:, :, :, M:] = float('nan')
     dx = torch.empty((B, Fin, Mp), device=dev)
     _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, st), 'bwd')
     assert torch.isfinite(dx[:, :, :M]).all()
+    LT64 = L64.T.tocsr()
+    LTd = torch.sparse_csr_tensor(torch.as_tensor(LT64.indptr.astype(np.int64)), torch.as_tensor(LT64.indices.astype(np.int64)),
+                                  torch.as_tensor(LT64.data), size=LT64.shape).to(dev)
+    Gk = lambda k: G[k, :, :, :M].double().reshape(B * Fin, M).t().contiguous()
+    if K == 1:
+        dref = Gk(0)
+    else:
+        c2, c1 = torch.zeros_like(Gk(0)), Gk(K - 1)                                     # c_{j+2}, c_{j+1}
+        for j in range(K - 2, 0, -1):
+            c2, c1 = c1, Gk(j) + 2 * torch.sparse.mm(LTd, c1) - c2
+        dref = Gk(0) + torch.sparse.mm(LTd, c1) - c2
+    gotx = dx[:, :, :M].reshape(B * Fin, M).double()
+    per_plane = (gotx - dref.t()).abs().amax(dim=1) / dref.t().abs().amax(dim=1)
+    from conftest import record_measured
+    record_measured('northstar_launch_every_plane[%d,%d,%d,%s]' % (B, Fin, K, 'ordered' if ordered else 'reference'),
+                    fwd_worst_plane=worst, adjoint_worst_plane=float(per_plane.max()), planes=B * Fin)
+    assert float(per_plane.max()) <= 2e-5, 'adjoint: plane %d is %.3e from float64' % (int(per_plane.argmax()), float(per_plane.max()))
+    del dref, c1, c2
     lhs = float((stack[:, :, :, :M].double() * G[:, :, :, :M].double()).sum())
     rhs = float((x[:, :, :M].double() * dx[:, :, :M].double()).sum())
     mag = float((stack[:, :, :, :M].double() * G[:, :, :, :M].double()).abs().sum())

@@ -105,6 +105,23 @@ def main():
             t_bf = timeit(lambda: lib.chebgcn_fused_layer_bwd_x(g.handle, P(dout), P(mask_r), P(W), P(dx), B, Fin, K, Fout, st))
             print('   us: forward separate %.1f, fused with stack %.1f, fused without %.1f;  backward-x separate %.1f, fused %.1f' % (
                 t_sep, t_f1, t_f0, t_bs, t_bf), flush=True)
+            import ctypes
+            handle = ctypes.CDLL(_lib.LIB_PATH)
+            if hasattr(handle, 'chebgcn_debug_stampsf'):                 # tools/fbuild.sh f64 "-DCG_EXPERIMENT=1 -DCG_X=64"
+                for what, fn in (('forward with stack', lambda: lib.chebgcn_fused_layer_fwd(g.handle, P(x), P(W), P(bias), bias_kind, P(stack), P(out), P(mask), P(ws), nws, B, Fin, K, Fout, relu, st)),
+                                 ('backward', lambda: lib.chebgcn_fused_layer_bwd_x(g.handle, P(dout), P(mask_r), P(W), P(dx), B, Fin, K, Fout, st))):
+                    fn()
+                    torch.cuda.synchronize()
+                    buf = (ctypes.c_longlong * (16 * 64))()
+                    assert handle.chebgcn_debug_stampsf(buf) == 0
+                    t = np.array(buf, dtype=np.int64).reshape(16, 64)
+                    t0 = t[t > 0].min()
+                    ids = [i for i in range(64) if (t[:, i] > 0).any()]
+                    print('   stamps, %s (0 start, 1 row, 2 W in LDS, 3 input, 4 image of T_0, 5.. end of step, 21.. after the gather of a step, 40 results out):' % what)
+                    print('   id   ' + ' '.join('%6d' % i for i in ids))
+                    for w in range(16):
+                        if (t[w] > 0).any():
+                            print('   w%-3d ' % w + ' '.join('%6d' % (t[w, i] - t0 if t[w, i] > 0 else -1) for i in ids))
 
 
 if __name__ == '__main__':
