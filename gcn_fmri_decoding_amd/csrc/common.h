@@ -72,6 +72,10 @@ struct Ell {
     int32_t* rowptr = nullptr;    // [M+1]
     int32_t* col32 = nullptr;     // [nnz]
     float* cval = nullptr;        // [nnz]
+    // atlas-sized graphs (fused_small.hip): one 128-byte record per vertex, [Mp][32] dwords -- 0..9 the row's neighbour vertices
+    // two per dword (16 bits each, caller's entry order), 10 the row length, 12..31 the values -- so that a lane has its whole
+    // operator row after ONE memory round trip (through the row pointers it takes two); NULL where rows are longer than 20 entries
+    uint32_t* fs_rec = nullptr;
 };
 
 // what the on-chip kernels take by value

@@ -45,12 +45,13 @@ __device__ long long g_dbgf[16 * 64];
     } while (0)
 namespace {
 
-constexpr int FS_MAXLEN = 20;        // operator entries per row held in registers
+constexpr int FS_MAXLEN = 20;        // operator entries per row held in registers (template parameter ML: 16 where the graph's rows allow --
+                                     // six registers that the twelve-wave kernels otherwise spill)
 // floats per vertex row of the LDS image: the planes of the workgroup + 4 (16-byte aligned, 4 x an odd number)
 __host__ __device__ constexpr int fs_row(int PL) { return 2 * PL + 4; }
 
 struct FusedArgs {
-    const int32_t* rowptr; const int32_t* col; const float* val;     // CSR of the operator (forward: L~, backward: L~^T)
+    const uint32_t* rec;         // per-vertex operator records [Mp][32] (common.h Ell::fs_rec; forward: L~, backward: L~^T)
     const float* in;             // forward: x [B][Fin][Mp];  backward: dout [B][Fout][Mp]
     const float* W;              // [Fin*K][Fout]
     const float* bias;           // forward only
@@ -61,6 +62,9 @@ struct FusedArgs {
     size_t slab;                 // B*Fin*Mp
 };
 
+// workgroup barrier for LDS traffic only: __syncthreads() also waits for every global store in flight (s_waitcnt vmcnt(0)) --
+// the stack rows of a step would be acknowledged by memory before the next gather could start
+__device__ __forceinline__ void fs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n s_barrier" ::: "memory"); }
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int fs_opq(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ int fs_ops(int x) { asm volatile("" : "+s"(x)); return x; }
@@ -75,7 +79,7 @@ template <int PL> constexpr int pls = PL == 16 ? 4 : 8;
 
 // NW waves = 32*NW vertices.  PL = planes per lane: 16 (one workgroup per window) or 8 (two).  ADJ = false: the layer forward;
 // true: its gradient wrt the input.
-template <int NW, int PL, bool ADJ>
+template <int NW, int PL, bool ADJ, int ML>
 __global__ void __launch_bounds__(NW * 64)
 fused_layer_kernel(FusedArgs a) {
     constexpr int FS_ROW = fs_row(PL);
@@ -108,41 +112,77 @@ fused_layer_kernel(FusedArgs a) {
     for (int i = 0; i < PL; ++i) nst_fin += (ps<PL>(i) + pls<PL> * h + sp4 < a.Fin) ? 1 : 0;
     const int nv_fout = vok ? nacc_fout : 0, nv_fin = vok ? nst_fin : 0;
 
-    // ---- this vertex's operator row -> registers (neighbour vertices two per register, values) --------------------------
-    unsigned ec[FS_MAXLEN / 2];
-    float ev[FS_MAXLEN];
-    const int rp = vok ? a.rowptr[v] : 0;
-    const int len = vok ? a.rowptr[v + 1] - rp : 0;
+    // ---- prologue: this vertex's operator row -> registers, W -> LDS ------------------------------------------------------------
+    // Memory round trips, not bytes, are what the prologue costs (phase stamps: 14-20k of a launch's 80-98k cycles with one load
+    // per round trip): the row pointers and the first batch of W are requested together, the row's entries as soon as the
+    // pointers are back, and W moves in batches of WU loads per thread.
+    // forward:  Ws[k][q][fout] = W[plane(q) * K + k][fout], q = i + PL h' the in-plane index of the B operand's lane half;
+    // backward: Ws[j][fo][row] = W[fin(row) * K + j][fo], row = accumulator row, fin(row) = the state plane of the lane (row's
+    //           half) and register (row's pattern index mod PL) that receives it.  Global reads run along fo in both (one 128-byte
+    //           line per 32 lanes); the backward image is written transposed.
+    constexpr int WU = 8;
+    const int nW = a.K * 1024;
+    auto w_src = [&](int idx, int& dst) -> const float* {
+        const int k = idx >> 10, r = (idx >> 5) & 31, q = idx & 31;          // q = fo: the fastest index of the global read
+        int fin;
+        if (!ADJ) {
+            fin = r < 2 * PL ? ps<PL>(r % PL) + pls<PL> * (r / PL) + sp4 : 1 << 20;
+            dst = idx;
+        } else {
+            const int rh = (r >> 2) & 1, ri = (r & 3) + 4 * (r >> 3);            // row r = pu(ri) + 4 rh
+            fin = ps<PL>(ri % PL) + pls<PL> * rh + sp4;
+            dst = (k << 10) + (q << 5) + r;
+        }
+        return (fin < a.Fin && q < a.Fout) ? a.W + (size_t)(fin * a.K + k) * a.Fout + q : nullptr;
+    };
+    auto w_batch_load = [&](int base, float (&wv)[WU]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int e = 0; e < FS_MAXLEN; ++e) {
-        const bool live = e < len;
-        const unsigned ci = live ? (unsigned)a.col[rp + e] : 0u;
-        if (e & 1) ec[e >> 1] |= ci << 16; else ec[e >> 1] = ci;
-        ev[e] = live ? a.val[rp + e] : 0.f;
+        for (int u = 0; u < WU; ++u) {
+            int dst;
+            const int idx = base + u * NW * 64;
+            const float* p = idx < nW ? w_src(idx, dst) : nullptr;
+            const float t = *(p ? p : a.W);                                // (unconditional: a branch per load is a round trip per load)
+            wv[u] = p ? t : 0.f;
+        }
+    };
+    auto w_batch_store = [&](int base, const float (&wv)[WU]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            int dst = 0;
+            const int idx = base + u * NW * 64;
+            if (idx < nW) { w_src(idx, dst); Ws[dst] = wv[u]; }
+        }
+    };
+    // the vertex's record (one 128-byte line: neighbour pairs, length, values) and two batches of W: one round trip for all
+    float wv0[WU], wv1[WU];
+    w_batch_load(threadIdx.x, wv0);
+    w_batch_load(threadIdx.x + WU * NW * 64, wv1);
+    const uint32_t* rec = a.rec + (size_t)(vok ? v : 0) * 32;
+    unsigned ec[ML / 2];
+    float ev[ML];
+#pragma unroll
+    for (int e = 0; e < ML / 2; ++e) ec[e] = rec[e];
+#pragma unroll
+    for (int e = 0; e < ML; ++e) ev[e] = __builtin_bit_cast(float, rec[12 + e]);
+    const int len = vok ? (int)rec[10] : 0;
+    if (!vok) {
+#pragma unroll
+        for (int e = 0; e < ML / 2; ++e) ec[e] = 0u;
+#pragma unroll
+        for (int e = 0; e < ML; ++e) ev[e] = 0.f;
+    }
+    w_batch_store(threadIdx.x, wv0);
+    w_batch_store(threadIdx.x + WU * NW * 64, wv1);
+    for (int base = threadIdx.x + 2 * WU * NW * 64; base < nW; base += WU * NW * 64) {
+        float wv[WU];
+        w_batch_load(base, wv);
+        w_batch_store(base, wv);
     }
     int lmax = len;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) lmax = max(lmax, __shfl_xor(lmax, d));
     const int lenw = __builtin_amdgcn_readfirstlane(lmax);          // the wave's longest row (uniform)
     CG_FSTAMP(1);
-
-    // ---- W -> LDS, arranged for the A operand of the product this kernel runs ---------------------------------------------
-    // forward:  Ws[k][q][fout] = W[plane(q) * K + k][fout], q = i + PL h' the in-plane index of the B operand's lane half;
-    // backward: Ws[j][fo][row] = W[fin(row) * K + j][fo], row = accumulator row, fin(row) = the state plane of the lane (row's
-    //           half) and register (row's pattern index mod PL) that receives it.
-    for (int idx = threadIdx.x; idx < a.K * 1024; idx += NW * 64) {
-        const int k = idx >> 10, r = (idx >> 5) & 31, q = idx & 31;
-        int fin, fo;
-        if (!ADJ) {
-            fo = q;
-            fin = r < 2 * PL ? ps<PL>(r % PL) + pls<PL> * (r / PL) + sp4 : 1 << 20;
-        } else {
-            fo = r;
-            const int rh = (q >> 2) & 1, ri = (q & 3) + 4 * (q >> 3);            // q = pu(ri) + 4 rh
-            fin = ps<PL>(ri % PL) + pls<PL> * rh + sp4;
-        }
-        Ws[idx] = (fin < a.Fin && fo < a.Fout) ? a.W[(size_t)(fin * a.K + k) * a.Fout + fo] : 0.f;
-    }
     __syncthreads();
     CG_FSTAMP(2);
 
@@ -162,7 +202,7 @@ fused_layer_kernel(FusedArgs a) {
 #pragma unroll
         for (int i = 0; i < PL; ++i) g[i] = 0.f;
 #pragma unroll
-        for (int e0 = 0; e0 < FS_MAXLEN; e0 += EC) {
+        for (int e0 = 0; e0 < ML; e0 += EC) {
             if (e0 < lenw) {                                             // uniform: no divergence, no LDS reads beyond the wave's rows
                 float4 t[EC][PL / 4];
 #pragma unroll
@@ -253,31 +293,33 @@ fused_layer_kernel(FusedArgs a) {
                 for (int i = 0; i < PL; ++i)
                     if (i < n) (s0 + (size_t)ps<PL>(i) * mp)[lsoff] = cur[i];
             }
-            yacc = product_fwd(0, cur, yacc);
         } else {
             const f32x16 g0 = product_bwd(a.K - 1, in);                  // c_{K-1} = G_{K-1} = W_{K-1} dy
 #pragma unroll
             for (int i = 0; i < PL; ++i) { cur[i] = g0[i]; prev[i] = 0.f; }
         }
         put_image(cur);
-        __syncthreads();                                                  // the image of T_0 / c_{K-1}
+        fs_barrier();                                                     // the image of T_0 / c_{K-1}
         CG_FSTAMP(4);
         for (int step = 1; step < a.K; ++step) {
             const bool last = step == a.K - 1;
             const float f = ADJ ? (last ? 1.f : 2.f) : (step == 1 ? 1.f : 2.f);
+            // the matrix instructions of a step are issued IN FRONT of the gather they do not depend on (forward: T_{k-1} x
+            // W_{k-1}; backward: G_j = W_j dy, taken into `prev`): the matrix pipe works while the wave gathers
+            if (!ADJ) {
+                yacc = product_fwd(step - 1, cur, yacc);
+            } else {
+                const f32x16 gj = product_bwd(a.K - 1 - step, in);       // G_j = W_j dy
+#pragma unroll
+                for (int i = 0; i < PL; ++i) prev[i] = gj[i] - prev[i];
+            }
             float g[PL];
             gather(g);
             CG_FSTAMP(20 + step);
             float nw[PL];
-            if (!ADJ) {
 #pragma unroll
-                for (int i = 0; i < PL; ++i) nw[i] = fmaf(f, g[i], -prev[i]);
-            } else {
-                const f32x16 gj = product_bwd(a.K - 1 - step, in);       // G_j = W_j dy
-#pragma unroll
-                for (int i = 0; i < PL; ++i) nw[i] = fmaf(f, g[i], gj[i] - prev[i]);
-            }
-            __syncthreads();                                              // every gather of this step has read the image
+            for (int i = 0; i < PL; ++i) nw[i] = ADJ ? fmaf(f, g[i], prev[i]) : fmaf(f, g[i], -prev[i]);
+            fs_barrier();                                                 // every gather of this step has read the image
             if (!last) put_image(nw);
 #pragma unroll
             for (int i = 0; i < PL; ++i) { prev[i] = cur[i]; cur[i] = nw[i]; }
@@ -289,11 +331,11 @@ fused_layer_kernel(FusedArgs a) {
                     for (int i = 0; i < PL; ++i)
                         if (i < n) (sk + (size_t)ps<PL>(i) * mp)[lsoff] = cur[i];
                 }
-                yacc = product_fwd(step, cur, yacc);
             }
-            if (!last) __syncthreads();                                   // the image of T_k / c_j
+            if (!last) fs_barrier();                                      // the image of T_k / c_j
             CG_FSTAMP(4 + step);
         }
+        if (!ADJ) yacc = product_fwd(a.K - 1, cur, yacc);
         // ---- results --------------------------------------------------------------------------------------------------------
         if (!ADJ && NS > 1) {
             // half of the sum over the input planes: raw, for fused_combine_kernel ([half][B][32][Mp]; rows beyond Fout are zero)
@@ -375,10 +417,10 @@ int fs_waves(int Mp) { return Mp <= 256 ? 8 : Mp <= 384 ? 12 : 0; }
 int fs_split(int B, int cus) { return 2 * B <= cus + cus / 2 ? 2 : 1; }
 size_t fs_lds(int nw, int PL, int K) { return ((size_t)32 * nw * fs_row(PL) + (size_t)K * 1024) * sizeof(float); }
 
-template <int NW, int PL, bool ADJ>
+template <int NW, int PL, bool ADJ, int ML>
 int fs_launch(const FusedArgs& a, int cus, hipStream_t stream) {
     const size_t lds = fs_lds(NW, PL, a.K);
-    CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_kernel<NW, PL, ADJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_layer_kernel<NW, PL, ADJ, ML>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
     static const std::string name = "fused_layer_kernel<" + std::to_string(NW) + "," + std::to_string(PL) + "," + (ADJ ? "true" : "false") + ">";
     note_dispatch(name.c_str());
@@ -388,17 +430,21 @@ int fs_launch(const FusedArgs& a, int cus, hipStream_t stream) {
     slots -= slots % NS;
     const int want = a.B * NS;
     const int grid = want < slots ? want : slots;
-    hipLaunchKernelGGL((fused_layer_kernel<NW, PL, ADJ>), dim3(grid), dim3(NW * 64), lds, stream, a);
+    hipLaunchKernelGGL((fused_layer_kernel<NW, PL, ADJ, ML>), dim3(grid), dim3(NW * 64), lds, stream, a);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }
 
-template <bool ADJ>
-int fs_dispatch(const FusedArgs& a, int cus, int split, hipStream_t stream) {
+template <bool ADJ, int ML>
+int fs_dispatch_ml(const FusedArgs& a, int cus, int split, hipStream_t stream) {
     const int nw = fs_waves(a.Mp);
-    if (nw == 8) return split == 2 ? fs_launch<8, 8, ADJ>(a, cus, stream) : fs_launch<8, 16, ADJ>(a, cus, stream);
-    if (nw == 12) return split == 2 ? fs_launch<12, 8, ADJ>(a, cus, stream) : fs_launch<12, 16, ADJ>(a, cus, stream);
+    if (nw == 8) return split == 2 ? fs_launch<8, 8, ADJ, ML>(a, cus, stream) : fs_launch<8, 16, ADJ, ML>(a, cus, stream);
+    if (nw == 12) return split == 2 ? fs_launch<12, 8, ADJ, ML>(a, cus, stream) : fs_launch<12, 16, ADJ, ML>(a, cus, stream);
     return fail(CHEBGCN_EUNSUPPORTED, "fused layer: %d vertices", a.M);
+}
+template <bool ADJ>
+int fs_dispatch(const FusedArgs& a, int cus, int split, int max_len, hipStream_t stream) {
+    return max_len <= 16 ? fs_dispatch_ml<ADJ, 16>(a, cus, split, stream) : fs_dispatch_ml<ADJ, FS_MAXLEN>(a, cus, split, stream);
 }
 
 }  // namespace
@@ -410,7 +456,7 @@ extern "C" int chebgcn_fused_layer_supported(const chebgcn_graph* g, int B, int 
     if (!g || B <= 0 || Fin <= 0 || K <= 0 || Fout <= 0 || Fin > 32 || Fout > 32) return 0;
     const int nw = fs_waves(g->Mp);
     if (nw == 0 || !g->lds_ok) return 0;
-    if (g->fwd.max_len > FS_MAXLEN || g->adj.max_len > FS_MAXLEN) return 0;
+    if (g->fwd.max_len > FS_MAXLEN || g->adj.max_len > FS_MAXLEN || !g->fwd.fs_rec || !g->adj.fs_rec) return 0;
     if (fs_lds(nw, 16, K) > 160 * 1024) return 0;
     return 1;
 }
@@ -432,12 +478,12 @@ extern "C" int chebgcn_fused_layer_fwd(const chebgcn_graph* g, const float* x, c
     CG_REQUIRE(split == 1 || (workspace && workspace_bytes >= chebgcn_fused_layer_workspace(g, B, Fin, K, Fout)),
                "fused_layer_fwd: workspace of chebgcn_fused_layer_workspace() bytes needed");
     FusedArgs a;
-    a.rowptr = g->fwd.rowptr; a.col = g->fwd.col32; a.val = g->fwd.cval;
+    a.rec = g->fwd.fs_rec;
     a.in = x; a.W = W; a.bias = bias; a.stack = stack; a.out = split == 2 ? (float*)workspace : out;
     a.mask = relu ? relu_mask : nullptr;
     a.B = B; a.M = g->M; a.Mp = g->Mp; a.Fin = Fin; a.K = K; a.Fout = Fout; a.relu = relu; a.bias_kind = bias_kind;
     a.slab = (size_t)B * Fin * g->Mp;
-    const int rc = fs_dispatch<false>(a, g->num_cus, split, stream);
+    const int rc = fs_dispatch<false>(a, g->num_cus, split, g->fwd.max_len, stream);
     if (rc != CHEBGCN_OK || split == 1) return rc;
     note_dispatch_more("fused_combine_kernel");
     hipLaunchKernelGGL(fused_combine_kernel, dim3((g->Mp / 4 + 255) / 256, Fout, B), dim3(256), 0, stream, (const float*)workspace, bias,
@@ -452,11 +498,11 @@ extern "C" int chebgcn_fused_layer_bwd_x(const chebgcn_graph* g, const float* do
     if (!chebgcn_fused_layer_supported(g, B, Fin, K, Fout))
         return fail(CHEBGCN_EUNSUPPORTED, "fused_layer_bwd_x: shape not served (chebgcn_fused_layer_supported)");
     FusedArgs a;
-    a.rowptr = g->adj.rowptr; a.col = g->adj.col32; a.val = g->adj.cval;
+    a.rec = g->adj.fs_rec;
     a.in = dout; a.W = W; a.bias = nullptr; a.stack = nullptr; a.out = dx; a.mask = const_cast<uint8_t*>(relu_mask);
     a.B = B; a.M = g->M; a.Mp = g->Mp; a.Fin = Fin; a.K = K; a.Fout = Fout; a.relu = 0; a.bias_kind = CHEBGCN_BIAS_NONE;
     a.slab = (size_t)B * Fin * g->Mp;
-    return fs_dispatch<true>(a, g->num_cus, fs_split(B, g->num_cus), (hipStream_t)stream_);
+    return fs_dispatch<true>(a, g->num_cus, fs_split(B, g->num_cus), g->adj.max_len, (hipStream_t)stream_);
 }
 
 #ifdef CG_EXPERIMENT

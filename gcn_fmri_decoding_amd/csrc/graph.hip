@@ -2,6 +2,7 @@
 // sliced-ELL images (for the on-chip recurrence) plus plain CSR (fallback path).
 // Replaces the constant tf.SparseTensor of lib_new/models_gcn.py:593-596.
 #include <algorithm>
+#include <cstring>
 #include <new>
 #include <numeric>
 #include <string.h>
@@ -56,7 +57,7 @@ static int upload(T** dst, const std::vector<T>& src) {
 }
 
 static void free_ell(Ell& e) {
-    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval, e.uval, e.uids, e.blkmap};
+    void* ptrs[] = {e.ginfo, e.colq, e.colo, e.valq, e.valp, e.rowslot, e.nodeslot, e.rowptr, e.col32, e.cval, e.uval, e.uids, e.blkmap, e.fs_rec};
     for (void* p : ptrs) (void)hipFree(p);
     e = Ell();
 }
@@ -152,6 +153,25 @@ static void place_group(int planes, const int (&rows)[64], int q0, int L, const 
             *cost_ideal += 1;
         }
     }
+}
+
+// per-vertex operator records of the fused atlas-size layer (common.h Ell::fs_rec); rows of more than 20 entries: none
+static int build_fs_records(int M, int Mp, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& col,
+                            const std::vector<float>& val, Ell* out) {
+    std::vector<uint32_t> rec((size_t)Mp * 32, 0u);
+    for (int v = 0; v < M; ++v) {
+        const int len = rowptr[v + 1] - rowptr[v];
+        if (len > 20) return CHEBGCN_OK;
+        uint32_t* r = &rec[(size_t)v * 32];
+        for (int e = 0; e < len; ++e) {
+            const uint32_t c = (uint32_t)col[rowptr[v] + e];
+            r[e >> 1] |= (e & 1) ? c << 16 : c;
+            const float w = val[rowptr[v] + e];
+            std::memcpy(&r[12 + e], &w, 4);
+        }
+        r[10] = (uint32_t)len;
+    }
+    return upload(&out->fs_rec, rec);
 }
 
 // CSR (host) -> device Ell.  Entry order inside a row is NOT the caller's: positions are chosen
@@ -563,6 +583,10 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
         rc = build_ell(M, g->Mp, 2, active, rp, ci, va, &g->fwd2);
         if (rc == CHEBGCN_OK) rc = build_ell(M, g->Mp, 2, active, trp, tci, tva, &g->adj2);
         g->has_alt2 = rc == CHEBGCN_OK;
+    }
+    if (rc == CHEBGCN_OK && g->Mp <= 384) {
+        rc = build_fs_records(M, g->Mp, rp, ci, va, &g->fwd);
+        if (rc == CHEBGCN_OK) rc = build_fs_records(M, g->Mp, trp, tci, tva, &g->adj);
     }
     // rows of L~ and of L~^T sorted by descending length (the caller relabelled the vertices: graph.length_order in the
     // Python host), isolated vertices last: the ordered images
