@@ -223,6 +223,50 @@ fc_bwd_x_kernel(const float* __restrict__ g, const float* __restrict__ y, const 
 
 }  // namespace chebgcn
 
+namespace chebgcn {
+// Softmax cross-entropy of the logits and its gradient in one launch (tf.nn.sparse_softmax_cross_entropy_with_logits +
+// tf.reduce_mean, models_gcn.py:257-259, and what TensorFlow's autodiff derives for them):
+//   loss = mean_b( logsumexp(z_b) - z_b[y_b] ),   dz[b][c] = (softmax(z_b)[c] - [c == y_b]) / B.
+// One workgroup: thread t takes the rows t, t + 256, ... in order, the 256 partial sums are added in a fixed tree --
+// deterministic.  (torch's cross_entropy + backward are six launches; at the reference's shapes the head of the step is
+// launch-bound.)
+template <typename LabelT>
+__global__ void __launch_bounds__(256)
+softmax_xent_kernel(const float* __restrict__ z, const LabelT* __restrict__ y, float* __restrict__ loss,
+                    float* __restrict__ dz, int B, int C) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* row = z + (size_t)b * C;
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+        long long t = (long long)y[b];
+        t = t < 0 ? 0 : t >= C ? C - 1 : t;                   // (a label outside [0, C) is the caller's error: clamped, not read past the row)
+        float s = 0.f, so = 0.f;                              // all classes; all but the labelled one
+        for (int c = 0; c < C; ++c) {
+            const float e = expf(row[c] - m);
+            s += e;
+            so += c == t ? 0.f : e;
+        }
+        // -log softmax at the labelled class = log(1 + so / e_t): no cancellation when the prediction is confident and right
+        const float et = expf(row[t] - m);
+        acc += et > 1e-30f ? log1pf(so / et) : logf(s) - (row[t] - m);
+        const float inv = invB / s;
+        float* drow = dz + (size_t)b * C;
+        // softmax - 1 at the labelled class is -(sum of the others) / s: no cancellation when the prediction is confident
+        for (int c = 0; c < C; ++c) drow[c] = c == t ? -so * inv : expf(row[c] - m) * inv;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = part[0] * invB;
+}
+}  // namespace chebgcn
+
 using namespace chebgcn;
 
 // splits of the reduction across workgroups: enough workgroups for two per CU, at least 64 chunks (512 input features) each
@@ -284,6 +328,22 @@ extern "C" int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const
         else
             hipLaunchKernelGGL(fc_bwd_x_kernel<false>, grid, dim3(FC_WAVES * 64), 0, stream, g, y, W, dx, (long long)lddx, B, I, O);
     }
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_softmax_xent(const float* logits, const void* labels, int labels_int64, float* loss, float* dlogits,
+                                    int B, int C, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(logits && labels && loss && dlogits, "softmax_xent: NULL argument");
+    CG_REQUIRE(B > 0 && C > 0, "softmax_xent: bad shape");
+    note_dispatch(labels_int64 ? "softmax_xent_kernel<int64>" : "softmax_xent_kernel<int32>");
+    if (labels_int64)
+        hipLaunchKernelGGL(softmax_xent_kernel<long long>, dim3(1), dim3(256), 0, stream, logits, (const long long*)labels, loss,
+                           dlogits, B, C);
+    else
+        hipLaunchKernelGGL(softmax_xent_kernel<int32_t>, dim3(1), dim3(256), 0, stream, logits, (const int32_t*)labels, loss,
+                           dlogits, B, C);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

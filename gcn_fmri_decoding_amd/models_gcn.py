@@ -432,14 +432,15 @@ class base_model(object):
         if self._dp is not None:
             self._dp.begin_step()
         logits = self._inference_storage(x_storage, self.dropout)
-        cross_entropy = Fnn.cross_entropy(logits, labels.long())
-        cross_entropy.backward()
+        # loss and d(loss)/d(logits) in one launch; autograd starts from the logits
+        cross_entropy, dlogits = ops.softmax_xent(logits, labels)
+        logits.backward(dlogits)
         grad_scale = 1.0
         if self._dp is not None:
             grad_scale = self._dp.finish_step()
         with torch.no_grad():       # the loss of this step is evaluated on the pre-update variables
             v = self._flat[:self._n_reg]
-            loss = torch.add(cross_entropy.detach(), torch.dot(v, v), alpha=0.5 * self.regularization)   # + reg * sum l2_loss
+            loss = torch.add(cross_entropy, torch.dot(v, v), alpha=0.5 * self.regularization)   # + reg * sum l2_loss
         self._apply_adam(grad_scale, lr_t)
         with torch.no_grad():
             # tf.train.ExponentialMovingAverage(0.9) over a Tensor: zero-initialised shadow,

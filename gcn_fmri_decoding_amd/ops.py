@@ -277,6 +277,25 @@ def _mean_grad_buffer(B, Mp, device):
     return buf
 
 
+def softmax_xent(logits, labels):
+    """Mean softmax cross-entropy of ``logits [B, C]`` against ``labels [B]`` (int32 or int64) and its gradient wrt the
+    logits, one launch (tf.nn.sparse_softmax_cross_entropy_with_logits + tf.reduce_mean, models_gcn.py:257-259).  Returns
+    (loss: 0-d tensor, dlogits [B, C]); the caller seeds autograd with ``logits.backward(dlogits)``."""
+    _require_cuda(logits, labels)
+    if logits.dim() != 2 or logits.dtype != torch.float32 or labels.dim() != 1 or labels.numel() != logits.shape[0]:
+        raise ValueError('softmax_xent: logits [B, C] float32 and labels [B]')
+    if labels.dtype not in (torch.int32, torch.int64):
+        labels = labels.long()
+    z = logits.detach().contiguous()
+    labels = labels.contiguous()
+    B, C = z.shape
+    loss = torch.empty((), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z)
+    _lib.check(_lib.lib().chebgcn_softmax_xent(_p(z), _p(labels), int(labels.dtype == torch.int64), _p(loss), _p(dz), B, C,
+                                               _stream()), 'softmax_xent')
+    return loss, dz
+
+
 def cache_keys():
     """Keys of the per-stream scratch caches above (workspaces, the fused last layer's gradient buffer)."""
     return {('ws',) + k for k in _workspaces} | {('mg',) + k for k in _mean_grad_buffers}

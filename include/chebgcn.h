@@ -296,6 +296,13 @@ int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bia
 int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const float* g, const float* y, float* dW, float* db,
                    float* dx, int64_t lddx, int B, int I, int O, chebgcn_stream stream);
 
+/* ---- loss: tf.nn.sparse_softmax_cross_entropy_with_logits + tf.reduce_mean (models_gcn.py:257-259) and its gradient wrt
+ * the logits, one launch:  *loss = mean_b( logsumexp(z_b) - z_b[y_b] ),  dlogits[b][c] = (softmax(z_b)[c] - [c == y_b]) / B.
+ * logits, dlogits: [B][C] dense; labels: [B] int32 (labels_int64 = 0) or int64 (1), values in [0, C); loss: one float.
+ * Deterministic (fixed-order sums). */
+int chebgcn_softmax_xent(const float* logits, const void* labels, int labels_int64, float* loss, float* dlogits, int B,
+                         int C, chebgcn_stream stream);
+
 /* ---- optimizer: tf.train.AdamOptimizer step (models_gcn.py:296, TF form) ---------
  * g' = grad_scale * g + l2 * p (per-segment l2 handled by the caller passing
  * segments);  m += (1-b1)(g'-m);  v += (1-b2)(g'^2-v);  p -= lr_t * m / (sqrt(v)+eps)

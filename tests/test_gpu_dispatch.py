@@ -653,3 +653,29 @@ def test_bf16_layer_takes_the_dy16_path(ops, dev, lib):
     assert 'brelu_pool_bwd' in logs[False] and 'dy16' not in logs[False]['contract_bwd_w_bf16']
     for name, a, c in zip(('dx', 'dW', 'dbias'), grads[True], grads[False]):
         assert torch.equal(a, c), '%s differs between the bf16-dy and the fp32-dy layer' % name
+
+
+@pytest.mark.parametrize('B,C,dtype', [(128, 22, torch.int64), (64, 21, torch.int32), (1, 2, torch.int64), (1000, 7, torch.int32), (3, 1, torch.int64)])
+def test_softmax_xent_vs_float64(ops, dev, B, C, dtype):
+    """chebgcn_softmax_xent (tf.nn.sparse_softmax_cross_entropy_with_logits + tf.reduce_mean, models_gcn.py:257-259, and its
+    gradient) against float64 NumPy; logits with a wide range (the max-shift must hold); bit-identical from run to run."""
+    from gcn_fmri_decoding_amd import _lib
+    rs = np.random.RandomState(B + C)
+    z = (rs.randn(B, C) * 8).astype(np.float32)
+    y = rs.randint(0, C, B)
+    zd, yd = torch.as_tensor(z).to(dev), torch.as_tensor(y).to(dev).to(dtype)
+    loss, dz = ops.softmax_xent(zd, yd)
+    assert _lib.last_dispatch() == 'softmax_xent_kernel<%s>' % ('int64' if dtype == torch.int64 else 'int32')
+    z64 = z.astype(np.float64)
+    m = z64.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(z64 - m).sum(1))
+    ref = float((lse - z64[np.arange(B), y]).mean())
+    sm = np.exp(z64 - lse[:, None])
+    sm[np.arange(B), y] -= 1
+    dref = sm / B
+    e_l = abs(float(loss) - ref) / max(abs(ref), 1e-30)
+    e_d = np.abs(dz.cpu().numpy() - dref).max() / np.abs(dref).max() if C > 1 else float(np.abs(dz.cpu().numpy()).max())
+    record_measured('softmax_xent[%d,%d]' % (B, C), loss=e_l, dlogits=e_d)
+    assert e_l <= 1e-6 and e_d <= 2e-6, (e_l, e_d)
+    loss2, dz2 = ops.softmax_xent(zd, yd)
+    assert torch.equal(loss, loss2) and torch.equal(dz, dz2)
