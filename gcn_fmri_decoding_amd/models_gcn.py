@@ -199,6 +199,10 @@ class base_model(object):
         self._init_variables()
         if self._dp is not None:
             self._dp.broadcast_parameters()
+        if self._auto_step_graph():
+            # atlas-sized graphs (what the reference trains on): the step is a chain of ~100 kernels of 3-60 us and launch-bound;
+            # captured once as a HIP graph it is the same kernels on the same operands, bit for bit (enable_step_graph)
+            self.enable_step_graph(True)
         train_dev, val_dev = self.stage(train_data), self.stage(val_data)
         train_labels = np.asarray(train_labels)
         labels_dev = torch.as_tensor(train_labels.astype(np.int64)).to(self.device)
@@ -243,6 +247,20 @@ class base_model(object):
             self.fit_log['loss_average'] = [float(v) for v in self.fit_log['loss_average']]
         t_step = (time.time() - t_wall) / num_steps
         return accuracies, losses, t_step
+
+    # fit() captures the training step by itself where that pays: 'auto' (graphs of at most 2048 vertices), True, False
+    step_graph = 'auto'
+
+    def _auto_step_graph(self):
+        mode = os.environ.get('CHEBGCN_STEP_GRAPH', self.step_graph)
+        if mode in (False, 0, '0', 'off', 'False'):
+            return False
+        ok = (self.device.type == 'cuda' and self.momentum != 0 and self._fusable()
+              and (self._dp is None or self._dp.capturable))
+        if mode in (True, 1, '1', 'on', 'True'):
+            return ok
+        graphs = getattr(self, 'graphs', None) or []
+        return ok and bool(graphs) and all(g.Mp <= 2048 for g in graphs)
 
     def _session(self):
         """Stand-in for the ``tf.Session`` the reference hands around (``sess`` arguments): there is
@@ -513,8 +531,13 @@ class base_model(object):
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         before = ops.cache_keys()
-        with torch.cuda.graph(graph):
-            sg['loss_average'] = self._step_body(sg['x'], sg['labels'], sg['lr_t'], sg['ema_c'][0])
+        cgcnn._captures = getattr(cgcnn, '_captures', 0) + 1
+        ops.capture_tag = cgcnn._captures
+        try:
+            with torch.cuda.graph(graph):
+                sg['loss_average'] = self._step_body(sg['x'], sg['labels'], sg['lr_t'], sg['ema_c'][0])
+        finally:
+            ops.capture_tag = None
         sg['graph'] = graph
         sg['cache_keys'] = ops.cache_keys() - before       # scratch allocated on the capture streams: it dies with this graph
         return sg

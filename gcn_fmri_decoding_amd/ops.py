@@ -252,12 +252,19 @@ def perm_data(x, perm, sample=None, out=None):
 # ------------------------------------------------------------------------------------
 
 _workspaces = {}
+# set by cgcnn._capture_step around a capture: scratch allocated while capturing comes from THAT graph's private pool and is
+# never handed to another graph (or to eager code on a stream with the same handle)
+capture_tag = None
+
+
+def _cap():
+    return capture_tag if (capture_tag is not None and torch.cuda.is_current_stream_capturing()) else None
 
 
 def _workspace(nbytes, device, tag=''):
     """Scratch of a library call, kept per device, stream and use: launches on one stream are ordered, so the buffer of the
     previous call of the same kind is free by the time the next one runs."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
+    key = (device.index, torch.cuda.current_stream().cuda_stream, tag, _cap())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
@@ -270,7 +277,7 @@ _mean_grad_buffers = {}
 
 def _mean_grad_buffer(B, Mp, device):
     """[B, Mp] scratch of the fused last layer's backward; columns beyond M stay zero (only [:, :M] is ever written)."""
-    key = (B, Mp, device.index, torch.cuda.current_stream().cuda_stream)
+    key = (B, Mp, device.index, torch.cuda.current_stream().cuda_stream, _cap())
     buf = _mean_grad_buffers.get(key)
     if buf is None:
         buf = _mean_grad_buffers[key] = torch.zeros((B, Mp), dtype=torch.float32, device=device)
