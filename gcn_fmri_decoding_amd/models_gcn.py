@@ -214,13 +214,20 @@ class base_model(object):
         num_steps = int(self.num_epochs * n_train / self.batch_size)
         say('training with {} steps in total with batch_size={} and epochs={} for training_set={}:'.format(
             num_steps, self.batch_size, self.num_epochs, n_train))
+        pool_dev = pool_labels = None       # the deque's content on the device, uploaded when it is refilled (once per epoch)
+        pool_at = 0
         for step in range(1, num_steps + 1):
             if len(indices) < self.batch_size:
                 indices.extend(np.random.permutation(n_train))
+                pool_dev = torch.as_tensor(np.asarray(indices, np.int32)).to(self.device)
+                pool_labels = labels_dev[pool_dev.long()]
+                pool_at = 0
             idx = [indices.popleft() for _ in range(self.batch_size)]
-            idx_dev = torch.as_tensor(np.asarray(idx, np.int32)).to(self.device)
+            idx_dev = pool_dev[pool_at:pool_at + self.batch_size]
+            batch_labels = pool_labels[pool_at:pool_at + self.batch_size]
+            pool_at += self.batch_size
             x = self._gather(train_dev, idx_dev)
-            learning_rate, loss_average = self.train_step(x, labels_dev[idx_dev.long()])
+            learning_rate, loss_average = self.train_step(x, batch_labels)
             if self.record_fit:
                 self.fit_log['idx'].append(np.asarray(idx))
                 self.fit_log['loss_average'].append(loss_average)
