@@ -53,12 +53,16 @@ def seeded_model(z, dev, params, **kw):
     return net, Ls
 
 
+@pytest.mark.parametrize('step_graph', ['auto', '0'])
 @pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_flat_n212'])
-def test_fit_predict_loop_vs_oracle(dev, name, tmp_path, monkeypatch):
+def test_fit_predict_loop_vs_oracle(dev, name, step_graph, tmp_path, monkeypatch):
     """models_gcn.py:112-184 / :31-71 with dropout keep_prob = 1 (the only dropout setting an oracle
     can follow): 2.5 epochs over 23 windows in batches of 4 (the deque is refilled mid-batch), an
-    evaluation every 3 steps on a validation set whose size (10) is not a multiple of the batch."""
+    evaluation every 3 steps on a validation set whose size (10) is not a multiple of the batch.
+    ``fit`` captures the training step as a HIP graph by itself on graphs this small (cgcnn.step_graph = 'auto'); both the
+    captured and the eager loop are held against the oracle."""
     monkeypatch.setenv('CHEBGCN_HOME', str(tmp_path))
+    monkeypatch.setenv('CHEBGCN_STEP_GRAPH', step_graph)
     z = load_golden(name)
     params = {k[len('param:'):]: z[k].copy() for k in z.files if k.startswith('param:')}
     batch, epochs, every, reg = 4, 2.5, 3, 5e-4
@@ -85,6 +89,7 @@ def test_fit_predict_loop_vs_oracle(dev, name, tmp_path, monkeypatch):
     np.random.seed(2024)
     acc, losses, t_step = net.fit(data, labels, vdata, vlabels)
     assert net.global_step == log['num_steps']
+    assert (net._sg is not None) == (step_graph == 'auto'), 'fit() did not take the %s step' % ('captured' if step_graph == 'auto' else 'eager')
     assert [i.tolist() for i in net.fit_log['idx']] == [i.tolist() for i in log['idx']]      # same samples, same order
     np.testing.assert_allclose(net.fit_log['loss_average'], log['loss_average'], rtol=5e-5)
     np.testing.assert_allclose(losses, log['losses'], rtol=5e-5)                              # incl. the padded last batch
