@@ -72,6 +72,17 @@ def rel_err(got, ref, scale=None):
     return float((got.double() - ref).abs().max() / scale)
 
 
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def elementwise_eps(got, ref, mag):
+    """max over the ELEMENTS of |got - ref| / (eps32 * mag), mag = the sum of the magnitudes of the products an element adds up
+    (the scale of its own rounding error: the textbook bound is n * eps * mag for n terms, ~sqrt(n) in practice).  A per-tensor
+    max norm hides a wrong element wherever the tensor has larger ones; this does not."""
+    d = (got.double() - ref).abs()
+    return float((d / (EPS32 * mag.clamp(min=1e-30))).max())
+
+
 CASES = {
     # name: (B, M, Fin, K, Fout, forward, bwd_x stem, bwd_w RT, bwd_w reduce)
     'bench_b64': (64, 10466, 32, 5, 32, 'contract_fwd_ring_kernel', 'contract_bwd_x_lds_kernel<%s>', 5, 'big'),
@@ -110,6 +121,10 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
     pre = torch.einsum('rbm,ro->bom', S, W.double()) + bias[:, :M].double()
     got['fwd'] = rel_err(out[..., :M], pre.clamp(min=0), pre.abs().max())
     assert got['fwd'] <= REL, 'contract_fwd (%s): %.3e' % (fwd_name, got['fwd'])
+    mag = torch.einsum('rbm,ro->bom', S.abs(), W.double().abs()) + bias[:, :M].double().abs()
+    got['fwd_elementwise_eps'] = elementwise_eps(out[..., :M], pre.clamp(min=0), mag)
+    assert got['fwd_elementwise_eps'] <= 16, 'contract_fwd (%s): an element is %.1f eps of its own terms off' % (fwd_name, got['fwd_elementwise_eps'])
+    del mag
     bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, Fout, Mp)[..., :M].bool()
     assert torch.equal(bits, out[..., :M] > 0), 'ReLU bit mask disagrees with the output'
     del pre
@@ -123,6 +138,7 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
     n = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
     ws = torch.empty(n, dtype=torch.uint8, device=dev)
     dW_ref = torch.einsum('rbm,bom->ro', S, dy)
+    dW_mag = torch.einsum('rbm,bom->ro', S.abs(), dy.abs())
     del S
     ntiles = (Fin * K + 31) // 32
     assert min(ntiles, 5) == rt
@@ -139,10 +155,14 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
         key = 'bwd_w_relu' if folded else 'bwd_w'
         got[key] = rel_err(dW, dW_ref)
         assert got[key] <= GREL, '%s (%s): %.3e' % (key, name, got[key])
+        # a sum over B*M ~ 1e5..1e6 products: fixed-order partial sums of partial sums, errors ~ sqrt(n) eps of the terms' magnitudes
+        got[key + '_elementwise_eps'] = elementwise_eps(dW, dW_ref, dW_mag)
+        assert got[key + '_elementwise_eps'] <= 16, '%s (%s): an element is %.1f eps of its own terms off' % (key, name, got[key + '_elementwise_eps'])
         dWs[folded] = dW
     assert torch.equal(dWs[True], dWs[False]), 'folded and plain dW differ'            # the same products in the same order
 
     gs_ref = torch.einsum('ro,bom->rbm', W.double(), dy).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    gs_mag = torch.einsum('ro,bom->rbm', W.double().abs(), dy.abs()).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
     gss = {}
     for folded in (True, False):
         gstack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
@@ -155,6 +175,8 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
         key = 'bwd_x_relu' if folded else 'bwd_x'
         got[key] = rel_err(gstack[..., :M], gs_ref)
         assert got[key] <= GREL, '%s (%s): %.3e' % (key, name, got[key])
+        got[key + '_elementwise_eps'] = elementwise_eps(gstack[..., :M], gs_ref, gs_mag)
+        assert got[key + '_elementwise_eps'] <= 16, '%s (%s): an element is %.1f eps of its own terms off' % (key, name, got[key + '_elementwise_eps'])
         gss[folded] = gstack[..., :M]
     assert torch.equal(gss[True], gss[False]), 'folded and plain dstack differ'
     record_measured('contraction_arm_vs_float64[%s]' % case, **got)
