@@ -230,6 +230,7 @@ namespace chebgcn {
 // One workgroup: thread t takes the rows t, t + 256, ... in order, the 256 partial sums are added in a fixed tree --
 // deterministic.  (torch's cross_entropy + backward are six launches; at the reference's shapes the head of the step is
 // launch-bound.)
+constexpr int XENT_REG = 32;      // classes held in registers (the reference's tasks: 21-23 cognitive states)
 template <typename LabelT>
 __global__ void __launch_bounds__(256)
 softmax_xent_kernel(const float* __restrict__ z, const LabelT* __restrict__ y, float* __restrict__ loss,
@@ -239,10 +240,35 @@ softmax_xent_kernel(const float* __restrict__ z, const LabelT* __restrict__ y, f
     const float invB = 1.f / (float)B;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* row = z + (size_t)b * C;
-        float m = row[0];
-        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
         long long t = (long long)y[b];
         t = t < 0 ? 0 : t >= C ? C - 1 : t;                   // (a label outside [0, C) is the caller's error: clamped, not read past the row)
+        float* drow = dz + (size_t)b * C;
+        if (C <= XENT_REG) {
+            // the row in registers: ONE memory round trip (a loop over row[c] is a dependent load per class and pass: 12 us for
+            // 128 x 22 logits)
+            float v[XENT_REG];
+#pragma unroll
+            for (int c = 0; c < XENT_REG; ++c) v[c] = c < C ? row[c] : -__builtin_inff();
+            float m = v[0];
+#pragma unroll
+            for (int c = 1; c < XENT_REG; ++c) m = fmaxf(m, v[c]);
+            float s = 0.f, so = 0.f, et = 0.f;
+#pragma unroll
+            for (int c = 0; c < XENT_REG; ++c) {
+                v[c] = c < C ? expf(v[c] - m) : 0.f;
+                s += v[c];
+                so += c == t ? 0.f : v[c];
+                et = c == t ? v[c] : et;
+            }
+            acc += et > 1e-30f ? log1pf(so / et) : logf(s) - logf(fmaxf(et, 1e-45f));
+            const float inv = invB / s;
+#pragma unroll
+            for (int c = 0; c < XENT_REG; ++c)
+                if (c < C) drow[c] = c == t ? -so * inv : v[c] * inv;
+            continue;
+        }
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
         float s = 0.f, so = 0.f;                              // all classes; all but the labelled one
         for (int c = 0; c < C; ++c) {
             const float e = expf(row[c] - m);
@@ -253,7 +279,6 @@ softmax_xent_kernel(const float* __restrict__ z, const LabelT* __restrict__ y, f
         const float et = expf(row[t] - m);
         acc += et > 1e-30f ? log1pf(so / et) : logf(s) - (row[t] - m);
         const float inv = invB / s;
-        float* drow = dz + (size_t)b * C;
         // softmax - 1 at the labelled class is -(sum of the others) / s: no cancellation when the prediction is confident
         for (int c = 0; c < C; ++c) drow[c] = c == t ? -so * inv : expf(row[c] - m) * inv;
     }

@@ -677,7 +677,8 @@ def test_bf16_layer_takes_the_dy16_path(ops, dev, lib):
         assert torch.equal(a, c), '%s differs between the bf16-dy and the fp32-dy layer' % name
 
 
-@pytest.mark.parametrize('B,C,dtype', [(128, 22, torch.int64), (64, 21, torch.int32), (1, 2, torch.int64), (1000, 7, torch.int32), (3, 1, torch.int64)])
+@pytest.mark.parametrize('B,C,dtype', [(128, 22, torch.int64), (64, 21, torch.int32), (1, 2, torch.int64), (1000, 7, torch.int32), (3, 1, torch.int64),
+                                       (70, 32, torch.int32), (33, 45, torch.int64)])
 def test_softmax_xent_vs_float64(ops, dev, B, C, dtype):
     """chebgcn_softmax_xent (tf.nn.sparse_softmax_cross_entropy_with_logits + tf.reduce_mean, models_gcn.py:257-259, and its
     gradient) against float64 NumPy; logits with a wide range (the max-shift must hold); bit-identical from run to run."""
