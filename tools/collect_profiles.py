@@ -20,7 +20,7 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
                  ('kbench_config4.txt', '%s_kbench_config4_K25_F64.txt'), ('kbench_config5.txt', '%s_kbench_config5_bf16.txt'),
                  ('hbm_stream_probe.txt', '%s_hbm_stream_probe.txt'), ('mfma_f32_probe.txt', '%s_mfma_f32_probe.txt'),
                  ('traffic_raw.json', '%s_traffic_raw.json'), ('kbench_two_planes.txt', '%s_kbench_two_plane_recurrence.txt'), ('kbench_reference_order.txt', '%s_kbench_reference_order_recurrence.txt'),
-                 ('stampso.txt', '%s_recurrence_ord_phase_stamps.txt'), ('stampsb.txt', '%s_bf16_phase_stamps.txt'), ('config5_layer.txt', '%s_config5_layer.txt'), ('recurrence_ord_sq_counters.txt', '%s_recurrence_ord_sq_counters.txt'),
+                 ('stampso.txt', '%s_recurrence_ord_phase_stamps.txt'), ('stampsb.txt', '%s_bf16_phase_stamps.txt'), ('stampsf.txt', '%s_fused_small_phase_stamps.txt'), ('config5_layer.txt', '%s_config5_layer.txt'), ('recurrence_ord_sq_counters.txt', '%s_recurrence_ord_sq_counters.txt'),
                  ('fused_small_check.txt', '%s_fused_small_check.txt'), ('parity_measured.jsonl', '%s_parity_measured.jsonl'),
                  ('mfma.txt', '%s_contraction_mfma_counters.txt'), ('stamps4.txt', '%s_recurrence4_phase_stamps.txt'), ('mfma_counters_available.txt', '%s_mfma_counters_available.txt'),
                  ('config4_kernel_stats.csv', '%s_config4_kernel_stats.csv'), ('config5_kernel_stats.csv', '%s_config5_kernel_stats.csv'),

@@ -29,6 +29,10 @@ if [ -f build_x/libchebgcn_b64.so ]; then
 fi
 python3 tools/config5_probe.py > $out/config5_layer.txt 2>&1
 python3 tools/fused_check.py > $out/fused_small_check.txt 2>&1
+# ... and its phase stamps (build_x/libchebgcn_f64.so: tools/fbuild.sh f64 "-DCG_EXPERIMENT=1 -DCG_X=64")
+if [ -f build_x/libchebgcn_f64.so ]; then
+  CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_f64.so python3 tools/fused_check.py 2>&1 | grep -A30 "N=360 M=376 B=128 Fin=32" | grep -B1 -A13 "stamps" > $out/stampsf.txt
+fi
 cp gpurun_out/pmcmfma_refresh/available.txt $out/mfma_counters_available.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-windows 0 --kernel-legs 0 > $out/prof.log 2>&1
