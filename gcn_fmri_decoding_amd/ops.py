@@ -79,6 +79,7 @@ fused_small = os.environ.get('CHEBGCN_FUSED_SMALL', '1') != '0'
 # contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd (dW feeds neither): +1.5 % on the
 # configs[1] step.  Not on instrumented steps, whose per-kernel event times must not include a neighbour.
 overlap_bwd_w = True
+bias_side_small = True       # fused atlas-size layers: the bias reduction on the second stream as well
 _side_streams = {}
 
 
@@ -583,6 +584,12 @@ class ChebConv(torch.autograd.Function):
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     launch_bwd_w()
+                    if bias_job is not None and ctx.fused and bias_side_small:
+                        # atlas-sized layers: the main stream is the critical path of a chain of short launches and the second
+                        # stream has slack -- the bias reduction goes there too (on the benchmark graph that costs 4 %: it stays
+                        # behind contract_bwd_x / recurrence_bwd on the main stream)
+                        bias_job()
+                        bias_job = None
             else:
                 launch_bwd_w()
         else:
