@@ -41,6 +41,9 @@ SIGNATURES = {
     'chebgcn_contract_bwd_x_bf16': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p]),
     'chebgcn_contract_bwd_w_bf16_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'chebgcn_contract_bwd_w_bf16': (_i, [_p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _i, _p]),
+    'chebgcn_adam_partials': (_i, [_i64]),
+    'chebgcn_adam_step_sq': (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _p]),
+    'chebgcn_loss_bookkeeping': (_i, [_p, _p, _i, _f, _p, _f, _f, _p, _p, _p, _p]),
     'chebgcn_softmax_xent': (_i, [_p, _p, _i, _p, _p, _i, _i, _p]),
     'chebgcn_relu_grad_bf16': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p]),
     'chebgcn_bf16_dy16_supported': (_i, [_i, _i, _i, _i, _i]),

@@ -314,6 +314,54 @@ adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
     }
 }
 
+// Adam as above (step size by value, or from device memory when lr_t_dev is set) that also leaves the sum of squares of the
+// PRE-update variables it walks -- the L2 term of the loss (models_gcn.py:262-266: regularization * sum tf.nn.l2_loss) -- as one
+// partial per workgroup (fixed-order tree inside the workgroup); chebgcn_loss_bookkeeping adds the partials in index order.
+__global__ void __launch_bounds__(256)
+adam_sq_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+               float lr_t_val, const float* __restrict__ lr_t_dev, float b1, float b2, float eps, float gscale, float l2,
+               float* __restrict__ sq_part) {
+    __shared__ float red[256];
+    const float lr_t = lr_t_dev ? *lr_t_dev : lr_t_val;
+    float sq = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        sq = fmaf(pi, pi, sq);
+        const float gi = fmaf(l2, pi, gscale * g[i]);
+        const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+        const float vi = v[i] + (1.f - b2) * (gi * gi - v[i]);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+    red[threadIdx.x] = sq;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sq_part[blockIdx.x] = red[0];
+}
+
+// loss = cross_entropy + half_reg * sum(partials);  the ExponentialMovingAverage(0.9) of the loss with its zero-debiasing
+// (models_gcn.py:269-275): ema += (1 - decay) * (loss - ema);  loss_average = ema * corr.  One wave, one launch (torch: dot x 2,
+// add, lerp, mul).
+__global__ void __launch_bounds__(64)
+loss_bookkeeping_kernel(const float* __restrict__ ce, const float* __restrict__ sq_part, int nparts, float half_reg,
+                        float* __restrict__ ema, float decay, float corr_val, const float* __restrict__ corr_dev,
+                        float* __restrict__ loss_out, float* __restrict__ loss_average_out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += sq_part[i];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (threadIdx.x == 0) {
+        const float loss = *ce + half_reg * s;
+        const float e = *ema + (1.f - decay) * (loss - *ema);
+        *ema = e;
+        if (loss_out) *loss_out = loss;
+        *loss_average_out = e * (corr_dev ? *corr_dev : corr_val);
+    }
+}
+
 }  // namespace chebgcn
 
 using namespace chebgcn;
@@ -572,6 +620,35 @@ extern "C" int chebgcn_adam_step_dev(float* p, const float* g, float* m, float* 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, g, m, v, n, lr_t_dev, beta1, beta2,
                        eps, grad_scale, l2);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_adam_partials(int64_t n) {
+    int64_t blocks = (n + 255) / 256;
+    return (int)(blocks > 4096 ? 4096 : blocks < 0 ? 0 : blocks);
+}
+
+extern "C" int chebgcn_adam_step_sq(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev,
+                                    float beta1, float beta2, float eps, float grad_scale, float l2, float* sq_partials,
+                                    chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(p && g && m && v && sq_partials && n > 0, "adam_step_sq: bad argument");
+    note_dispatch("adam_sq_kernel");
+    hipLaunchKernelGGL(adam_sq_kernel, dim3((unsigned)chebgcn_adam_partials(n)), dim3(256), 0, stream, p, g, m, v, n, lr_t, lr_t_dev,
+                       beta1, beta2, eps, grad_scale, l2, sq_partials);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_loss_bookkeeping(const float* cross_entropy, const float* sq_partials, int nparts, float half_reg,
+                                        float* ema, float decay, float corr, const float* corr_dev, float* loss_out,
+                                        float* loss_average_out, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(cross_entropy && ema && loss_average_out && nparts >= 0 && (nparts == 0 || sq_partials), "loss_bookkeeping: bad argument");
+    note_dispatch("loss_bookkeeping_kernel");
+    hipLaunchKernelGGL(loss_bookkeeping_kernel, dim3(1), dim3(64), 0, stream, cross_entropy, sq_partials, nparts, half_reg, ema,
+                       decay, corr, corr_dev, loss_out, loss_average_out);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

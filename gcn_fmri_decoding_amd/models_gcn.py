@@ -463,17 +463,26 @@ class base_model(object):
         grad_scale = 1.0
         if self._dp is not None:
             grad_scale = self._dp.finish_step()
-        with torch.no_grad():       # the loss of this step is evaluated on the pre-update variables
-            v = self._flat[:self._n_reg]
-            loss = torch.add(cross_entropy, torch.dot(v, v), alpha=0.5 * self.regularization)   # + reg * sum l2_loss
-        self._apply_adam(grad_scale, lr_t)
-        with torch.no_grad():
-            # tf.train.ExponentialMovingAverage(0.9) over a Tensor: zero-initialised shadow,
-            # zero-debiased on read (:269-275); shadow = 0.9 * shadow + 0.1 * loss, in place, as one kernel
-            if self._loss_ema is None:
-                self._loss_ema = torch.zeros((), dtype=torch.float32, device=self.device)
-            self._loss_ema.lerp_(loss, 0.1)
-            loss_average = self._loss_ema * ema_correction
+        if self._loss_ema is None:
+            self._loss_ema = torch.zeros((), dtype=torch.float32, device=self.device)
+        if self.momentum != 0 and self.device.type == 'cuda':
+            # the loss of this step is evaluated on the PRE-update variables: Adam's pass over the regularised variables leaves
+            # the partial sums of their squares (reg * sum l2_loss, :262-266), and one launch finishes the bookkeeping --
+            # loss, tf.train.ExponentialMovingAverage(0.9) over it (zero-initialised shadow, zero-debiased on read, :269-275)
+            nparts = self._apply_adam(grad_scale, lr_t, want_sq=True)
+            corr = ema_correction if isinstance(ema_correction, torch.Tensor) and ema_correction.is_cuda else float(ema_correction)
+            if isinstance(corr, torch.Tensor) and corr.dim() == 0:
+                corr = corr.reshape(1)
+            loss_average = ops.loss_bookkeeping(cross_entropy, getattr(self, '_sq_part', None), nparts, 0.5 * self.regularization,
+                                                self._loss_ema, corr)
+        else:
+            with torch.no_grad():
+                v = self._flat[:self._n_reg]
+                loss = torch.add(cross_entropy, torch.dot(v, v), alpha=0.5 * self.regularization)   # + reg * sum l2_loss
+            self._apply_adam(grad_scale, lr_t)
+            with torch.no_grad():
+                self._loss_ema.lerp_(loss, 0.1)
+                loss_average = self._loss_ema * ema_correction
         self.training_mode = False
         return loss_average
 
@@ -549,7 +558,9 @@ class base_model(object):
         sg['cache_keys'] = ops.cache_keys() - before       # scratch allocated on the capture streams: it dies with this graph
         return sg
 
-    def _apply_adam(self, grad_scale=1.0, lr_t=None):
+    def _apply_adam(self, grad_scale=1.0, lr_t=None, want_sq=False):
+        """TF-form Adam over the flat buffers; ``want_sq``: the pass over the regularised variables also leaves the partial sums
+        of their squares in ``self._sq_part`` (returns how many)."""
         if self.momentum == 0:
             # tf.train.GradientDescentOptimizer branch (:288-289)
             lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
@@ -562,12 +573,19 @@ class base_model(object):
         if lr_t is None:
             lr_t = self._adam_lr_t(self.global_step + 1)
         r, n = self._n_reg, self._n_total
-        if r > 0:
+        nparts = 0
+        if r > 0 and want_sq:
+            if getattr(self, '_sq_part', None) is None:
+                self._sq_part = torch.zeros(4096, dtype=torch.float32, device=self.device)
+            nparts = ops.adam_step_sq(self._flat[:r], self._grad[:r], self._adam_m[:r], self._adam_v[:r], lr_t, self._sq_part, b1, b2,
+                                      1e-8, grad_scale, self.regularization)
+        elif r > 0:
             ops.adam_step(self._flat[:r], self._grad[:r], self._adam_m[:r], self._adam_v[:r], lr_t, b1, b2, 1e-8,
                           grad_scale, self.regularization)
         if n > r:
             ops.adam_step(self._flat[r:], self._grad[r:], self._adam_m[r:], self._adam_v[r:], lr_t, b1, b2, 1e-8,
                           grad_scale, 0.0)
+        return nparts
 
     # ---------------------------------------------------------------- helpers
 

@@ -777,6 +777,39 @@ def fc_backward(x, W, g, y, dW, db, need_dx):
     return (dx,)
 
 
+def adam_step_sq(p, g, m, v, lr_t, sq_partials, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
+    """``adam_step`` that also leaves the per-workgroup partial sums of squares of the PRE-update ``p`` in ``sq_partials``
+    (float32, at least ``adam_partials(n)`` elements): the L2 term of the loss without a pass of its own.  Returns the
+    number of partials written."""
+    _require_cuda(p, g, m, v, sq_partials)
+    n = p.numel()
+    if not (g.numel() == m.numel() == v.numel() == n) or n == 0:
+        raise ValueError('adam_step_sq: size mismatch')
+    lib = _lib.lib()
+    nparts = lib.chebgcn_adam_partials(n)
+    if sq_partials.dtype != torch.float32 or sq_partials.numel() < nparts:
+        raise ValueError('adam_step_sq: sq_partials needs %d float32' % nparts)
+    dev_lr = isinstance(lr_t, torch.Tensor)
+    if dev_lr and (lr_t.dtype != torch.float32 or lr_t.numel() != 1 or not lr_t.is_cuda):
+        raise ValueError('adam_step_sq: a device lr_t must be one float32')
+    _lib.check(lib.chebgcn_adam_step_sq(_p(p), _p(g), _p(m), _p(v), n, 0.0 if dev_lr else float(lr_t), _p(lr_t) if dev_lr else None,
+                                        float(beta1), float(beta2), float(eps), float(grad_scale), float(l2), _p(sq_partials),
+                                        _stream()), 'adam_step_sq')
+    return nparts
+
+
+def loss_bookkeeping(cross_entropy, sq_partials, nparts, half_reg, ema, corr, decay=0.9):
+    """loss = cross_entropy + half_reg * sum(sq_partials[:nparts]); ema <- ema + (1 - decay)(loss - ema) in place;
+    returns loss_average = ema * corr (``corr``: float, or one-element device tensor read when the kernel runs)."""
+    _require_cuda(cross_entropy, ema)
+    out = torch.empty((), dtype=torch.float32, device=ema.device)
+    dev_c = isinstance(corr, torch.Tensor)
+    _lib.check(_lib.lib().chebgcn_loss_bookkeeping(_p(cross_entropy), _p(sq_partials) if nparts else None, int(nparts), float(half_reg),
+                                                   _p(ema), float(decay), 0.0 if dev_c else float(corr), _p(corr) if dev_c else None,
+                                                   None, _p(out), _stream()), 'loss_bookkeeping')
+    return out
+
+
 def adam_step(p, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
     """In-place TF-form Adam on flat fp32 buffers (models_gcn.py:296).  ``lr_t``: a Python float, or a one-element
     fp32 DEVICE tensor read when the kernel runs (chebgcn_adam_step_dev: the form a captured step graph replays)."""

@@ -296,6 +296,20 @@ int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bia
 int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const float* g, const float* y, float* dW, float* db,
                    float* dx, int64_t lddx, int B, int I, int O, chebgcn_stream stream);
 
+/* Adam as above (lr_t by value, or read from *lr_t_dev when that is not NULL) which also leaves the sum of squares of the
+ * PRE-update variables -- the L2 term of the loss, models_gcn.py:262-266 -- as chebgcn_adam_partials(n) per-workgroup partial
+ * sums in sq_partials; and the rest of the loss bookkeeping of a step in one launch:
+ *   loss = *cross_entropy + half_reg * sum(sq_partials[0..nparts));   *ema += (1 - decay) * (loss - *ema)   (the
+ *   tf.train.ExponentialMovingAverage(0.9) of :269-275);   *loss_average_out = *ema * corr   (corr read from *corr_dev when set:
+ *   the zero-debiasing factor 1 / (1 - decay^t));   *loss_out = loss when not NULL.  Fixed-order sums. */
+int chebgcn_adam_partials(int64_t n);
+int chebgcn_adam_step_sq(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev,
+                         float beta1, float beta2, float eps, float grad_scale, float l2, float* sq_partials,
+                         chebgcn_stream stream);
+int chebgcn_loss_bookkeeping(const float* cross_entropy, const float* sq_partials, int nparts, float half_reg, float* ema,
+                             float decay, float corr, const float* corr_dev, float* loss_out, float* loss_average_out,
+                             chebgcn_stream stream);
+
 /* ---- loss: tf.nn.sparse_softmax_cross_entropy_with_logits + tf.reduce_mean (models_gcn.py:257-259) and its gradient wrt
  * the logits, one launch:  *loss = mean_b( logsumexp(z_b) - z_b[y_b] ),  dlogits[b][c] = (softmax(z_b)[c] - [c == y_b]) / B.
  * logits, dlogits: [B][C] dense; labels: [B] int32 (labels_int64 = 0) or int64 (1), values in [0, C); loss: one float.

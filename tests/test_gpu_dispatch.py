@@ -702,3 +702,37 @@ def test_softmax_xent_vs_float64(ops, dev, B, C, dtype):
     assert e_l <= 1e-6 and e_d <= 2e-6, (e_l, e_d)
     loss2, dz2 = ops.softmax_xent(zd, yd)
     assert torch.equal(loss, loss2) and torch.equal(dz, dz2)
+
+
+@pytest.mark.parametrize('n,dev_scalars', [(1000, False), (700001, True), (2500000, False)])
+def test_adam_with_squares_and_loss_bookkeeping(ops, dev, n, dev_scalars):
+    """chebgcn_adam_step_sq = chebgcn_adam_step bit for bit, plus the partial sums of squares of the PRE-update variables;
+    chebgcn_loss_bookkeeping: loss = ce + reg/2 * sum p^2 (models_gcn.py:262-266), the EMA(0.9) of :269-275 and its debiased
+    read, against float64."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(n)
+    p0 = torch.randn(n, generator=gen, device=dev) * 0.1
+    g = torch.randn(n, generator=gen, device=dev)
+    m0 = torch.randn(n, generator=gen, device=dev) * 0.01
+    v0 = torch.rand(n, generator=gen, device=dev) * 0.01
+    lr_t, reg = 1.7e-3, 5e-4
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    ops.adam_step(pa, g, ma, va, lr_t, grad_scale=0.5, l2=reg)
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    part = torch.full((4096,), float('nan'), device=dev)
+    lr = torch.tensor([lr_t], dtype=torch.float32, device=dev) if dev_scalars else lr_t
+    nparts = ops.adam_step_sq(pb, g, mb, vb, lr, part, grad_scale=0.5, l2=reg)
+    assert nparts == min((n + 255) // 256, 4096)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), 'adam_step_sq is not adam_step'
+    sq_ref = float((p0.double() ** 2).sum())
+    e_sq = abs(float(part[:nparts].double().sum()) - sq_ref) / sq_ref
+    ce = torch.tensor(2.345, dtype=torch.float32, device=dev)
+    ema = torch.tensor(1.25, dtype=torch.float32, device=dev)
+    corr = 1.0 / (1 - 0.9 ** 7)
+    out = ops.loss_bookkeeping(ce, part, nparts, 0.5 * reg, ema, torch.tensor([corr], dtype=torch.float32, device=dev) if dev_scalars else corr)
+    loss_ref = 2.345 + 0.5 * reg * sq_ref
+    ema_ref = 1.25 + 0.1 * (loss_ref - 1.25)
+    e_ema = abs(float(ema) - ema_ref) / ema_ref
+    e_out = abs(float(out) - ema_ref * corr) / (ema_ref * corr)
+    record_measured('adam_sq_loss_bookkeeping[%d]' % n, sum_sq=e_sq, ema=e_ema, loss_average=e_out)
+    assert e_sq <= 2e-6 and e_ema <= 1e-6 and e_out <= 1e-6, (e_sq, e_ema, e_out)
