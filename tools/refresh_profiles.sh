@@ -19,18 +19,21 @@ cp gpurun_out/traffic_refresh/traffic_raw.json $out/ 2>/dev/null
 bash tools/pmc_mfma.sh refresh > $out/mfma.txt 2>&1
 # the ordered recurrence kernels: SQ instruction / wait / LDS counters at the north-star shape and at the batch of the bench
 # step, and the in-kernel phase stamps of one plane group (build_x/libchebgcn_x64.so: tools/xbuild.sh 64)
+# (the experiment libraries are built HERE, not on the GPU box: a stale one lacks the symbols the ctypes table asks for -- skip it
+#  rather than overwrite the stamp files with a traceback)
+lib_ok() { [ -f "$1" ] && CHEBGCN_LIB=$1 python3 -c "from gcn_fmri_decoding_amd import _lib; _lib.lib()" 2>/dev/null; }
 bash tools/pmc_sq.sh refresh_ord --B 256 --iters 3 --kernels recurrence_fwd_inplace recurrence_bwd > $out/recurrence_ord_sq_counters.txt 2>&1
-if [ -f build_x/libchebgcn_x64.so ]; then
+if lib_ok $GRAFT_REPO_ROOT/build_x/libchebgcn_x64.so; then
   CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_x64.so python3 tools/kbench.py --B 256 --kernels recurrence_fwd_inplace recurrence_bwd --stamps > $out/stampso.txt 2>&1
 fi
 # the bf16 contraction kernels of config 5 (build_x/libchebgcn_b64.so: tools/bbuild.sh b64 "-DCG_EXPERIMENT=1 -DCG_X=64")
-if [ -f build_x/libchebgcn_b64.so ]; then
+if lib_ok $GRAFT_REPO_ROOT/build_x/libchebgcn_b64.so; then
   CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_b64.so python3 tools/kbench.py --stamps --B 64 --fin 60 --fout 256 --K 5 --iters 10 --kernels contract_fwd_bf16 contract_bwd_x_bf16_dy16 > $out/stampsb.txt 2>&1
 fi
 python3 tools/config5_probe.py > $out/config5_layer.txt 2>&1
 python3 tools/fused_check.py > $out/fused_small_check.txt 2>&1
 # ... and its phase stamps (build_x/libchebgcn_f64.so: tools/fbuild.sh f64 "-DCG_EXPERIMENT=1 -DCG_X=64")
-if [ -f build_x/libchebgcn_f64.so ]; then
+if lib_ok $GRAFT_REPO_ROOT/build_x/libchebgcn_f64.so; then
   CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_f64.so python3 tools/fused_check.py 2>&1 | grep -A30 "N=360 M=376 B=128 Fin=32" | grep -B1 -A13 "stamps" > $out/stampsf.txt
 fi
 cp gpurun_out/pmcmfma_refresh/available.txt $out/mfma_counters_available.txt 2>/dev/null
