@@ -33,6 +33,8 @@ def load_graph(n_nodes, levels, rank, world, barrier):
     if rank == 0 and not os.path.exists(path):
         from gcn_fmri_decoding_amd import graph
         Ls, perm, _ = graph.synthetic_graph(n_nodes, k=8, levels=levels)
+        if perm is None:                    # levels = 0: no coarsening, no fake vertices
+            perm = np.arange(Ls[0].shape[0])
         fields = {'perm': np.asarray(perm, np.int32), 'nl': np.int64(len(Ls))}
         for i, L in enumerate(Ls):
             L = sp.csr_matrix(L)

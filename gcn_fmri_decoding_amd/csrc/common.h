@@ -58,7 +58,7 @@ struct Ell {
     uint4* uids = nullptr;        // [ngroups*64]
     // Ordered image (recurrence_ord.hip; graphs whose rows come sorted by descending length): thread t of a workgroup of
     // ord_NT threads owns ord_NQ vertex quads (rows 4q..4q+3, the same 16 bytes it loads and stores per plane),
-    // vertex v has LDS slot (v & 3)*ord_SQ + (v >> 2) while (v >> 2) < ord_SQ; group (4u + i)*(ord_NT/64) + w, lane l is row
+    // vertex v has LDS slot (v & 3)*ord_SQ + (v >> 2) while (v >> 2) < ord_SQ (an entry = `planes` floats: 4 or 2); group (4u + i)*(ord_NT/64) + w, lane l is row
     // 4*(64*blkmap[w*ord_NQ + u] + l) + i.  Only ginfo / colo / valq / uval / uids / blkmap are built.
     // Which 64-quad block a wave works on at level u is a table (blkmap[w*ord_NQ + u], ascending in u): the rows are sorted,
     // so block b holds longer rows than block b + 1 -- dealt out in order, wave 0 would get the longest rows of every level
@@ -109,9 +109,11 @@ bool onchip4_fits(int lds_entries, int rows, int Mq);
 template <bool ADJ>
 int dispatch_onchip4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
                      hipStream_t stream);
-// recurrence_ord.hip: shape {NQ, NG} of the ordered kernel for a graph of Mq vertex quads of which the first SQ have rows
-// (512 threads, 10240 LDS entries); false = not served
-bool ordered_shape(int Mq, int SQ, int* NQ, int* NG);
+// recurrence_ord.hip: shape {NQ, NG, planes per workgroup} of the ordered kernel for a graph of Mq vertex quads of which the
+// first SQ have rows; false = not served.  ordered_fits: the launch is addressable by the ordered kernels
+// (one 32-bit buffer descriptor per slab), else the caller takes the regular images
+bool ordered_shape(int Mq, int SQ, int* NT, int* NQ, int* NG, int* planes);
+bool ordered_fits(const chebgcn_graph* g, int nplanes);
 template <bool ADJ>
 int dispatch_ordered(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
                      hipStream_t stream);

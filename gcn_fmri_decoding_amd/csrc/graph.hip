@@ -340,11 +340,11 @@ static int build_ell(int M, int Mp, int planes, const std::vector<char>& active,
 // Ordered image (common.h, recurrence_ord.hip): the operator of a graph whose rows are sorted by descending length, laid
 // out for threads that own whole vertex quads.  Same record formats as above (fixed-stride image of the first 12 entries of
 // every row group + the variable-stride quads for longer rows), same bank-aware placement of the entries of a row.
-static int build_ell_ordered(int M, int NT, int NQ, int NG, int SQ, const std::vector<int32_t>& rowptr,
+static int build_ell_ordered(int M, int NT, int NQ, int NG, int SQ, int planes, const std::vector<int32_t>& rowptr,
                              const std::vector<int32_t>& col, const std::vector<float>& val, Ell* out) {
     int rc;
     const int NW = NT / 64, NJ = 4 * NG, ngroups = NJ * NW;
-    out->planes = 4;
+    out->planes = planes;
     out->ord_NT = NT; out->ord_NQ = NQ; out->ord_NG = NG; out->ord_SQ = SQ;
     auto slot_of_vertex = [&](int v) { return (uint32_t)((v & 3) * SQ + (v >> 2)); };
     const uint32_t zero_slot = (uint32_t)(4 * SQ);
@@ -429,13 +429,13 @@ static int build_ell_ordered(int M, int NT, int NQ, int NG, int SQ, const std::v
     for (int g = 0; g < ngroups; ++g) {
         int rows[64];
         for (int lane = 0; lane < 64; ++lane) rows[lane] = row_of(g, lane);
-        place_group(4, rows, ginfo[g].x, ginfo[g].y, rowptr, col, val, slot_of_vertex, colq, valq, &out->cost_before, &out->cost_after,
-                    &out->cost_ideal);
+        place_group(planes, rows, ginfo[g].x, ginfo[g].y, rowptr, col, val, slot_of_vertex, colq, valq, &out->cost_before,
+                    &out->cost_after, &out->cost_ideal);
     }
     out->ngroups = ngroups;
     out->max_len = max_len;
     out->nranked = ngroups * 64;
-    out->lds_entries = (4 * SQ + 2 + 3) & ~3;
+    out->lds_entries = (4 * SQ + 2 + 3) & ~3;            // (of `planes` floats each)
     out->zero_slot = (int)zero_slot;
     out->nslots = nslots;
     out->nquads = nquads;
@@ -592,11 +592,11 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
     // Python host), isolated vertices last: the ordered images
     if (rc == CHEBGCN_OK && want_planes == 0 && g->lds_ok) {
         const int nf = sorted_rows(M, rp), na = sorted_rows(M, trp);
-        int NQ = 0, NG = 0;
-        if (nf >= 0 && nf == na && nf == nactive && ordered_shape(g->Mp / 4, (nactive + 3) / 4, &NQ, &NG)) {
+        int NT = 0, NQ = 0, NG = 0, PL = 0;
+        if (nf >= 0 && nf == na && nf == nactive && ordered_shape(g->Mp / 4, (nactive + 3) / 4, &NT, &NQ, &NG, &PL)) {
             const int SQ = (nactive + 3) / 4;
-            rc = build_ell_ordered(M, 512, NQ, NG, SQ, rp, ci, va, &g->ofwd);
-            if (rc == CHEBGCN_OK) rc = build_ell_ordered(M, 512, NQ, NG, SQ, trp, tci, tva, &g->oadj);
+            rc = build_ell_ordered(M, NT, NQ, NG, SQ, PL, rp, ci, va, &g->ofwd);
+            if (rc == CHEBGCN_OK) rc = build_ell_ordered(M, NT, NQ, NG, SQ, PL, trp, tci, tva, &g->oadj);
             g->ord_ok = rc == CHEBGCN_OK;
         }
     }
@@ -638,6 +638,7 @@ extern "C" int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* va
         case 13: *value = g->ord_ok ? g->ofwd.cost_before : 0; break;        // items 9..11 of the ordered image
         case 14: *value = g->ord_ok ? g->ofwd.cost_after : 0; break;
         case 15: *value = g->ord_ok ? g->ofwd.cost_ideal : 0; break;
+        case 16: *value = g->ord_ok ? g->ofwd.planes : 0; break;
         default: return fail(CHEBGCN_EINVAL, "graph_query: unknown item %d", what);
     }
     return CHEBGCN_OK;

@@ -702,7 +702,7 @@ extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, fl
                              stack + k * slab, nplanes, 2.f, stream);
         return rc;
     }
-    if (g->ord_ok) return dispatch_ordered<false>(g, g->ofwd, x, stack, nplanes, K, copy_t0, stream);
+    if (g->ord_ok && ordered_fits(g, nplanes)) return dispatch_ordered<false>(g, g->ofwd, x, stack, nplanes, K, copy_t0, stream);
     const Ell& ell = pick_ell(g, false, nplanes);
     if (ell.planes == 4) return dispatch_onchip<4, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
     return dispatch_onchip<2, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
@@ -720,7 +720,7 @@ extern "C" int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstac
         CG_HIP(hipMemcpyAsync(dx, gstack, slab * sizeof(float), hipMemcpyDeviceToDevice, stream));
         return CHEBGCN_OK;
     }
-    if (g->ord_ok) return dispatch_ordered<true>(g, g->oadj, gstack, dx, nplanes, K, 0, stream);
+    if (g->ord_ok && ordered_fits(g, nplanes)) return dispatch_ordered<true>(g, g->oadj, gstack, dx, nplanes, K, 0, stream);
     if (g->lds_ok) {
         const Ell& ell = pick_ell(g, true, nplanes);
         if (ell.planes == 4) return dispatch_onchip<4, true>(g, ell, gstack, dx, nplanes, K, 0, stream);

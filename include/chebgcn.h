@@ -92,8 +92,10 @@ void chebgcn_graph_destroy(chebgcn_graph* g);
  * after the library's bank-aware placement / without any conflict, 12 = 1 if the handle carries
  * the ORDERED operator image: the rows of the caller's matrix are sorted by descending length
  * (isolated vertices last) and the graph was created with planes = 0 -- recurrence launches then
- * run the kernel that moves planes between HBM and registers directly (csrc/recurrence_ord.hip);
- * 13 / 14 / 15 = items 9 / 10 / 11 for that image. */
+ * run the kernel that moves planes between HBM and registers directly (csrc/recurrence_ord_kernel.h;
+ * served: 2049 ... 20476 active vertices with at most 2047 isolated / padding ones behind them);
+ * 13 / 14 / 15 = items 9 / 10 / 11 for that image, 16 = its planes per workgroup (4 up to 10238
+ * active vertices, 2 beyond; 0 = no ordered image). */
 int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* value);
 
 /* ---- Chebyshev recurrence, forward: models_gcn.py:598-610 -----------------------

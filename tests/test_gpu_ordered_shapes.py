@@ -1,0 +1,147 @@
+"""The ordered Chebyshev recurrence (csrc/recurrence_ord_kernel.h) over the graph sizes it serves, every kernel shape BY NAME.
+Needs an MI355X: ``-m gpu``.
+
+A network without pooling relabels its vertices by descending row length (``graph.length_order``), and the library then runs
+``cheb_ord_kernel<ENT,NQ,NG,512,*>`` (four planes per workgroup, 16-byte LDS entries: 2049 ... 10238 active vertices) or
+``cheb_ord2_kernel<...>`` (two planes, 8-byte entries: up to 20476).  NG = quad levels with rows = ceil(active / 4 / 512),
+NQ = quad levels in all = ceil(Mp / 4 / 512).  Reference semantics: ``lib_new/models_gcn.py:598-610`` (the recurrence),
+``lib_new/graph.py:155-172`` (``graph.chebyshev``, the oracle's twin), TF autodiff of it for the adjoint.
+
+Every case: the kernel template asserted through ``chebgcn_last_dispatch()``; EVERY plane of every order of a launch with
+more plane groups than workgroups and a partial last group against the same recurrence in float64 (``torch.sparse`` on the
+device, itself tied to the CPU oracle ``oracle/graph_ref`` on three planes at 1e-12), 1e-5 of the plane's own maximum
+(adjoint 2e-5); in place (T_0 already in slab 0) == with the copy of x, bit for bit; pads poisoned with NaN never leak;
+K = 2 (one step: the first is the last) and K = 3 beside K = 5.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import record_measured
+
+pytestmark = pytest.mark.gpu
+REL, GREL = 1e-5, 2e-5
+
+# (points of the synthetic kNN graph, coarsening levels) -> (kernel family, ENT, NQ, NG)
+SHAPES = [
+    ((2600, 1), ('cheb_ord_kernel', 4112, 2, 2)),
+    ((6000, 1), ('cheb_ord_kernel', 6160, 4, 3)),
+    ((8000, 1), ('cheb_ord_kernel', 8208, 5, 4)),
+    ((9000, 1), ('cheb_ord_kernel', 10240, 5, 5)),
+    ((10000, 0), ('cheb_ord_kernel', 10240, 5, 5)),         # the benchmark's points without a coarsening level
+    ((10000, 1), ('cheb_ord_kernel', 10240, 6, 5)),         # the benchmark graph
+    ((10239, 0), ('cheb_ord2_kernel', 10256, 5, 5)),        # 2560 quads of rows: two entries too many for 16-byte entries
+    ((10242, 1), ('cheb_ord2_kernel', 12304, 6, 6)),        # a 10242-vertex cortical mesh's size
+    ((13000, 1), ('cheb_ord2_kernel', 14352, 7, 7)),
+    ((19000, 1), ('cheb_ord2_kernel', 20480, 10, 10)),
+]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def _sparse64(Lcsr, dev):
+    return torch.sparse_csr_tensor(torch.as_tensor(Lcsr.indptr.astype(np.int64)), torch.as_tensor(Lcsr.indices.astype(np.int64)),
+                                   torch.as_tensor(Lcsr.data.astype(np.float64)), size=Lcsr.shape).to(dev)
+
+
+@pytest.mark.parametrize('K', [5, 2, 3])
+@pytest.mark.parametrize('graph_key,shape', SHAPES, ids=['n%d_l%d' % k for k, _ in SHAPES])
+def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
+    import bench
+    from gcn_fmri_decoding_amd import _lib, graph, ops
+    from oracle import graph_ref as GR
+    lib = _lib.lib()
+    family, ENT, NQ, NG = shape
+    PL = 4 if family == 'cheb_ord_kernel' else 2
+    if K != 5 and graph_key not in ((2600, 1), (10000, 1), (10242, 1)):
+        pytest.skip('K = 2, 3 on one graph per kernel family and the smallest shape')
+    Ls, _ = bench.load_graph(graph_key[0], graph_key[1], 0, 1, None)
+    L0 = Ls[0]
+    M = L0.shape[0]
+    order = graph.length_order(L0)
+    g = ops.Graph(L0, dev, order=order)
+    assert g.ordered, 'no ordered kernel shape for M = %d' % M
+    assert g.query(16) == PL
+    L = graph.permute(L0, order)
+    Mp = g.Mp
+    name_f = '%s<%d,%d,%d,512,false>' % (family, ENT, NQ, NG)
+    name_a = '%s<%d,%d,%d,512,true>' % (family, ENT, NQ, NG)
+    # more plane groups than the launch has workgroups (256 CUs x at most 2 workgroups), partial last group
+    B, Fin = 7, 301 if PL == 4 else 151
+    nplanes = B * Fin
+    assert nplanes % PL != 0 and (nplanes + PL - 1) // PL > 2 * 256
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(graph_key[0] + K)
+    x = torch.randn((B, Fin, Mp), generator=gen, device=dev)
+    x[:, :, M:] = float('nan')
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    stack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, st), 'fwd copy')
+    assert _lib.last_dispatch() == name_f
+    stack2 = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    stack2[0].copy_(x)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(stack2), P(stack2), B, Fin, K, st), 'fwd in place')
+    assert _lib.last_dispatch() == name_f
+    assert torch.equal(stack[:, :, :, :M], stack2[:, :, :, :M]), 'in place and copied T_0 differ'
+    assert torch.isfinite(stack[:, :, :, :M]).all()
+    del stack2
+
+    Lr = GR.rescale_L(L, 2)
+    L64 = Lr.astype(np.float64).tocsr()
+    Ld = _sparse64(L64, dev)
+    X = x[:, :, :M].double().reshape(nplanes, M).t().contiguous()
+    T64 = [X, torch.sparse.mm(Ld, X)]
+    for k in range(2, K):
+        T64.append(2 * torch.sparse.mm(Ld, T64[-1]) - T64[-2])
+    for (b, f) in [(0, 0), (B // 2, 5), (B - 1, Fin - 1)]:       # the float64 device recurrence against the CPU oracle
+        t0, t1 = x[b, f, :M].cpu().numpy().astype(np.float64), None
+        t1 = L64 @ t0
+        for k in range(2, K):
+            t0, t1 = t1, 2 * (L64 @ t1) - t0
+        got = T64[K - 1][:, b * Fin + f].cpu().numpy()
+        assert np.abs(got - t1).max() <= 1e-12 * np.abs(t1).max()
+    worst_f = 0.0
+    for k in range(K):
+        got = stack[k, :, :, :M].reshape(nplanes, M).double()
+        ref = T64[k].t()
+        per_plane = (got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)
+        worst_f = max(worst_f, float(per_plane.max()))
+        assert float(per_plane.max()) <= REL, '%s order %d: plane %d is %.3e from float64' % (
+            name_f, k, int(per_plane.argmax()), float(per_plane.max()))
+    del X, T64, stack
+
+    G = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    G[:, :, :, M:] = float('nan')
+    dx = torch.full((B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, st), 'bwd')
+    assert _lib.last_dispatch() == name_a
+    assert torch.isfinite(dx[:, :, :M]).all()
+    LTd = _sparse64(L64.T.tocsr(), dev)
+    Gk = lambda k: G[k, :, :, :M].double().reshape(nplanes, M).t().contiguous()
+    c2, c1 = torch.zeros_like(Gk(0)), Gk(K - 1)
+    for j in range(K - 2, 0, -1):
+        c2, c1 = c1, Gk(j) + 2 * torch.sparse.mm(LTd, c1) - c2
+    dref = (Gk(0) + torch.sparse.mm(LTd, c1) - c2).t()
+    gotx = dx[:, :, :M].reshape(nplanes, M).double()
+    per_plane = (gotx - dref).abs().amax(dim=1) / dref.abs().amax(dim=1)
+    record_measured('ordered_recurrence_every_plane[n%d_l%d,K%d]' % (graph_key[0], graph_key[1], K), kernel=name_f,
+                    fwd_worst_plane=worst_f, adjoint_worst_plane=float(per_plane.max()), planes=nplanes)
+    assert float(per_plane.max()) <= GREL, '%s: plane %d is %.3e from float64' % (name_a, int(per_plane.argmax()), float(per_plane.max()))
+
+
+def test_ordered_recurrence_not_for_atlas_sizes(dev):
+    """Up to 2048 active vertices the generic on-chip kernel and the fused atlas layer work in the caller's order: a graph in
+    length order gets no ordered image there (and cgcnn keeps the reference's tree order, models_gcn.py)."""
+    import bench
+    from gcn_fmri_decoding_amd import graph, ops
+    Ls, _ = bench.load_graph(1000, 1, 0, 1, None)
+    g = ops.Graph(Ls[0], dev, order=graph.length_order(Ls[0]))
+    assert not g.ordered and g.query(16) == 0

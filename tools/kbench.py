@@ -29,6 +29,7 @@ def main():
                                                      'contract_bwd_w_relu', 'contract_bwd_x_relu', 'bias_grad_relu', 'contract_bwd_w', 'contract_bwd_x',
                                                      'brelu_pool_bwd'])
     ap.add_argument('--nodes', type=int, default=10000, help='points of the synthetic kNN graph (10000 -> M = 10466)')
+    ap.add_argument('--levels', type=int, default=1, help='coarsening levels of the synthetic graph (1 -> fake vertices behind the real ones)')
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (0 = automatic, 2, 4)')
     ap.add_argument('--order', default='length', choices=['length', 'reference'],
@@ -43,7 +44,7 @@ def main():
     import bench
     from gcn_fmri_decoding_amd import _lib, ops
     dev = torch.device('cuda:0')
-    Ls, perm = bench.load_graph(args.nodes, 1, 0, 1, None)
+    Ls, perm = bench.load_graph(args.nodes, args.levels, 0, 1, None)
     lib = _lib.lib()
     import ctypes
     handle = ctypes.CDLL(_lib.LIB_PATH)
@@ -55,7 +56,7 @@ def main():
         tune(4, args.stagger)
     from gcn_fmri_decoding_amd import graph as G
     g = ops.Graph(Ls[0], dev, planes=args.planes, order=G.length_order(Ls[0]) if (args.order == 'length' and not args.planes) else None)
-    print('ordered recurrence kernels:', bool(g.query(12)), flush=True)
+    print('ordered recurrence kernels:', bool(g.query(12)), ' planes of the ordered image:', g.query(16), flush=True)
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
           g.query(11), flush=True)
     M, Mp = g.M, g.Mp
