@@ -241,8 +241,17 @@ softmax_xent_kernel(const float* __restrict__ z, const LabelT* __restrict__ y, f
     for (int b = threadIdx.x; b < B; b += 256) {
         const float* row = z + (size_t)b * C;
         long long t = (long long)y[b];
-        t = t < 0 ? 0 : t >= C ? C - 1 : t;                   // (a label outside [0, C) is the caller's error: clamped, not read past the row)
+        // a label outside [0, C) is the caller's error.  TensorFlow's GPU kernel answers with NaN for that row's loss and
+        // gradient (its CPU kernel raises); so does this one -- the loss of the step is NaN and the error surfaces -- and the
+        // row is never read past its end
+        const bool bad = t < 0 || t >= C;
+        t = t < 0 ? 0 : t >= C ? C - 1 : t;
         float* drow = dz + (size_t)b * C;
+        if (bad) {
+            acc += __builtin_nanf("");
+            for (int c = 0; c < C; ++c) drow[c] = __builtin_nanf("");
+            continue;
+        }
         if (C <= XENT_REG) {
             // the row in registers: ONE memory round trip (a loop over row[c] is a dependent load per class and pass: 12 us for
             // 128 x 22 logits)

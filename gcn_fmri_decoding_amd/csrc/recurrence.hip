@@ -642,7 +642,12 @@ static int dispatch_onchip(const chebgcn_graph* g, const Ell& ell, const float* 
         return nj * nthr >= rows && nq * nthr >= Mq && ell.lds_entries <= lds_capacity(nj, nthr, P);
     };
 #define CG_TRY(NJ, NQ, NTHR) if (fits(NJ, NQ, NTHR)) return launch_onchip<P, NJ, NQ, NTHR, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
-    CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256); CG_TRY(4, 2, 256); CG_TRY(8, 2, 256); CG_TRY(8, 3, 256);   // <= 2048 rows
+    // <= 2048 rows (the shapes with more linear pieces than a quarter of the rows serve four planes only: there the isolated
+    // vertices have pieces but no rows; with two planes every vertex is a row and the shape before them always fits)
+    CG_TRY(1, 1, 256); CG_TRY(2, 1, 256); CG_TRY(4, 1, 256);
+    if constexpr (P == 4) { CG_TRY(4, 2, 256); }
+    CG_TRY(8, 2, 256);
+    if constexpr (P == 4) { CG_TRY(8, 3, 256); }
     if constexpr (P == 4) {
         // beyond 2048 rows: the dedicated kernel of recurrence4.hip
         return dispatch_onchip4<ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);

@@ -43,6 +43,48 @@ class _Spec:
         self.vaxis = vaxis
 
 
+class InternalPlanes(object):
+    """A batch in plane storage ``[B, channel, Mp]`` whose vertex axis is ALREADY in a model's internal vertex order
+    (``cgcnn.vertex_order``): what ``_gather`` and ``compose_perm`` staging produce and what ``train_step`` /
+    ``_inference_storage`` take as is.  A plain tensor handed to those is in the caller's order and is relabelled.
+
+    The order is a property of this wrapper, not of the tensor: nothing a tensor operation returns (a slice, ``.clone()``,
+    ``.contiguous()``, ``.to()``, a data-parallel shard) can carry it along by accident or lose it silently.  Batch slices,
+    ``clone`` and ``detach`` are offered here and stay wrapped; ``planes`` is the tensor for code that knows what it holds."""
+    __slots__ = ('planes', 'owner')
+
+    def __init__(self, planes, owner):
+        if isinstance(planes, InternalPlanes):
+            planes = planes.planes
+        self.planes, self.owner = planes, owner
+
+    shape = property(lambda self: self.planes.shape)
+    device = property(lambda self: self.planes.device)
+
+    def __len__(self):
+        return self.planes.shape[0]
+
+    def __getitem__(self, windows):
+        """A slice / index set over the WINDOW axis only (the vertex axis must stay whole)."""
+        if isinstance(windows, tuple):
+            raise IndexError('InternalPlanes: index the window axis only')
+        picked = self.planes[windows]
+        return InternalPlanes(picked if picked.dim() == 3 else picked.unsqueeze(0), self.owner)
+
+    def clone(self):
+        return InternalPlanes(self.planes.clone(), self.owner)
+
+    def detach(self):
+        return InternalPlanes(self.planes.detach(), self.owner)
+
+    def copy_(self, other):
+        """Refill the buffer from another batch in the same internal order (a plain tensor here would be ambiguous)."""
+        if not isinstance(other, InternalPlanes) or other.owner is not self.owner:
+            raise TypeError('InternalPlanes.copy_: the source must be a batch in the same model\'s internal order')
+        self.planes.copy_(other.planes)
+        return self
+
+
 class base_model(object):
     """Counterpart of ``base_model`` (:18-355): run-time interface + variable helpers."""
 
@@ -68,6 +110,7 @@ class base_model(object):
         self._params = {}
         self._dp = None                 # optional data-parallel helper (dist.DataParallel)
         self._step_graph_on, self._sg, self._sg_warm = False, None, 0      # enable_step_graph()
+        self._step_graph_user = None    # the caller's explicit enable_step_graph(True / False), None = never asked
         self._order = None              # internal vertex order (cgcnn: graph.length_order), None = the caller's
         self.record_fit = False         # keep the sampled indices and the loss_average series of fit()
 
@@ -97,22 +140,31 @@ class base_model(object):
     def compose_perm(self, perm=None):
         """Index map (device int32) for ``ops.perm_data`` that takes raw data columns straight to the model's internal
         vertex order: ``perm[order]`` for the list ``coarsening.compute_perm`` returned (None: the identity).  Batches staged
-        with it are marked with ``as_internal``."""
+        with it are wrapped with ``as_internal``."""
         perm = np.arange(self._M0, dtype=np.int64) if perm is None else np.asarray(perm, np.int64)
         if self._order is not None:
             perm = perm[self._order]
         return torch.as_tensor(perm.astype(np.int32)).to(self.device)
 
     def as_internal(self, x_storage):
-        """Marks plane storage as being in the model's internal vertex order already (``_inference_storage`` relabels
-        unmarked input itself, one gather kernel per batch)."""
-        x_storage._chebgcn_internal = True
-        return x_storage
+        """Declares plane storage to be in this model's internal vertex order already: returns it wrapped as
+        ``InternalPlanes`` (``train_step`` / ``_inference_storage`` relabel a plain tensor themselves, one gather kernel per
+        batch).  The declaration lives in the wrapper, never on the tensor."""
+        return InternalPlanes(x_storage, self)
 
     def _to_internal(self, x_storage):
-        if self._order is None or getattr(x_storage, '_chebgcn_internal', False):
+        """The batch as a plain tensor in the internal vertex order."""
+        if isinstance(x_storage, InternalPlanes):
+            if x_storage.owner is not self and not self._same_order(x_storage.owner):
+                raise ValueError('this batch is in the internal vertex order of another model')
+            return x_storage.planes
+        if self._order is None:
             return x_storage
-        return self.as_internal(x_storage.index_select(2, self._order_pad))
+        return x_storage.index_select(2, self._order_pad)
+
+    def _same_order(self, other):
+        a, b = self._order, getattr(other, '_order', None)
+        return (a is None and b is None) or (a is not None and b is not None and np.array_equal(a, b))
 
     def predict(self, data, labels=None, sess=None):
         """Batched prediction (:31-71).  The last batch is zero-padded to ``batch_size``
@@ -130,7 +182,7 @@ class base_model(object):
                 x = self._gather(data_dev, torch.as_tensor(idx, dtype=torch.int32).to(self.device))
                 if end - begin < self.batch_size:
                     pad = ops.plane_empty(self.batch_size, x.shape[1], data_dev.shape[1], self.device, zero=True)
-                    pad[:end - begin] = x
+                    pad[:end - begin] = x.planes
                     x = self.as_internal(pad)
                 with torch.no_grad():
                     logits = self._inference_storage(x, 1)
@@ -199,12 +251,27 @@ class base_model(object):
         self._init_variables()
         if self._dp is not None:
             self._dp.broadcast_parameters()
-        if self._auto_step_graph():
+        auto_graph = self._step_graph_user is None and not self._step_graph_on and self._auto_step_graph()
+        if auto_graph:
             # atlas-sized graphs (what the reference trains on): the step is a chain of ~100 kernels of 3-60 us and launch-bound;
-            # captured once as a HIP graph it is the same kernels on the same operands, bit for bit (enable_step_graph)
-            self.enable_step_graph(True)
+            # captured once as a HIP graph it is the same kernels on the same operands, bit for bit (enable_step_graph).
+            # An explicit enable_step_graph(True / False) of the caller is left alone; fit() switches its own choice off
+            # again when it returns
+            self.enable_step_graph(True, _by_fit=True)
+        try:
+            return self._fit_loop(train_data, train_labels, val_data, val_labels, t_process, t_wall, rank0, say)
+        finally:
+            self.fit_captured = self._sg is not None      # whether the loop ran the captured step (tests, bench)
+            if auto_graph:
+                self.enable_step_graph(False, _by_fit=True)
+
+    def _fit_loop(self, train_data, train_labels, val_data, val_labels, t_process, t_wall, rank0, say):
         train_dev, val_dev = self.stage(train_data), self.stage(val_data)
         train_labels = np.asarray(train_labels)
+        n_classes = int(self.M[-1])
+        if train_labels.size and (train_labels.min() < 0 or train_labels.max() >= n_classes):
+            # (tf.nn.sparse_softmax_cross_entropy_with_logits raises on the CPU and returns NaN on the GPU, :257)
+            raise ValueError('fit(): labels must lie in [0, %d); got %d ... %d' % (n_classes, train_labels.min(), train_labels.max()))
         labels_dev = torch.as_tensor(train_labels.astype(np.int64)).to(self.device)
         accuracies, losses = [], []
         best = []
@@ -489,7 +556,7 @@ class base_model(object):
 
     # ---------------------------------------------------------------- captured step (HIP graph)
 
-    def enable_step_graph(self, on=True):
+    def enable_step_graph(self, on=True, _by_fit=False):
         """Run ``train_step`` as ONE captured HIP graph (``torch.cuda.CUDAGraph`` on ROCm = hipGraph): the first two
         calls run eagerly (library initialisation), the third captures -- forward, loss, backward, Adam and the loss
         bookkeeping, the second stream of ``contract_bwd_w`` included -- and every later call copies the batch into
@@ -498,6 +565,8 @@ class base_model(object):
         Under ``dist.DataParallel`` on RCCL the gradient all-reduces are captured with the step (they are enqueued on
         streams like kernels, forked from and joined to the capture stream) and replayed with it; on other backends
         (gloo) the step stays eager.  While per-kernel event timers are set (``ops.timers``) the step runs eagerly too."""
+        if not _by_fit:
+            self._step_graph_user = bool(on)      # an explicit choice: fit() does not override it
         self._step_graph_on = bool(on)
         self._drop_step_graph()
         self._sg_warm = 0
@@ -521,7 +590,7 @@ class base_model(object):
             if self._sg_warm < 2:
                 self._sg_warm += 1
                 t = self.global_step + 1
-                loss_average = self._step_body(x_storage, labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
+                loss_average = self._step_body(self.as_internal(x_storage), labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
                 self.global_step += 1
                 return self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum), loss_average
             self._drop_step_graph()
@@ -541,7 +610,7 @@ class base_model(object):
         if ops.timers is not None:
             raise RuntimeError('per-kernel event timers cannot run inside a captured step')
         dev = self.device
-        sg = {'x': self.as_internal(x_storage.detach().clone()), 'labels': labels.detach().clone(),
+        sg = {'x': x_storage.detach().clone(), 'labels': labels.detach().clone(),
               'lr_t': torch.zeros(1, dtype=torch.float32, device=dev), 'ema_c': torch.zeros(1, dtype=torch.float32, device=dev)}
         if self._loss_ema is None:
             self._loss_ema = torch.zeros((), dtype=torch.float32, device=dev)
@@ -552,7 +621,7 @@ class base_model(object):
         ops.capture_tag = cgcnn._captures
         try:
             with torch.cuda.graph(graph):
-                sg['loss_average'] = self._step_body(sg['x'], sg['labels'], sg['lr_t'], sg['ema_c'][0])
+                sg['loss_average'] = self._step_body(self.as_internal(sg['x']), sg['labels'], sg['lr_t'], sg['ema_c'][0])
         finally:
             ops.capture_tag = None
         sg['graph'] = graph
@@ -988,7 +1057,7 @@ class cgcnn(base_model):
                 raise RuntimeError('this model keeps its per-vertex variables in a relabelled vertex order (vertex_order = '
                                    "'length'), which the layer-by-layer path does not know: construct it with "
                                    "CHEBGCN_VERTEX_ORDER=reference to replace filter / brelu / pool methods")
-            return self._inference(ops.plane_view(x, self.L[0].shape[0]), dropout)
+            return self._inference(ops.plane_view(self._to_internal(x), self.L[0].shape[0]), dropout)
         x = self._to_internal(x)
         nl = len(self.p)
         B = x.shape[0]
@@ -1134,8 +1203,8 @@ class model_perf(object):
             x = model._gather(data_dev, idx)
             if end - begin < batch_size:
                 pad = ops.plane_empty(batch_size, x.shape[1], data_dev.shape[1], model.device, zero=True)
-                pad[:end - begin] = x
-                x = pad
+                pad[:end - begin] = x.planes
+                x = model.as_internal(pad)
             batch_labels = np.zeros(batch_size, np.int64)
             batch_labels[:end - begin] = test_labels[begin:end]
             with torch.no_grad():

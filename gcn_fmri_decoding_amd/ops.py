@@ -359,6 +359,11 @@ def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout
                'contract_fwd_bf16')
 
 
+def _grad_mode(bufs):
+    """Grad mode of the caller of ``cheb_conv`` (``Buffers.grad_mode``); a bare ``ChebConv.apply`` without buffers: on."""
+    return True if bufs is None else bool(bufs.grad_mode)
+
+
 class ChebConv(torch.autograd.Function):
     """y = pool(act(sum_k T_k(L~) x W_k + bias)) on plane storage tensors.
 
@@ -403,7 +408,7 @@ class ChebConv(torch.autograd.Function):
         if mean:
             if not conv_mean_supported(B, M, Fin, K, Fout, pool, relu, getattr(bufs, 'precision', 'f32')):
                 raise ValueError('cheb_conv(mean=True): layer not served (ops.conv_mean_supported)')
-            wants_grad = any(ctx.needs_input_grad[:3])
+            wants_grad = _grad_mode(bufs) and any(ctx.needs_input_grad[:3])
             mask = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device) if wants_grad else None
             y = torch.empty((B, Mp), dtype=torch.float32, device=x.device)
             b = bias.detach().contiguous() if bias is not None else None
@@ -430,7 +435,7 @@ class ChebConv(torch.autograd.Function):
         # pool == 1 with ReLU: contract_fwd leaves a bit per vertex (the ReLU mask) and the gradients of the
         # contraction gate the incoming gradient themselves -- no dy tensor, no pass over `out` in backward
         fold = bool(fold_relu_grad and pool == 1 and relu and precision == 'f32')
-        wants_grad = any(ctx.needs_input_grad[:3])       # inference: no mask is written
+        wants_grad = _grad_mode(bufs) and any(ctx.needs_input_grad[:3])       # inference: no mask is written
         if pool == 1 and relu and wants_grad:
             # the mask also serves the separate ReluGrad pass (bf16 gradients): a byte per four vertices instead of `out`
             argmax = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device)
@@ -452,8 +457,8 @@ class ChebConv(torch.autograd.Function):
         lib = _lib.lib()
         B, Fin, Mp = x.shape
         M, Fout = graph.M, Wc.shape[1]
-        need_w = bool(ctx.needs_input_grad[1])
-        wants_grad = any(ctx.needs_input_grad[:3])
+        need_w = bool(_grad_mode(bufs) and ctx.needs_input_grad[1])
+        wants_grad = _grad_mode(bufs) and any(ctx.needs_input_grad[:3])
         if not need_w:
             stack = None                          # nothing will read it (inference, frozen weights): it is never written
         elif stack is None:
@@ -652,11 +657,15 @@ class Buffers:
     kernels are enqueued (dist.DataParallel starts the layer's all-reduce from it).  ``mean``: the
     layer is followed by ``tf.reduce_mean(x, -1)`` (models_gcn.py:673) and returns that mean, storage
     [B, Mp], instead of its output (chebgcn_contract_fwd_mean; the gradients read one plane per window)."""
-    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean')
+    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean', 'grad_mode')
 
     def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False):
         self.stack, self.out, self.dW, self.dbias, self.precision, self.done = stack, out, dW, dbias, precision, done
         self.mean = mean          # the layer returns the mean over its filters, [B, Mp] (see conv_mean_supported)
+        # the caller's grad mode: inside Function.forward grad mode is always off, and ``ctx.needs_input_grad`` is True for a
+        # Parameter even under torch.no_grad() -- with this off nothing that only a backward pass would read is written
+        # (the ReLU mask; in the fused atlas layer the whole K-slab stack)
+        self.grad_mode = torch.is_grad_enabled()
 
 
 def conv_mean_supported(B, M, Fin, K, Fout, pool, relu, precision='f32'):
@@ -670,10 +679,7 @@ def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias
     """``precision``: arithmetic of the contraction and of its two gradients ('f32', 'bf16', 'bf16x3':
     chebgcn_contract_fwd_bf16 / _bwd_x_bf16 / _bwd_w_bf16 with 1 or 3 passes); storage, the recurrence, its adjoint
     and the bias / ReLU / pooling gradients stay fp32."""
-    bufs = None
-    if (stack is not None or out is not None or dW is not None or dbias is not None or precision != 'f32' or done is not None
-            or mean):
-        bufs = Buffers(stack, out, dW, dbias, precision, done, mean)
+    bufs = Buffers(stack, out, dW, dbias, precision, done, mean)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 

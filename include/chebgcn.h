@@ -315,7 +315,8 @@ int chebgcn_loss_bookkeeping(const float* cross_entropy, const float* sq_partial
 /* ---- loss: tf.nn.sparse_softmax_cross_entropy_with_logits + tf.reduce_mean (models_gcn.py:257-259) and its gradient wrt
  * the logits, one launch:  *loss = mean_b( logsumexp(z_b) - z_b[y_b] ),  dlogits[b][c] = (softmax(z_b)[c] - [c == y_b]) / B.
  * logits, dlogits: [B][C] dense; labels: [B] int32 (labels_int64 = 0) or int64 (1), values in [0, C); loss: one float.
- * Deterministic (fixed-order sums). */
+ * A label outside [0, C) makes *loss and that row of dlogits NaN (what TensorFlow's GPU kernel returns for it; nothing is
+ * read or written outside the row).  Deterministic (fixed-order sums). */
 int chebgcn_softmax_xent(const float* logits, const void* labels, int labels_int64, float* loss, float* dlogits, int B,
                          int C, chebgcn_stream stream);
 

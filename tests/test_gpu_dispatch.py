@@ -461,6 +461,30 @@ def test_internal_vertex_order_is_invisible(ops, dev, monkeypatch):
     with torch.no_grad():
         la, lb = a._inference_storage(x, 1).cpu().numpy(), b._inference_storage(x, 1).cpu().numpy()
     assert np.abs(la - lb).max() <= REL * np.abs(lb).max()
+    # The order a batch is in is carried by a wrapper (models_gcn.InternalPlanes), never by the tensor: whatever tensor
+    # operations produce is a plain tensor = the caller's order; slices / clones OF THE WRAPPER stay in the internal order.
+    with torch.no_grad():
+        for xv in (x.clone(), x[:], x.contiguous(), x[0:B]):
+            assert np.array_equal(a._inference_storage(xv, 1).cpu().numpy(), la)
+        raw = torch.as_tensor(rs.randn(B + 2, M, C).astype(np.float32)).to(dev)
+        xi = a._gather(raw, torch.arange(B, dtype=torch.int32, device=dev))             # staged: wrapped, internal order
+        assert isinstance(xi, models_gcn.InternalPlanes) and xi.shape == x.shape
+        li = a._inference_storage(xi, 1).cpu().numpy()
+        xr = raw[:B].permute(0, 2, 1).contiguous()                                        # the same batch, caller's order
+        xc = torch.zeros_like(x)
+        xc[:, :, :M] = xr
+        assert np.array_equal(a._inference_storage(xc, 1).cpu().numpy(), li)
+        for xv in (xi.clone(), xi[:], xi.detach(), xi[0:B]):
+            assert isinstance(xv, models_gcn.InternalPlanes)
+            assert np.array_equal(a._inference_storage(xv, 1).cpu().numpy(), li)
+        l13 = a._inference_storage(xi[1:3], 1).cpu().numpy()                              # (a smaller launch: other kernel arms)
+        assert np.abs(l13 - li[1:3]).max() <= REL * np.abs(li).max()
+        with pytest.raises(IndexError):
+            xi[:, 0]
+        with pytest.raises(ValueError):
+            b._inference_storage(xi, 1)              # another model's internal order
+        lb2 = b._inference_storage(b._gather(raw, torch.arange(B, dtype=torch.int32, device=dev)), 1).cpu().numpy()
+        assert np.abs(li - lb2).max() <= REL * np.abs(lb2).max()
     _, loss_a = a.train_step(x, ld)
     _, loss_b = b.train_step(x, ld)
     assert abs(float(loss_a) - float(loss_b)) <= REL * abs(float(loss_b))
@@ -702,6 +726,15 @@ def test_softmax_xent_vs_float64(ops, dev, B, C, dtype):
     assert e_l <= 1e-6 and e_d <= 2e-6, (e_l, e_d)
     loss2, dz2 = ops.softmax_xent(zd, yd)
     assert torch.equal(loss, loss2) and torch.equal(dz, dz2)
+    # a label outside [0, C) (e.g. 1-based labels): NaN loss and NaN gradient for that row, like TensorFlow's GPU kernel --
+    # never a finite loss against a clamped class; the other rows keep their gradients
+    for bad in (C, -1):
+        yb = y.copy()
+        yb[B // 2] = bad
+        loss3, dz3 = ops.softmax_xent(zd, torch.as_tensor(yb).to(dev).to(dtype))
+        assert torch.isnan(loss3).all() and torch.isnan(dz3[B // 2]).all()
+        keep = [b for b in range(B) if b != B // 2]
+        assert torch.equal(dz3[keep], dz[keep])
 
 
 @pytest.mark.parametrize('n,dev_scalars', [(1000, False), (700001, True), (2500000, False)])

@@ -89,7 +89,9 @@ def test_fit_predict_loop_vs_oracle(dev, name, step_graph, tmp_path, monkeypatch
     np.random.seed(2024)
     acc, losses, t_step = net.fit(data, labels, vdata, vlabels)
     assert net.global_step == log['num_steps']
-    assert (net._sg is not None) == (step_graph == 'auto'), 'fit() did not take the %s step' % ('captured' if step_graph == 'auto' else 'eager')
+    assert net.fit_captured == (step_graph == 'auto'), 'fit() did not take the %s step' % ('captured' if step_graph == 'auto' else 'eager')
+    # fit()'s own choice ends with fit(): later train_step calls of the caller are eager unless the caller asks
+    assert net._sg is None and not net._step_graph_on and net._step_graph_user is None
     assert [i.tolist() for i in net.fit_log['idx']] == [i.tolist() for i in log['idx']]      # same samples, same order
     np.testing.assert_allclose(net.fit_log['loss_average'], log['loss_average'], rtol=5e-5)
     np.testing.assert_allclose(losses, log['losses'], rtol=5e-5)                              # incl. the padded last batch

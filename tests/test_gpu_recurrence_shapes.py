@@ -1,9 +1,14 @@
-"""The ordered Chebyshev recurrence (csrc/recurrence_ord_kernel.h) over the graph sizes it serves, every kernel shape BY NAME.
-Needs an MI355X: ``-m gpu``.
+"""Every kernel shape of the Chebyshev recurrence BY NAME, over the graph sizes that reach it.  Needs an MI355X: ``-m gpu``.
+
+Part 1: the ordered kernels (csrc/recurrence_ord_kernel.h).  Part 2 (``test_caller_order_recurrence_shape``): the kernels a
+graph in the caller's vertex order runs -- networks with pooling, atlas sizes, pinned plane counts, sizes the ordered kernels
+do not serve (csrc/recurrence.hip ``dispatch_onchip``: 256 / 512 / 768 threads, 1..40 rows per thread, two or four planes;
+csrc/recurrence4.hip ``dispatch_onchip4``: four planes beyond 2048 rows).
 
 A network without pooling relabels its vertices by descending row length (``graph.length_order``), and the library then runs
 ``cheb_ord_kernel<ENT,NQ,NG,512,*>`` (four planes per workgroup, 16-byte LDS entries: 2049 ... 10238 active vertices) or
-``cheb_ord2_kernel<...>`` (two planes, 8-byte entries: up to 20476).  NG = quad levels with rows = ceil(active / 4 / 512),
+``cheb_ord2_kernel<...>`` (two planes, 8-byte entries: from 10753 vertices up to 20476 active ones; in the window between, the
+768-thread two-plane kernel of recurrence.hip on the caller's order is faster and is what runs).  NG = quad levels with rows = ceil(active / 4 / 512),
 NQ = quad levels in all = ceil(Mp / 4 / 512).  Reference semantics: ``lib_new/models_gcn.py:598-610`` (the recurrence),
 ``lib_new/graph.py:155-172`` (``graph.chebyshev``, the oracle's twin), TF autodiff of it for the adjoint.
 
@@ -32,8 +37,11 @@ SHAPES = [
     ((9000, 1), ('cheb_ord_kernel', 10240, 5, 5)),
     ((10000, 0), ('cheb_ord_kernel', 10240, 5, 5)),         # the benchmark's points without a coarsening level
     ((10000, 1), ('cheb_ord_kernel', 10240, 6, 5)),         # the benchmark graph
-    ((10239, 0), ('cheb_ord2_kernel', 10256, 5, 5)),        # 2560 quads of rows: two entries too many for 16-byte entries
-    ((10242, 1), ('cheb_ord2_kernel', 12304, 6, 6)),        # a 10242-vertex cortical mesh's size
+    # 2560 quads of rows are two entries too many for 16-byte entries; up to 10752 vertices the two-plane kernel of recurrence.hip
+    # on the CALLER's order is the faster one (recurrence_ord.hip ordered_shape): no ordered image, that kernel by name
+    ((10239, 0), ('cheb_onchip_kernel', 2, 14, 4)),
+    ((10242, 1), ('cheb_onchip_kernel', 2, 14, 4)),         # a 10242-vertex cortical mesh's size (M = 10742)
+    ((11000, 1), ('cheb_ord2_kernel', 12304, 6, 6)),
     ((13000, 1), ('cheb_ord2_kernel', 14352, 7, 7)),
     ((19000, 1), ('cheb_ord2_kernel', 20480, 10, 10)),
 ]
@@ -59,19 +67,26 @@ def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
     lib = _lib.lib()
     family, ENT, NQ, NG = shape
     PL = 4 if family == 'cheb_ord_kernel' else 2
-    if K != 5 and graph_key not in ((2600, 1), (10000, 1), (10242, 1)):
+    ordered = family != 'cheb_onchip_kernel'
+    if K != 5 and graph_key not in ((2600, 1), (10000, 1), (11000, 1)):
         pytest.skip('K = 2, 3 on one graph per kernel family and the smallest shape')
     Ls, _ = bench.load_graph(graph_key[0], graph_key[1], 0, 1, None)
     L0 = Ls[0]
     M = L0.shape[0]
     order = graph.length_order(L0)
     g = ops.Graph(L0, dev, order=order)
-    assert g.ordered, 'no ordered kernel shape for M = %d' % M
-    assert g.query(16) == PL
-    L = graph.permute(L0, order)
+    if ordered:
+        assert g.ordered, 'no ordered kernel shape for M = %d' % M
+        assert g.query(16) == PL
+        L = graph.permute(L0, order)
+    else:
+        assert not g.ordered                      # cgcnn then keeps the caller's order (models_gcn.cgcnn.__init__)
+        g, L = ops.Graph(L0, dev), L0
+        assert g.query(6) == 2
     Mp = g.Mp
-    name_f = '%s<%d,%d,%d,512,false>' % (family, ENT, NQ, NG)
-    name_a = '%s<%d,%d,%d,512,true>' % (family, ENT, NQ, NG)
+    nt = 512 if ordered else 768
+    name_f = '%s<%d,%d,%d,%d,false>' % (family, ENT, NQ, NG, nt)
+    name_a = '%s<%d,%d,%d,%d,true>' % (family, ENT, NQ, NG, nt)
     # more plane groups than the launch has workgroups (256 CUs x at most 2 workgroups), partial last group
     B, Fin = 7, 301 if PL == 4 else 151
     nplanes = B * Fin
@@ -145,3 +160,73 @@ def test_ordered_recurrence_not_for_atlas_sizes(dev):
     Ls, _ = bench.load_graph(1000, 1, 0, 1, None)
     g = ops.Graph(Ls[0], dev, order=graph.length_order(Ls[0]))
     assert not g.ordered and g.query(16) == 0
+
+
+# (points, coarsening levels, planes asked for) -> template of chebgcn_recurrence_fwd / _bwd on a launch of 6 planes.
+# tools/shape_names.py prints this table for a list of sizes; it is every reachable arm of dispatch_onchip / dispatch_onchip4.
+ONCHIP = 'cheb_onchip_kernel<%d,%d,%d,%d,%s>'
+CALLER_ORDER = [
+    ((40, 1, 0), (4, 1, 1, 256)), ((40, 1, 2), (2, 1, 1, 256)), ((360, 1, 0), (4, 2, 1, 256)), ((360, 1, 2), (2, 2, 1, 256)),
+    ((500, 1, 2), (2, 4, 1, 256)), ((900, 1, 0), (4, 4, 1, 256)), ((1000, 1, 0), (4, 4, 2, 256)), ((1000, 1, 2), (2, 8, 2, 256)),
+    ((1500, 1, 0), (4, 8, 2, 256)), ((2000, 1, 0), (4, 8, 3, 256)), ((2000, 1, 2), (2, 8, 3, 512)), ((4000, 1, 2), (2, 8, 3, 768)),
+    ((6000, 1, 2), (2, 11, 4, 768)), ((10000, 1, 2), (2, 14, 4, 768)), ((10500, 1, 2), (2, 24, 7, 512)),
+    ((13000, 1, 2), (2, 32, 9, 512)), ((16000, 1, 2), (2, 40, 11, 512)),
+    # recurrence4.hip: <entries, rows per thread, pieces per thread, 512, adjoint, isolated vertices in registers>
+    ((2600, 1, 4), ('cheb4_kernel<5120,10,3,512,false,true>', 'cheb4_kernel<5120,10,3,512,true,false>')),
+    ((5000, 3, 4), ('cheb4_kernel<5120,10,3,512,false,false>', 'cheb4_kernel<5120,10,3,512,true,false>')),
+    ((5000, 6, 4), ('cheb4_kernel<5120,10,4,512,false,false>', 'cheb4_kernel<5120,10,4,512,true,false>')),
+    ((6000, 1, 4), ('cheb4_kernel<10240,20,6,512,false,true>', 'cheb4_kernel<10240,20,6,512,true,false>')),
+    ((9000, 3, 4), ('cheb4_kernel<10240,20,6,512,false,false>', 'cheb4_kernel<10240,20,6,512,true,false>')),
+    ((10000, 6, 4), ('cheb4_kernel<10240,20,7,512,false,false>', 'cheb4_kernel<10240,20,7,512,true,false>')),
+]
+
+
+@pytest.mark.parametrize('key,shape', CALLER_ORDER, ids=['n%d_l%d_p%d' % k for k, _ in CALLER_ORDER])
+def test_caller_order_recurrence_shape(dev, key, shape):
+    """Every plane of a launch of 7 planes (partial last group for either plane count), K = 5, against the CPU oracle
+    (``oracle/graph_ref.chebyshev`` = ``lib_new/graph.py:155-172``) and the float64 Clenshaw adjoint; x and G non-zero at the
+    coarsening's fake vertices, pads NaN."""
+    import bench
+    from gcn_fmri_decoding_amd import _lib, ops
+    from oracle import graph_ref as GR
+    lib = _lib.lib()
+    nodes, levels, planes = key
+    if len(shape) == 4:
+        name_f, name_a = ONCHIP % (shape + ('false',)), ONCHIP % (shape + ('true',))
+    else:
+        name_f, name_a = shape
+    Ls, _ = bench.load_graph(nodes, levels, 0, 1, None)
+    L = Ls[0]
+    M = L.shape[0]
+    g = ops.Graph(L, dev, planes=planes)
+    assert not g.ordered
+    B, Fin, K, Mp = 1, 7, 5, g.Mp
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(nodes + planes)
+    x = torch.randn((B, Fin, Mp), generator=gen, device=dev)
+    x[:, :, M:] = float('nan')
+    G = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    G[:, :, :, M:] = float('nan')
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    stack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, st), 'fwd')
+    assert _lib.last_dispatch() == name_f
+    dx = torch.full((B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, st), 'bwd')
+    assert _lib.last_dispatch() == name_a
+    Lr = GR.rescale_L(L, 2)
+    ref = GR.chebyshev(Lr, x[0, :, :M].cpu().numpy().T.copy(), K)                 # [K, M, Fin]
+    got = stack[:, 0, :, :M].permute(0, 2, 1).cpu().numpy()
+    e_f = max(np.abs(got[:, :, f] - ref[:, :, f]).max() / np.abs(ref[:, :, f]).max() for f in range(Fin))
+    LT = Lr.T.tocsr().astype(np.float64)
+    Gb = G[:, 0, :, :M].cpu().numpy().transpose(0, 2, 1).astype(np.float64)
+    c1, c2 = Gb[K - 1], np.zeros_like(Gb[0])
+    for j in range(K - 2, 0, -1):
+        c1, c2 = Gb[j] + 2 * (LT @ c1) - c2, c1
+    dref = Gb[0] + LT @ c1 - c2
+    gx = dx[0, :, :M].cpu().numpy().T
+    e_a = max(np.abs(gx[:, f] - dref[:, f]).max() / np.abs(dref[:, f]).max() for f in range(Fin))
+    record_measured('caller_order_recurrence_shape[n%d_l%d_p%d]' % key, kernel=name_f, fwd_worst_plane=e_f, adjoint_worst_plane=e_a)
+    assert e_f <= REL, '%s: %.3e' % (name_f, e_f)
+    assert e_a <= GREL, '%s: %.3e' % (name_a, e_a)
