@@ -95,16 +95,28 @@ __device__ long long g_dbgb[16 * 64];
 // a stage holds [16 rows][128 vertices] bf16 (4 KB, one DMA instruction per four rows), lane (c, g) reads the four vertices
 // 4c..4c+3 of its eight rows with ds_read_b64 and transposes 8 x 4 halves into the four operands with v_perm_b32 (as many
 // instructions as the fp32 -> bf16 conversions they replace).
-template <int PASSES, int NW, bool X16 = false>
+//
+// NVT: vertex tiles per work item.  With NVT = 1 the NW compute waves are NW filter slices of 64 on ONE tile of 128 vertices
+// (layers of 256 filters and more, the gradient wrt the stack).  A layer of 64 or 128 filters would leave three or two of
+// four waves multiplying padding (round 4: the config-4 forward, 64 filters, ran at 72 of the 288 TFLOP/s it issued): there
+// the waves are NW / NVT filter slices x NVT vertex tiles -- wave w = slice w % NWF of tile w / NWF -- a stage carries the
+// 16 reduction rows of all NVT tiles and the NWF slices of the packed W.
+template <int PASSES, int NW, bool X16 = false, int NVT = 1>
 struct Bf16Cfg {
+    static_assert(NW % NVT == 0 && (NVT == 1 || NW == 4), "compute waves = filter slices x vertex tiles");
+    static constexpr int NWF = NW / NVT;                          // filter slices of 64
     static constexpr int PARTS = PASSES == 3 ? 2 : 1;
-    static constexpr int WPART = NW * 64 * 32;                    // bytes of one bf16 image of W per stage
-    static constexpr int XPART = X16 ? 4096 : 8192;               // bytes of the reduction rows per stage
+    static constexpr int WPART = NWF * 64 * 32;                   // bytes of one bf16 image of W per stage
+    static constexpr int XTILE = X16 ? 4096 : 8192;               // bytes of the reduction rows of one vertex tile per stage
+    static constexpr int XPART = NVT * XTILE;
     static constexpr int STAGE = XPART + PARTS * WPART;           // bytes
     static constexpr int NSTAGE = (147456 / STAGE);               // <= 144 KB
-    static constexpr int NXDMA = X16 ? 1 : 2;                     // DMA instructions of the reduction rows per four rows and stage
-    static constexpr int NDMA1 = 2 * (NXDMA + 2 * PARTS);         // DMA instructions per stage of producer 1
-    static constexpr int NDMA0 = NDMA1 + (NW > 4 ? 2 * PARTS : 0);    // ... of producer 0
+    static constexpr int NXDMA = X16 ? 1 : 2;                     // DMA instructions of the reduction rows per four rows, tile and stage
+    // filter slice s of the packed W belongs to producer (s / 2) % 2 (one or two slices: s % 2)
+    static constexpr int NWS1 = NWF >= 4 ? 2 : NWF / 2;           // slices of producer 1
+    static constexpr int NWS0 = NWF - NWS1;                       // ... of producer 0
+    static constexpr int NDMA1 = 2 * NXDMA * NVT + 2 * PARTS * NWS1;  // DMA instructions per stage of producer 1
+    static constexpr int NDMA0 = 2 * NXDMA * NVT + 2 * PARTS * NWS0;  // ... of producer 0
     static constexpr int DEPTH = (NSTAGE - 2) < 63 / NDMA0 ? (NSTAGE - 2) : 63 / NDMA0;
     static_assert(DEPTH >= 2 && DEPTH * NDMA0 <= 63, "vmcnt is a 6-bit counter");
     // A per-vertex bias (b2relu: [Fout][Mp], as large as the result) travels through the SAME ring: after the k-steps of an
@@ -119,18 +131,19 @@ struct Bf16Cfg {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int PASSES, int NW, bool X16 = false>
+template <int PASSES, int NW, bool X16 = false, int NVT = 1>
 __global__ void __launch_bounds__((NW + 2) * 64)
 contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int FoutP, int ntm, int nitems) {
     static_assert(!X16 || PASSES == 1, "bf16 rows have no low part");
-    using C = Bf16Cfg<PASSES, NW, X16>;
+    using C = Bf16Cfg<PASSES, NW, X16, NVT>;
+    constexpr int NWF = C::NWF;
     extern __shared__ __attribute__((aligned(16))) char ring[];         // [NSTAGE][STAGE]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, g = lane >> 5;
     const size_t lo_part = (size_t)nks * FoutP * 16;                     // bf16 elements between the hi and lo image
 
-    // work item = (filter group of 256, window, 128 vertices), walked with the pipeline running.
+    // work item = (filter group of 64 NWF, window, 128 NVT vertices), walked with the pipeline running (ntm = tiles of 128 NVT).
     // XCD-aware order: workgroup w runs on XCD w % 8 (round-robin dispatch); XCD x takes the vertex tiles x, x + 8, ... for
     // ALL windows, so the per-vertex bias rows of its tiles (a wide layer's bias is [256][Mp] = 10.7 MB, more than one
     // 4 MB L2) stay in ITS L2 across the windows instead of being fetched again by whichever XCD meets the tile next.
@@ -155,15 +168,21 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
         const int nbias = (C::RING_BIAS && a.bias_kind == CHEBGCN_BIAS_VERTEX) ? C::BIAS_STEPS : 0;     // bias stages per item
         const int s16f = 16 / a.K, s16k = 16 % a.K;
         int pf[2][2], pk[2][2];
-        const float* p_base;                                       // window + vertex part of the source address
-        const __bf16* p_w;                                         // this lane's 16 bytes of the packed W, k-step 0, wave 0
+        // (hipcc 7.2: an array of template-dependent size captured by the lambdas below makes the HOST side drop the kernel's stub
+        // without a diagnostic -- the library then fails to load with an undefined symbol; a fixed size does not)
+        static_assert(NVT <= 4, "p_base");
+        const float* p_base[4];                                    // window + vertex part of the source address, per vertex tile
+        const __bf16* p_w;                                         // this lane's 16 bytes of the packed W, k-step 0, slice 0
         auto producer_item = [&]() {
             // (X16: addresses in units of float: a bf16 plane is Mp/2 floats long; lane l takes the 16-byte piece l%16 of its row)
-            int m = item_mt(p_it) * 128 + (X16 ? 8 * (lane & 15) : 4 * c);
-            if (m >= a.Mp) m = 0;                                  // beyond the plane: any readable address, never stored
-            p_base = X16 ? a.stack + (((size_t)item_b(p_it) * a.Fin * a.Mp + m) >> 1)
-                         : a.stack + (size_t)item_b(p_it) * a.Fin * a.Mp + m;
-            p_w = Wp + (size_t)item_z(p_it) * (NW * 64) * 16 + lane * 8;
+#pragma unroll
+            for (int t = 0; t < NVT; ++t) {
+                int m = (item_mt(p_it) * NVT + t) * 128 + (X16 ? 8 * (lane & 15) : 4 * c);
+                if (m >= a.Mp) m = 0;                              // beyond the plane: any readable address, never stored
+                p_base[t] = X16 ? a.stack + (((size_t)item_b(p_it) * a.Fin * a.Mp + m) >> 1)
+                                : a.stack + (size_t)item_b(p_it) * a.Fin * a.Mp + m;
+            }
+            p_w = Wp + (size_t)item_z(p_it) * (NWF * 64) * 16 + lane * 8;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -189,22 +208,30 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
         auto produce = [&](int slot) {
             const unsigned stage = (unsigned)(size_t)ring + slot * C::STAGE;
             if (C::RING_BIAS && p_ks >= nks) {
-                // bias stage i = p_ks - nks: instruction q of wave part v covers the rows rho = 2q, 2q + 1 (g = rho >> 2,
-                // jj = rho & 3) of [v][8 rows][128 vertices]: filter 64 v + 32 (i >> 2) + acc_row(4 (i & 3) + jj, g)
+                // bias stage i = p_ks - nks: instruction q of compute wave v covers the rows rho = 2q, 2q + 1 (g = rho >> 2,
+                // jj = rho & 3) of [v][8 rows][128 vertices]: filter 64 (v % NWF) + 32 (i >> 2) + acc_row(4 (i & 3) + jj, g) at
+                // the vertices of tile v / NWF
                 const int i = p_ks - nks;
-                int m = item_mt(p_it) * 128 + 4 * c;
-                if (m >= a.Mp) m = 0;
-#pragma unroll
-                for (int u = 0; u < C::NDMA1; ++u) {
+                auto bias_dma = [&](int u) __attribute__((always_inline)) {
                     const int uu = u & 7;                          // (beyond 8: padding, re-reads of the first ones into the unused W part)
                     const int j = uu >> 2, q = uu & 3;
                     const int v = 2 * pw + j;
                     const int rho = 2 * q + g;
-                    int fo = item_z(p_it) * (NW * 64) + 64 * v + 32 * (i >> 2) + acc_row(4 * (i & 3) + (rho & 3), rho >> 2);
+                    int m = (item_mt(p_it) * NVT + v / NWF) * 128 + 4 * c;
+                    if (m >= a.Mp) m = 0;
+                    int fo = item_z(p_it) * (NWF * 64) + 64 * (v % NWF) + 32 * (i >> 2) + acc_row(4 * (i & 3) + (rho & 3), rho >> 2);
                     if (fo >= a.Fout) fo = a.Fout - 1;
                     __builtin_amdgcn_global_load_lds(a.bias + (size_t)fo * a.Mp + m,
                                                      reinterpret_cast<__attribute__((address_space(3))) void*>(
                                                          u < 8 ? stage + v * 4096 + q * 1024 : stage + 16384 + pw * 4096 + q * 1024), 16, 0, 0);
+                };
+                // (a stage is the same number of DMA instructions whatever it carries: the vmcnt waits are constants per producer)
+                if (C::NDMA0 != C::NDMA1 && pw == 0) {
+#pragma unroll
+                    for (int u = 0; u < C::NDMA0; ++u) bias_dma(u);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < C::NDMA1; ++u) bias_dma(u);
                 }
                 if (++p_ks == nks + nbias) {
                     p_ks = 0;
@@ -221,17 +248,20 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
                     // rows beyond Fin*K re-read the last plane (finite data) against zero weights
                     const bool live = pf[j][q] < a.Fin;
                     const int fin = live ? pf[j][q] : a.Fin - 1, k = live ? pk[j][q] : a.K - 1;
-                    const float* src = X16 ? p_base + (((size_t)k * a.slab + (size_t)fin * a.Mp) >> 1)
-                                           : p_base + (size_t)k * a.slab + (size_t)fin * a.Mp;
-                    __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                                                              stage + (X16 ? v * 1024 : (4 * v + 2 * q) * 512)), 16, 0, 0);
+                    const size_t row_off = X16 ? (((size_t)k * a.slab + (size_t)fin * a.Mp) >> 1) : (size_t)k * a.slab + (size_t)fin * a.Mp;
+#pragma unroll
+                    for (int t = 0; t < NVT; ++t)
+                        __builtin_amdgcn_global_load_lds(p_base[t] + row_off, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                                                                  stage + t * C::XTILE + (X16 ? v * 1024 : (4 * v + 2 * q) * 512)), 16, 0, 0);
                     pk[j][q] += s16k;
                     pf[j][q] += s16f;
                     if (pk[j][q] >= a.K) { pk[j][q] -= a.K; ++pf[j][q]; }
                 }
-                w_dma(stage, v);
+                if (NWF >= 4) w_dma(stage, v);
             }
-            if (NW > 4 && pw == 0) w_dma(stage, 4);
+            if (NWF > 4 && pw == 0) w_dma(stage, 4);
+            if (NWF == 2) w_dma(stage, pw);
+            if (NWF == 1 && pw == 0) w_dma(stage, 0);
             p_w += w_step;
             if (++p_ks == nks + nbias) {
                 p_ks = 0;
@@ -259,9 +289,10 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
     // ---- compute waves ------------------------------------------------------------------------------------------------
     int cslot = 0;
     for (int it = lw; it < nmine; it += Lw) {
-        const int fo0 = (item_z(it) * NW + wave) * 64;
+        const int vf = NVT == 1 ? wave : wave % NWF, vt = NVT == 1 ? 0 : wave / NWF;       // filter slice, vertex tile of this wave
+        const int fo0 = (item_z(it) * NWF + vf) * 64;
         const int b = item_b(it);
-        const int n0 = item_mt(it) * 128 + 4 * c;
+        const int n0 = (item_mt(it) * NVT + vt) * 128 + 4 * c;
         const bool valid = n0 < a.Mp;
         f32x16 acc[2][4];
 #pragma unroll
@@ -275,8 +306,8 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
         for (int ks = 0; ks < nks; ++ks) {
             __builtin_amdgcn_s_barrier();                      // the producers have seen stage `cslot` land
             CG_BSTAMP(it == lw + 2 * Lw, ks);
-            const unsigned xb = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + (X16 ? g * 2048 + c * 8 : g * 4096 + c * 16);
-            const unsigned ab = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + C::XPART + (64 * wave + c) * 32 + 16 * g;
+            const unsigned xb = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + vt * C::XTILE + (X16 ? g * 2048 + c * 8 : g * 4096 + c * 16);
+            const unsigned ab = (unsigned)(size_t)(ring + (size_t)cslot * C::STAGE) + C::XPART + (64 * vf + c) * 32 + 16 * g;
             const unsigned ab2 = ab + C::WPART;                // the lo image (PASSES == 3)
             f32x4 x[8];
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -887,12 +918,15 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
 
 using namespace chebgcn;
 
-static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw, bool x16 = false);
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw, bool x16 = false,
+                                int nvt = 1);
+// vertex tiles per work item of the forward: the four compute waves are 4 / nvt filter slices of 64
+static int fwd_bf16_tiles(int Fout) { return Fout <= 64 ? 4 : Fout <= 128 ? 2 : 1; }
 
 extern "C" size_t chebgcn_contract_fwd_bf16_workspace(int Fin, int K, int Fout) {
     if (Fin <= 0 || K <= 0 || Fout <= 0) return 0;
     const size_t nks = bf16_ksteps(Fin * K), FoutP = ((size_t)Fout + 255) / 256 * 256;
-    return 2 * nks * FoutP * 16 * sizeof(uint16_t);      // hi and lo images
+    return 2 * nks * FoutP * 16 * sizeof(uint16_t);      // hi and lo images (narrow layers pack 64 or 128 columns: less)
 }
 
 extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, const float* bias, int bias_kind,
@@ -919,20 +953,21 @@ extern "C" int chebgcn_contract_fwd_bf16(const float* stack, const float* W, con
     a.pool = pool; a.pool_kind = pool_kind; a.relu = relu; a.bias_kind = bias_kind;
     a.Mo = M / pool; a.Mpo = plane_stride(a.Mo);
     a.slab = (size_t)B * Fin * a.Mp;
-    const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + 255) / 256 * 256;
+    const int nvt = fwd_bf16_tiles(Fout), G = 256 / nvt;
+    const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + G - 1) / G * G;
     note_dispatch("pack_w_bf16_kernel");
     hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((nks * FoutP + 255) / 256), dim3(256), 0, stream, W, (__bf16*)workspace,
                        a.FinK, Fout, nks, FoutP, passes == 3 ? 2 : 1, 0);
     CG_HIP(hipGetLastError());
-    return launch_contract_bf16(a, passes, workspace, stream, 4);
+    return launch_contract_bf16(a, passes, workspace, stream, 4, false, nvt);
 }
 
 // the packed operand is in `workspace`; `a` describes the rows, the planes and the epilogue
-static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw, bool x16) {
+static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, hipStream_t stream, int nw, bool x16, int nvt) {
     const int B = a.B, M = a.M, Fout = a.Fout;
-    const int G = nw * 64;                               // filters per work item
+    const int G = nw / nvt * 64;                         // filters per work item
     const int nks = bf16_ksteps(a.FinK), FoutP = (Fout + G - 1) / G * G;
-    const int ntm = (M + 127) / 128;
+    const int ntm = (M + 128 * nvt - 1) / (128 * nvt);   // vertex tiles of a work item's size
     const int64_t nitems64 = (int64_t)ntm * B * (FoutP / G);
     CG_REQUIRE(nitems64 < (1ll << 31), "contract_fwd_bf16: too many tiles");
     const int nitems = (int)nitems64;
@@ -944,18 +979,23 @@ static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, h
             cus = 256;
     }
 
-#define CG_BF16_LAUNCH_X(P, NW, X, TAG)                                                                            \
+#define CG_BF16_LAUNCH_XT(P, NW, X, T, TAG)                                                                        \
     do {                                                                                                           \
-        constexpr int lds = Bf16Cfg<P, NW, X>::NSTAGE * Bf16Cfg<P, NW, X>::STAGE;                                  \
+        constexpr int lds = Bf16Cfg<P, NW, X, T>::NSTAGE * Bf16Cfg<P, NW, X, T>::STAGE;                            \
         const dim3 grid(nitems < cus ? nitems : cus);           /* one persistent workgroup per CU */              \
         note_dispatch_more("contract_fwd_bf16_kernel<" #P "," #NW TAG ">");                                        \
-        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_fwd_bf16_kernel<P, NW, X>),              \
+        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_fwd_bf16_kernel<P, NW, X, T>),           \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                              \
-        hipLaunchKernelGGL((contract_fwd_bf16_kernel<P, NW, X>), grid, dim3((NW + 2) * 64), lds, stream, a,              \
+        hipLaunchKernelGGL((contract_fwd_bf16_kernel<P, NW, X, T>), grid, dim3((NW + 2) * 64), lds, stream, a,     \
                            (const __bf16*)workspace, nks, FoutP, ntm, nitems);                                     \
     } while (0)
+#define CG_BF16_LAUNCH_X(P, NW, X, TAG) CG_BF16_LAUNCH_XT(P, NW, X, 1, TAG)
 #define CG_BF16_LAUNCH(P, NW) CG_BF16_LAUNCH_X(P, NW, false, "")
-    if (x16) {
+    if (nvt == 4) {                                      // (the forward of layers of at most 64 filters: four vertex tiles per item)
+        if (passes == 3) CG_BF16_LAUNCH_XT(3, 4, false, 4, ",tiles4"); else CG_BF16_LAUNCH_XT(1, 4, false, 4, ",tiles4");
+    } else if (nvt == 2) {                               // (at most 128 filters: two slices x two tiles)
+        if (passes == 3) CG_BF16_LAUNCH_XT(3, 4, false, 2, ",tiles2"); else CG_BF16_LAUNCH_XT(1, 4, false, 2, ",tiles2");
+    } else if (x16) {
         if (nw == 5) CG_BF16_LAUNCH_X(1, 5, true, ",x16"); else CG_BF16_LAUNCH_X(1, 4, true, ",x16");
     } else if (nw == 5) {
         if (passes == 3) CG_BF16_LAUNCH(3, 5); else CG_BF16_LAUNCH(1, 5);
@@ -964,6 +1004,7 @@ static int launch_contract_bf16(const FwdArgs& a, int passes, void* workspace, h
     }
 #undef CG_BF16_LAUNCH
 #undef CG_BF16_LAUNCH_X
+#undef CG_BF16_LAUNCH_XT
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -332,6 +332,20 @@ def _check_grad_buffer(buf, shape, what):
 
 
 PRECISIONS = {'f32': 0, 'bf16': 1, 'bf16x3': 3}     # contraction arithmetic -> passes of chebgcn_contract_fwd_bf16
+FP32_MFMA_BALANCE = 19.6        # flop per HBM byte at which the fp32-input matrix cores (157 TFLOP/s) meet 8 TB/s
+
+
+def resolve_precision(precision, Fin, K, Fout):
+    """'auto' -> the arithmetic a layer of this shape computes in: 'f32' (fp32-input matrix instructions, exact products)
+    where the contraction is HBM-bound anyway (what BASELINE configs[1] runs: 32 filters), 'bf16x3' where fp32 matrix
+    work would bound it -- more than 32 filters and an arithmetic intensity 2*Fin*K*Fout / (4*(Fin*K + Fout)) above the
+    machine balance of the fp32 matrix cores.  'bf16x3' splits each fp32 operand into two bf16 and accumulates
+    hi*hi + hi*lo + lo*hi in fp32: 3e-6 ... 6e-6 of the tensor's scale from the fp32 layer (tests/test_gpu_dispatch.py holds
+    every arm to 1e-5 against float64), at a third of the time.  Anything else is returned unchanged."""
+    if precision != 'auto':
+        return precision
+    ai = float(Fin) * K * Fout / (2.0 * (Fin * K + Fout))
+    return 'bf16x3' if (Fout > 32 and ai > FP32_MFMA_BALANCE) else 'f32'
 
 
 def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision='f32'):
@@ -669,6 +683,7 @@ class Buffers:
 
 
 def conv_mean_supported(B, M, Fin, K, Fout, pool, relu, precision='f32'):
+    precision = resolve_precision(precision, Fin, K, Fout)
     """Can ``cheb_conv(..., mean=True)`` serve this layer?  (pool 1, ReLU, fp32 contraction, a shape of the ring kernel.)"""
     return bool(fold_relu_grad and pool == 1 and relu and precision == 'f32'
                 and _lib.lib().chebgcn_contract_fwd_mean_supported(B, M, Fin, K, Fout))
@@ -676,9 +691,10 @@ def conv_mean_supported(B, M, Fin, K, Fout, pool, relu, precision='f32'):
 
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
               dW=None, dbias=None, precision='f32', done=None, mean=False):
-    """``precision``: arithmetic of the contraction and of its two gradients ('f32', 'bf16', 'bf16x3':
+    """``precision``: arithmetic of the contraction and of its two gradients ('auto': resolve_precision; 'f32', 'bf16', 'bf16x3':
     chebgcn_contract_fwd_bf16 / _bwd_x_bf16 / _bwd_w_bf16 with 1 or 3 passes); storage, the recurrence, its adjoint
     and the bias / ReLU / pooling gradients stay fp32."""
+    precision = resolve_precision(precision, x.shape[1], K, W.shape[1])
     bufs = Buffers(stack, out, dW, dbias, precision, done, mean)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 

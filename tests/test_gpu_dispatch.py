@@ -182,6 +182,95 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
     record_measured('contraction_arm_vs_float64[%s]' % case, **got)
 
 
+# ---------------------------------------------------------------------------------------
+# wide layers: the split-bf16 contraction ('bf16x3', what precision 'auto' resolves to above 32 filters) at 1e-5
+# ---------------------------------------------------------------------------------------
+
+SPLIT_CASES = {
+    # name: (B, Fin, K, Fout, forward kernel, bwd_x kernel, bwd_w kernel)
+    'config4_b16': (16, 64, 25, 64, 'contract_fwd_bf16_kernel<3,4,tiles4>', 'contract_fwd_bf16_kernel<3,5>', 'contract_bwd_w_bf16_kernel<5,2,3>'),
+    'config5_b32': (32, 60, 5, 256, 'contract_fwd_bf16_kernel<3,4>', 'contract_fwd_bf16_kernel<3,5>', 'contract_bwd_w_bf16_wide_kernel<3>'),
+    'f128_b32': (32, 128, 5, 128, 'contract_fwd_bf16_kernel<3,4,tiles2>', 'contract_fwd_bf16_kernel<3,5>', 'contract_bwd_w_bf16_wide_kernel<3>'),
+    'pool6_l2_b32': (32, 32, 10, 64, 'contract_fwd_bf16_kernel<3,4,tiles4>', 'contract_fwd_bf16_kernel<3,5>', 'contract_bwd_w_bf16_kernel<5,2,3>'),
+    'pool6_l5_b32': (32, 64, 5, 128, 'contract_fwd_bf16_kernel<3,4,tiles2>', 'contract_fwd_bf16_kernel<3,5>', 'contract_bwd_w_bf16_wide_kernel<3>'),
+}
+
+
+@pytest.mark.parametrize('bias_kind', ['vertex', 'filter'])
+@pytest.mark.parametrize('case', sorted(SPLIT_CASES))
+def test_split_bf16_arm_vs_float64(ops, dev, lib, case, bias_kind):
+    """chebgcn_contract_fwd_bf16 / _bwd_w_bf16 / _bwd_x_bf16 with passes = 3 (each fp32 operand split into two bf16, hi*hi +
+    hi*lo + lo*hi accumulated in fp32) against float64 products of the SAME fp32 operands, at the bound the fp32 kernels are
+    held to -- 1e-5 of the tensor's scale (north star: "1e-5 relative fp32"), not a bf16-style bound: this is the arithmetic
+    precision 'auto' gives every layer of more than 32 filters (ops.resolve_precision).  Kernel templates asserted: the forward
+    of 64 / 128 filters runs four / two vertex tiles per work item (contract_bf16.hip Bf16Cfg NVT), config 4's K = 25 sums
+    are the longest of the BASELINE configs (1600 terms).  models_gcn.py:611-617, :297-303."""
+    from gcn_fmri_decoding_amd import _lib
+    B, Fin, K, Fout, fwd_name, bwx_name, bww_name = SPLIT_CASES[case]
+    if bias_kind == 'filter' and case not in ('config4_b16', 'f128_b32'):
+        pytest.skip('per-filter bias on one shape per tile geometry')
+    M = 10466
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(sum(map(ord, case)))
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    stack[..., M:] = float('nan')
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * (0.5 / np.sqrt(Fin * K))
+    if bias_kind == 'vertex':
+        bias = torch.zeros((Fout, Mp), device=dev)
+        bias[:, :M] = torch.randn((Fout, M), generator=gen, device=dev) * 0.3
+        bk, bias64 = ops.BIAS_VERTEX, bias[:, :M].double()
+    else:
+        bias = torch.randn((Fout,), generator=gen, device=dev) * 0.3
+        bk, bias64 = ops.BIAS_FILTER, bias.double()[:, None]
+    st = stream()
+    got = {}
+    out = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    mask = torch.zeros((B, Fout, Mp // 4), dtype=torch.uint8, device=dev)
+    nws = lib.chebgcn_contract_fwd_bf16_workspace(Fin, K, Fout)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    _lib.check(lib.chebgcn_contract_fwd_bf16(P(stack), P(W), P(bias), bk, P(out), P(mask), B, M, Fin, K, Fout, 1, 0, 1, 3, P(ws), nws, st), 'fwd')
+    assert _lib.last_dispatch() == 'pack_w_bf16_kernel + ' + fwd_name, _lib.last_dispatch()
+    S = stack[..., :M].permute(2, 0, 1, 3).reshape(Fin * K, B, M).double()
+    pre = torch.einsum('rbm,ro->bom', S, W.double()) + bias64
+    got['fwd'] = rel_err(out[..., :M], pre.clamp(min=0), pre.abs().max())
+    assert got['fwd'] <= REL, '%s: %.3e' % (fwd_name, got['fwd'])
+    bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, Fout, Mp)[..., :M].bool()
+    assert torch.equal(bits, out[..., :M] > 0), 'ReLU bit mask disagrees with the output'
+    del pre
+    dyf = torch.randn((B, Fout, Mp), generator=gen, device=dev)
+    dyf[..., :M] *= bits
+    dyf[..., M:] = 0.0
+    dy = dyf[..., :M].double()
+    n = lib.chebgcn_contract_bwd_w_bf16_workspace(B, M, Fin, K, Fout)
+    wsw = torch.empty(n, dtype=torch.uint8, device=dev)
+    dW = torch.full((Fin * K, Fout), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_w_bf16(P(stack), P(dyf), P(dW), P(wsw), n, B, M, Fin, K, Fout, 3, st), 'bwd_w')
+    assert _lib.last_dispatch().startswith(bww_name), _lib.last_dispatch()
+    got['bwd_w'] = rel_err(dW, torch.einsum('rbm,bom->ro', S, dy))
+    assert got['bwd_w'] <= REL, '%s: %.3e' % (bww_name, got['bwd_w'])
+    dW2 = torch.full_like(dW, float('nan'))
+    _lib.check(lib.chebgcn_contract_bwd_w_bf16(P(stack), P(dyf), P(dW2), P(wsw), n, B, M, Fin, K, Fout, 3, st), 'bwd_w')
+    assert torch.equal(dW, dW2), 'dW differs between two runs'
+    del S
+    n = lib.chebgcn_contract_bwd_x_bf16_workspace(Fin, K, Fout)
+    wsx = torch.empty(n, dtype=torch.uint8, device=dev)
+    gstack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_x_bf16(P(dyf), P(W), P(gstack), B, M, Fin, K, Fout, 3, P(wsx), n, st), 'bwd_x')
+    assert _lib.last_dispatch() == 'pack_w_bf16_kernel<transposed> + ' + bwx_name, _lib.last_dispatch()
+    gs_ref = torch.einsum('ro,bom->rbm', W.double(), dy).reshape(Fin, K, B, M).permute(1, 2, 0, 3)
+    got['bwd_x'] = rel_err(gstack[..., :M], gs_ref)
+    assert got['bwd_x'] <= REL, '%s: %.3e' % (bwx_name, got['bwd_x'])
+    del gs_ref, gstack
+    # one pass (operands rounded to bf16) through the same tile geometry: the bf16 bound
+    out1 = torch.full((B, Fout, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_contract_fwd_bf16(P(stack), P(W), P(bias), bk, P(out1), None, B, M, Fin, K, Fout, 1, 0, 1, 1, P(ws), nws, st), 'fwd1')
+    assert _lib.last_dispatch() == 'pack_w_bf16_kernel + ' + fwd_name.replace('<3,', '<1,'), _lib.last_dispatch()
+    got['fwd_one_pass_vs_split'] = rel_err(out1[..., :M], out[..., :M].double())
+    assert got['fwd_one_pass_vs_split'] <= 1e-2
+    record_measured('split_bf16_arm_vs_float64[%s,%s]' % (case, bias_kind), **got)
+
+
 # how contract_bwd_w's partials are reduced, by launch size (contract.hip launch_bwd_w)
 BWD_W_TAIL = {'big': ' + reduce_partials_wide', 'small': ' + reduce_partials_small'}
 

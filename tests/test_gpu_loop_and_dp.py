@@ -218,13 +218,21 @@ def _run_ranks(world, fixture, tmp_path, tag, extra_env=None):
     script = tmp_path / 'dp_worker.py'
     script.write_text(_WORKER)
     out = str(tmp_path / (tag + '_%d.npz'))
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   CHEBGCN_ROOT=ROOT, CHEBGCN_OUT=out, CHEBGCN_FIXTURE=fixture, HSA_ENABLE_IPC_MODE_LEGACY='0',
-                   **(extra_env or {}))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for attempt in (0, 1):
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port + attempt),
+                       CHEBGCN_ROOT=ROOT, CHEBGCN_OUT=out, CHEBGCN_FIXTURE=fixture, HSA_ENABLE_IPC_MODE_LEGACY='0',
+                       **(extra_env or {}))
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        # a rank KILLED BY A SIGNAL (seen once in round 5: SIGABRT out of a RCCL helper thread of a world-of-one process group,
+        # the same test green on the next box) is started again once, and the log of the first attempt is printed; a rank
+        # that FAILS (non-zero exit: an assertion, a Python error, a wrong result) is never retried
+        if attempt == 0 and any(p.returncode < 0 for p in procs) and all(p.returncode <= 0 for p in procs):
+            print('rank killed by a signal, starting the ranks again once:\n' + '\n'.join(l[-1500:] for l in logs))
+            continue
+        break
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
     return [np.load(out % r) for r in range(world)]
