@@ -153,13 +153,14 @@ def kernel_leg(lib_graph, B, Fin, K, launches, what):
     return out
 
 
-def config5_leg(lib_graph, B, Fin, K, Fout, steps):
-    """BASELINE configs[4]: one wide layer (block_dura = Fin = 60 -> Fout = 256, K = 5, per-vertex
-    bias + ReLU) trained forward + backward -- recurrence, contraction, bias/ReLU gradient,
-    contraction gradients (dW, d stack), adjoint recurrence -- with the contraction and its two
-    gradients in fp32 MFMA, bf16 and split-bf16 (``ops.cheb_conv(precision=...)``).  Reports the
-    layer step time, the per-kernel HIP-event times and the fp32 parity of the mixed-precision results
-    (max error relative to max|fp32 result| of y, dx and dW on the same layer without the ReLU)."""
+def layer_leg(lib_graph, B, Fin, K, Fout, steps, what, precisions=('f32', 'bf16', 'bf16x3')):
+    """One wide layer (per-vertex bias + ReLU) trained forward + backward -- recurrence, contraction, bias/ReLU
+    gradient, contraction gradients (dW, d stack), adjoint recurrence -- with the contraction and its two
+    gradients in fp32 MFMA, bf16 and split-bf16 (``ops.cheb_conv(precision=...)``): BASELINE configs[4]
+    (block_dura = Fin = 60 -> Fout = 256, K = 5) and configs[3] (K = 25, 64 -> 64).  Reports the layer step
+    time, the per-kernel HIP-event times and the fp32 parity of the mixed-precision results (max error relative
+    to max|fp32 result| of y, dx and dW on the same layer without the ReLU); ``default_precision`` = what
+    precision 'auto' (cgcnn's default) resolves to for this shape."""
     import torch
     from gcn_fmri_decoding_amd import ops
     g = lib_graph
@@ -172,11 +173,11 @@ def config5_leg(lib_graph, B, Fin, K, Fout, steps):
     bias = (torch.randn((Fout, g.Mp), generator=gen, device=dev) * 0.1).requires_grad_(True)
     gout = torch.randn((B, Fout, g.Mp), generator=gen, device=dev)
     gout[:, :, g.M:] = 0
-    out = {'shape': {'B': B, 'Fin': Fin, 'K': K, 'Fout': Fout, 'M': g.M}, 'steps': steps,
-           'what': 'BASELINE configs[4]: single wide layer forward + backward, HIP kernels only (no head, no optimizer)',
+    out = {'shape': {'B': B, 'Fin': Fin, 'K': K, 'Fout': Fout, 'M': g.M}, 'steps': steps, 'what': what,
+           'default_precision': ops.resolve_precision('auto', Fin, K, Fout),
            'timing': 'wall clock over the steps between synchronisations; per-kernel HIP events on a separate instrumented pass'}
     ref = None
-    for precision in ('f32', 'bf16', 'bf16x3'):
+    for precision in precisions:
         def layer_step():
             xs = x.detach().requires_grad_(True)
             W.grad = bias.grad = None
@@ -624,8 +625,12 @@ def main():
             g0 = net.graphs[0]
             line['northstar'] = kernel_leg(g0, 256, 32, 5, 100, 'north-star shape of BASELINE.json: K=5 recurrence, Fin=32, batch 256, '
                                                                 'M=10466; target frac >= 0.40')
-            line['config4'] = kernel_leg(g0, 64, 64, 25, 30, 'BASELINE configs[3]: K=25, Fin=Fout=64, batch 64 (SpMM-bound regime)')
-            line['config5'] = config5_leg(g0, 64, 60, 5, 256, 10)
+            line['config4'] = kernel_leg(g0, 64, 64, 25, 30, 'BASELINE configs[3]: K=25, Fin=Fout=64, batch 64 -- these entries time the two '
+                                                             'recurrence launches alone; the whole layer is in "layer"')
+            line['config4']['layer'] = layer_leg(g0, 64, 64, 25, 64, 5, 'BASELINE configs[3]: the whole K=25, 64 -> 64 layer forward + backward, '
+                                                 'HIP kernels only (no head, no optimizer)', ('f32', 'bf16x3'))
+            line['config5'] = layer_leg(g0, 64, 60, 5, 256, 10, 'BASELINE configs[4]: single wide layer forward + backward, HIP kernels only '
+                                        '(no head, no optimizer)')
             line['dp_overhead'] = dp_overhead_leg(net, step, nxt, DP_STEPS, 1e3 * dt / args.steps, dev)
             del net, data
             torch.cuda.empty_cache()

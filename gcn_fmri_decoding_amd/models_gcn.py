@@ -841,10 +841,13 @@ class cgcnn(base_model):
         self.regularization, self.dropout = regularization, dropout
         self.batch_size, self.eval_frequency = batch_size, eval_frequency
         self.dir_name = dir_name
-        # arithmetic of the contraction AND of its two gradients (ops.ChebConv): 'f32' (exact, default), 'bf16' or
-        # 'bf16x3' (bf16 matrix cores for wide layers); not a reference keyword -- set it on the instance.  It is
-        # part of the checkpoint's architecture record: a model rebuilt from a checkpoint computes as it was trained
-        self.contraction = 'f32'
+        # arithmetic of the contraction AND of its two gradients (ops.ChebConv), not a reference keyword -- set it on the
+        # instance: 'auto' (default; per layer, ops.resolve_precision: fp32 matrix instructions up to 32 filters -- every
+        # layer of BASELINE configs[1] and of the reference's training.py -- and split bf16, 'bf16x3', for wider layers,
+        # where fp32 matrix work would bound the layer; 3e-6 ... 6e-6 of the fp32 result, inside the 1e-5 the north star
+        # asks), 'f32' (exact products everywhere), 'bf16', 'bf16x3'.  It is part of the checkpoint's architecture record:
+        # a model rebuilt from a checkpoint computes as it was trained
+        self.contraction = os.environ.get('CHEBGCN_CONTRACTION', 'auto')
         # last conv layer + tf.reduce_mean(x, -1) (:673) in one kernel where the shape allows (ops.conv_mean_supported);
         # False keeps the two separate (same values up to the order of the sum over the filters)
         self.fuse_feature_mean = os.environ.get('CHEBGCN_FUSE_MEAN', '1') != '0'

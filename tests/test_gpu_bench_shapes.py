@@ -296,8 +296,14 @@ def test_config2_network_b2_vs_oracle(ops, dev, bench_graph):
 # the pooling ChebNet of the legacy monolith at full size
 # ---------------------------------------------------------------------------------------
 
-def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
-    """HCP_task_fmri_gcn_test8.py:1633-1636, 2071: six coarsening levels of the N = 10000 graph
+@pytest.mark.parametrize('contraction', ['f32', 'auto'])
+def test_pooling_chebnet_full_size_vs_oracle(ops, dev, contraction):
+    """``contraction``: 'f32' = exact products in every layer; 'auto' (cgcnn's default) = split bf16 in the layers of 64 and
+    128 filters (ops.resolve_precision): each contraction is within 1e-5 of float64 (test_split_bf16_arm_vs_float64), the
+    logits of the six-layer network within 2e-5; gradients that pass through max-pooling picks and ReLU decisions which flip on
+    a 5e-6 difference are held to a quantile bound, the measured values are recorded.
+
+    HCP_task_fmri_gcn_test8.py:1633-1636, 2071: six coarsening levels of the N = 10000 graph
     (M = 12672 / 6336 / ... / 198), p = [1,4,1,4,1,4], K = [20,10,10,10,5,5], F = [32,32,64,64,128,128],
     b2relu, block_dura 15, batch 2: logits, loss and the gradients of one training step against
     the oracle (layers at M = 12672, 3168 and 792 vertices with Fout up to 128 and max pooling 4)."""
@@ -309,6 +315,9 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
     reg = 5e-4
     net = models_gcn.cgcnn({'device': dev}, Ls, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1',
                            initial='he', channel=channel, regularization=reg, dropout=1, batch_size=B, verbose=False)
+    net.contraction = contraction
+    assert [ops.resolve_precision(contraction, fi, k, fo) for fi, k, fo in zip([channel] + F[:-1], K, F)] == (
+        ['f32'] * 6 if contraction == 'f32' else ['f32', 'f32', 'bf16x3', 'bf16x3', 'bf16x3', 'bf16x3'])
     assert [g.M for g in net.graphs] == [12672, 12672, 3168, 3168, 792, 792]
     onet = R.Net(Ls, F, K, p, Mfc, channel=channel, brelu='b2relu', regularization=reg)
     rs = np.random.RandomState(5)
@@ -331,10 +340,23 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev):
     grads = onet.backward(params, cache, dlogits)
     _, loss_avg = net.train_step(xs, torch.as_tensor(labels).to(dev))
     assert abs(float(loss_avg) - loss) <= GREL * abs(loss)
+    from conftest import record_measured
+    measured = {}
     for k in params:
-        gk = net.gradient(k)
+        gk = net.gradient(k).cpu().numpy().astype(np.float64)
         ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
-        close(gk.cpu().numpy(), ref, rel=5e-5, what='grad ' + k)
+        d = np.abs(gk - ref) / max(np.abs(ref).max(), 1e-30)
+        measured[k] = [float(np.quantile(d, 0.99)), float(d.max())]
+    record_measured('pooling_chebnet_full_size[%s]' % contraction, **measured)
+    for k, (q99, worst) in measured.items():
+        if contraction == 'f32':
+            assert worst <= 5e-5, 'grad %s: rel err %.3e' % (k, worst)
+        else:
+            # Measured (profiles/r05_parity_measured.jsonl): conv1/weights 7e-4 at the 99 % quantile, 1.2e-3 max, against 3.5e-6
+            # with exact products.  The four split-bf16 layers are each 4e-6 ... 6e-6 from fp32; what the deep gradients show is
+            # that difference carried back through six layers, max-pooling picks and ReLU decisions (two windows only: one
+            # flipped pick moves a whole gradient element to another vertex).  cgcnn.contraction = 'f32' is the exact path
+            assert q99 <= 2e-3 and worst <= 1e-2, 'grad %s: 99 %% quantile %.3e, max %.3e' % (k, q99, worst)
 
 
 # ---------------------------------------------------------------------------------------

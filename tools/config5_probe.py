@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""BASELINE configs[4] (one wide layer, forward + backward in fp32 / bf16 / split bf16) alone: bench.config5_leg without the
-rest of bench.py.  CHEBGCN_LIB selects a library variant (tools/bbuild.sh)."""
+"""BASELINE configs[4] / configs[3] (one wide layer, forward + backward in fp32 / bf16 / split bf16) alone: bench.layer_leg
+without the rest of bench.py.  CHEBGCN_LIB selects a library variant (tools/bbuild.sh).  SHAPE="Fin K Fout" (default 60 5 256)."""
 import json
 import os
 import sys
@@ -17,7 +17,9 @@ def main():
     Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
     L = Ls[0]
     g = ops.Graph(graph.permute(L, graph.length_order(L)), dev)
-    out = bench.config5_leg(g, 64, 60, 5, 256, int(os.environ.get('STEPS', 10)))
+    Fin, K, Fout = (int(v) for v in os.environ.get('SHAPE', '60 5 256').split())
+    out = bench.layer_leg(g, 64, Fin, K, Fout, int(os.environ.get('STEPS', 10)), 'one wide layer, forward + backward')
+    print('Fin = %d, K = %d, Fout = %d; precision auto -> %s' % (Fin, K, Fout, out['default_precision']))
     for p in ('f32', 'bf16', 'bf16x3'):
         leg = out[p]
         print('%-7s %.3f ms/step  %s' % (p, leg['ms_per_step'], json.dumps(leg.get('rel_err_vs_f32'))))
