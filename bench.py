@@ -266,6 +266,67 @@ def refshape_leg(dev, n_nodes, steps, warmup, batch=128, korder=10, block_dura=1
     return out
 
 
+def pool6_leg(dev, steps, warmup, batch=64, block_dura=15, instrumented=5):
+    """the pooling ChebNet of the legacy monolith (HCP_task_fmri_gcn_test8.py:1632-1635) at full size -- the
+    N = 10000 graph coarsened six times (M = 12672 / 3168 / 792 at the conv layers), F = [32, 32, 64, 64, 128, 128],
+    p = [1, 4, 1, 4, 1, 4], K = [20, 10, 10, 10, 5, 5], per-vertex biases, max pooling, FC 512-256-22 -- as a training
+    step (fwd + loss + bwd + Adam, batch gathered and permuted on device): windows/s, the per-kernel table of a separate
+    instrumented pass with the kernel template each entry dispatched, and the step's algorithmic bytes against 8 TB/s.
+    Vertices stay in the coarsening's tree order (pooling is a max over adjacent vertices there)."""
+    import torch
+    from gcn_fmri_decoding_amd import _lib, models_gcn, ops
+    Ls, perm = load_graph(10000, 6, 0, 1, None)
+    F, K, p, Mfc = [32, 32, 64, 64, 128, 128], [20, 10, 10, 10, 5, 5], [1, 4, 1, 4, 1, 4], [512, 256, 22]
+    torch.manual_seed(0)
+    net = models_gcn.cgcnn({'device': dev}, Ls, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he',
+                           channel=block_dura, regularization=5e-4, dropout=0.5, batch_size=batch, learning_rate=0.001,
+                           decay_rate=0.9, momentum=0.9, verbose=False)
+    out = {'shape': {'N': 10000, 'M': [int(g.M) for g in net.graphs], 'F': F, 'K': K, 'p': p, 'fc': Mfc, 'batch': batch,
+                     'block_dura': block_dura}, 'steps': steps, 'warmup': warmup,
+           'precision': [ops.resolve_precision(net.contraction, fi, k, fo) for fi, k, fo in zip([block_dura] + F[:-1], K, F)],
+           'what': 'SURVEY 8(f)4: the monolith\'s pooling ChebNet at full size, full training step, inputs resident in HBM'}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    S = 2 * batch
+    data = torch.randn((S, 10000, block_dura), generator=gen, device=dev)
+    labels = torch.randint(0, 21, (S,), generator=gen, device=dev)
+    order = torch.stack([torch.randperm(S, generator=gen, device=dev)[:batch].to(torch.int32)
+                         for _ in range(steps + warmup + instrumented)])
+    perm_dev = net.compose_perm(perm)
+
+    def step(i):
+        idx = order[i]
+        x = net.as_internal(ops.perm_data(data, perm_dev, idx))
+        return net.train_step(x, labels[idx.long()])
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        _, loss = step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out.update({'ms_per_step': 1e3 * dt, 'windows_per_s': batch / dt, 'final_loss': float(loss)})
+    if instrumented:
+        overlap, ops.overlap_bwd_w = ops.overlap_bwd_w, False
+        ops.timers = ops.KernelTimers(by_dispatch=True)
+        for i in range(warmup + steps, warmup + steps + instrumented):
+            step(i)
+        kern = ops.timers.summary()
+        ops.timers = None
+        ops.overlap_bwd_w = overlap
+        out['kernels'] = {k: {'ms_per_step': v['total_ms'] / instrumented, 'launches_per_step': v['launches'] / instrumented,
+                              'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
+                              'frac_hbm': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'TFLOPs': v['flops'] / (v['total_ms'] * 1e-3) / 1e12} for k, v in kern.items()}
+        step_bytes = sum(v['bytes'] for v in kern.values()) / instrumented
+        out['step_roofline'] = {'algorithmic_bytes_per_step': step_bytes, 'frac': step_bytes / dt / 1e9 / HBM_PEAK_GBS}
+        out['kernel_ms_sum'] = sum(v['total_ms'] for v in kern.values()) / instrumented
+    del net, data
+    torch.cuda.empty_cache()
+    return out
+
+
 DP_STEPS = 40
 
 
@@ -635,6 +696,7 @@ def main():
             del net, data
             torch.cuda.empty_cache()
             line['refshape'] = {'n360': refshape_leg(dev, 360, 100, 10), 'n1000': refshape_leg(dev, 1000, 100, 10)}
+            line['pool6'] = pool6_leg(dev, 10, 3)
             from gcn_fmri_decoding_amd import graph as G
             line['fit'] = {'configs1': fit_leg(dev, Ls[0], cfg, args.batch, 8 * args.batch, 2 * args.batch, 25,
                                                'BASELINE configs[1] (M = %d, batch %d)' % (Ls[0].shape[0], args.batch)),

@@ -35,8 +35,11 @@ class KernelTimers:
     roofline line).  Events are recorded on the stream the kernel is launched on; nothing
     is synchronised until ``summary()``.  Disabled (``timers is None``) by default."""
 
-    def __init__(self, every=1):
+    def __init__(self, every=1, by_dispatch=False):
         self.records = {}           # name -> list of (start, end, algorithmic bytes, flops)
+        # by_dispatch: one entry per (op, kernel template chebgcn_last_dispatch() reported) instead of one per op -- a
+        # network whose layers differ in size runs the same op on different kernels
+        self.by_dispatch = bool(by_dispatch)
         # An event pair per launch costs ~5 % of a training step (the markers keep consecutive
         # kernels from overlapping): with ``every = n`` only every n-th step is instrumented.
         # The caller announces steps with ``next_step()``.
@@ -58,6 +61,8 @@ class KernelTimers:
         start.record()
         rc = fn()
         end.record()
+        if self.by_dispatch:
+            name = '%s | %s' % (name, _lib.last_dispatch())
         self.records.setdefault(name, []).append((start, end, nbytes, flops))
         return rc
 
