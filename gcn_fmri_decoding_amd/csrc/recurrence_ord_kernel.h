@@ -45,6 +45,12 @@ extern int g_stagger;
 #define CG_ORD_WG2 1         // cap the registers of the smallest shape so that two workgroups share a CU (adjoint: 20 spilled registers,
                              // 0.202 -> 0.186 ms at N = 2600 and 0.229 -> 0.218 ms at N = 3800, batch 256; forward fits anyway)
 #endif
+#ifndef CG_ORD_RING4
+#define CG_ORD_RING4 2       // operator ring depth (slices ahead) of the four-plane shapes: what the registers allow
+#endif
+#ifndef CG_ORD_RING2
+#define CG_ORD_RING2 2       // ... of the two-plane shapes
+#endif
 #ifndef CG_ORD_PRIO
 #define CG_ORD_PRIO 1
 #endif
@@ -329,9 +335,10 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
             // Operator records of slice j (group j*NW + wave) sit at compile-time offsets behind one per-wave base; they
             // travel through a ring two slices deep: values of quads 0 / 1, the record of entries 8..11, the eight ids of
             // quads 0 and 1.  The two optional requests are skipped by scalar-only tests (j is a constant, nA / nB SGPRs).
-            float4 uq[3][2];
-            float2 ub[2];
-            uint4 uo[2];
+            constexpr int RD = PL == 4 ? CG_ORD_RING4 : CG_ORD_RING2;      // slices of operator records in flight per wave
+            float4 uq[3][RD];
+            float2 ub[RD];
+            uint4 uo[RD];
             const unsigned vsoff = (unsigned)wave * 4096u, isoff = (unsigned)wave * 1024u;
             auto urequest = [&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
@@ -340,16 +347,16 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
                 const f32x4 a = __builtin_amdgcn_raw_buffer_load_b128(uval_rsrc, lane * 16, vs + vo, 0);
                 const f32x4 b = __builtin_amdgcn_raw_buffer_load_b128(uval_rsrc, lane * 16, vs + (vo + 1024u), 0);
                 const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(uids_rsrc, lane * 16, is + io, 0);
-                uq[0][j & 1] = make_float4(a.x, a.y, a.z, a.w);
-                uq[1][j & 1] = make_float4(b.x, b.y, b.z, b.w);
-                uo[j & 1] = make_uint4(c.x, c.y, c.z, c.w);
+                uq[0][j % RD] = make_float4(a.x, a.y, a.z, a.w);
+                uq[1][j % RD] = make_float4(b.x, b.y, b.z, b.w);
+                uo[j % RD] = make_uint4(c.x, c.y, c.z, c.w);
                 if (j < opaque_s(nA)) {
                     const f32x4 d = __builtin_amdgcn_raw_buffer_load_b128(uval_rsrc, lane * 16, vs + (vo + 2048u), 0);
-                    uq[2][j & 1] = make_float4(d.x, d.y, d.z, d.w);
+                    uq[2][j % RD] = make_float4(d.x, d.y, d.z, d.w);
                 }
                 if (__builtin_expect(j < opaque_s(nB), 0)) {
                     const f32x2 h = __builtin_amdgcn_raw_buffer_load_b64(uval_rsrc, lane * 16, vs + (vo + 3072u), 0);
-                    ub[j & 1] = make_float2(h.x, h.y);
+                    ub[j % RD] = make_float2(h.x, h.y);
                 }
             };
             auto lds_quad = [&](const uint2 c, const float4 v, ent_t& acc) __attribute__((always_inline)) {
@@ -361,7 +368,7 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
                 acc = fma4(v.w, t3, acc);
             };
             urequest(std::integral_constant<int, 0>{});
-            if constexpr (NJ > 1) urequest(std::integral_constant<int, 1>{});
+            static_for<1, (RD < NJ ? RD : NJ)>([&](auto jc) { urequest(jc); });
             // levels without rows: nothing to gather, their pieces go out right away (forward: c(step) x; adjoint: dx)
             static_for<NG, NQ>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
@@ -386,9 +393,9 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
                     else if (pr == 1) __builtin_amdgcn_s_setprio(1);
                     else __builtin_amdgcn_s_setprio(0);
                 }
-                const uint4 o01 = uo[j & 1];
-                const float4 v0 = uq[0][j & 1], v1 = uq[1][j & 1], v2 = uq[2][j & 1];
-                const float2 v3 = ub[j & 1];
+                const uint4 o01 = uo[j % RD];
+                const float4 v0 = uq[0][j % RD], v1 = uq[1][j % RD], v2 = uq[2][j % RD];
+                const float2 v3 = ub[j % RD];
                 ent_t acc = zero4;
                 lds_quad(make_uint2(o01.x, o01.y), v0, acc);
                 lds_quad(make_uint2(o01.z, o01.w), v1, acc);
@@ -409,7 +416,7 @@ cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ ds
                         acc = fma4(w3.y, t3, acc);
                     }
                 }
-                if constexpr (j + 2 < NJ) urequest(std::integral_constant<int, j + 2>{});      // refill the ring slots just consumed
+                if constexpr (j + RD < NJ) urequest(std::integral_constant<int, j + RD>{});    // refill the ring slots just consumed
                 // rows beyond 12 entries (rare; sorted: the first slices of a wave): their further quads from the
                 // variable-stride image
                 if ((opaque_s(j < 32 ? mC : mC_hi) >> (j & 31)) & 1u) {
@@ -546,7 +553,9 @@ int launch_ord_shape(const chebgcn_graph* g, const Ell& ell, const float* src, f
 }  // namespace
 
 // shapes built: four planes, 512 threads, NG = 2..5; two planes, kOrd2NT threads, every NG from the first that does not fit
-// four planes to 20476 active vertices; NQ = NG or NG + 1 each
+// four planes to 20476 active vertices; NQ = NG or NG + 1 each.  (Three planes -- 12-byte entries, up to 13650 active vertices --
+// were built and measured in round 5: ds_read_b96 at a 12-byte stride runs the gather at a quarter of the two-plane rate,
+// 0.10 of the HBM roofline at N = 10242; EXPERIMENTS.md)
 #ifndef CG_ORD2_NT
 #define CG_ORD2_NT 512
 #endif

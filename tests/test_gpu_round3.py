@@ -129,7 +129,7 @@ def test_captured_step_with_dropout_trains(ops, dev):
     assert all(np.isfinite(v) for v in vals) and not torch.equal(before, net._flat)
 
 
-@pytest.mark.parametrize('n_nodes', [360, 1000])
+@pytest.mark.parametrize('n_nodes', [360, 400, 1000])
 def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
     """The network the reference's ``training.py`` actually builds (model.py:271-280, training.py:34,
     configure_fmri.py:28, 41): atlas-sized graph (360 = MMP atlas; 1000), kNN-8, one coarsening level, ChebNet
@@ -207,6 +207,20 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
         # (lr = 2e-3 in the bound: where a ReLU flipped, the two gradients of a bias element can have opposite signs and the
         # first Adam update, -lr * sign(g), differs by two learning rates)
         assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], 0, ill, k, rel=2e-5, lr=2e-3, quantile=0.999)
+    # which kernels a step of this shape runs: up to 384 vertices every conv layer and its input gradient are ONE on-chip
+    # launch each (csrc/fused_small.hip; 12 waves at M = 376, a window split between two workgroups at batch 128)
+    ops.timers = ops.KernelTimers(by_dispatch=True)
+    net.train_step(xs, ld)
+    names = sorted(ops.timers.summary())
+    ops.timers = None
+    if ops.plane_stride(M) <= 384:
+        nw = 12
+        for want in ('fused_layer_fwd | fused_layer_kernel<%d,8,false> + fused_combine_kernel' % nw,
+                     'fused_layer_bwd_x | fused_layer_kernel<%d,8,true>' % nw):
+            assert want in names, (want, names)
+        assert not any(n.startswith('recurrence') for n in names), names
+    else:
+        assert not any('fused_layer' in n for n in names) and any(n.startswith('recurrence_fwd | cheb_onchip_kernel<4,') for n in names), names
     # the same model through the captured graph: two more eager steps, capture, replay -- bit-identical to a twin that
     # runs all of them eagerly
     twin = models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he',
