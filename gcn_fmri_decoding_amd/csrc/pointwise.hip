@@ -346,14 +346,27 @@ adam_sq_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
 // loss = cross_entropy + half_reg * sum(partials);  the ExponentialMovingAverage(0.9) of the loss with its zero-debiasing
 // (models_gcn.py:269-275): ema += (1 - decay) * (loss - ema);  loss_average = ema * corr.  One wave, one launch (torch: dot x 2,
 // add, lerp, mul).
-__global__ void __launch_bounds__(64)
+// (1024 threads: the ~3700 partials of the configs[1] variables were 58 dependent loads per lane of one wave, 16.7 us of the
+// step; four per thread and a fixed tree are 4 us.  Deterministic: the order of the additions depends on nparts only.)
+__global__ void __launch_bounds__(1024)
 loss_bookkeeping_kernel(const float* __restrict__ ce, const float* __restrict__ sq_part, int nparts, float half_reg,
                         float* __restrict__ ema, float decay, float corr_val, const float* __restrict__ corr_dev,
                         float* __restrict__ loss_out, float* __restrict__ loss_average_out) {
+    __shared__ float red[16];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     float s = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 64) s += sq_part[i];
+    for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + 1024 * u < nparts ? sq_part[i0 + 1024 * u] : 0.f;
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
     for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w];
         const float loss = *ce + half_reg * s;
         const float e = *ema + (1.f - decay) * (loss - *ema);
         *ema = e;
@@ -647,7 +660,7 @@ extern "C" int chebgcn_loss_bookkeeping(const float* cross_entropy, const float*
     hipStream_t stream = (hipStream_t)stream_;
     CG_REQUIRE(cross_entropy && ema && loss_average_out && nparts >= 0 && (nparts == 0 || sq_partials), "loss_bookkeeping: bad argument");
     note_dispatch("loss_bookkeeping_kernel");
-    hipLaunchKernelGGL(loss_bookkeeping_kernel, dim3(1), dim3(64), 0, stream, cross_entropy, sq_partials, nparts, half_reg, ema,
+    hipLaunchKernelGGL(loss_bookkeeping_kernel, dim3(1), dim3(1024), 0, stream, cross_entropy, sq_partials, nparts, half_reg, ema,
                        decay, corr, corr_dev, loss_out, loss_average_out);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
