@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'refresh')
 DST = os.path.join(ROOT, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 
 for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats.csv', '%s_bench_kernel_stats.csv'),
                  ('kbench.txt', '%s_kbench.txt'), ('kbench.json', '%s_kbench.json'),
@@ -29,7 +29,14 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
                  ('northstar_recurrence_bwd_kernel_stats.csv', '%s_northstar_bwd_kernel_stats.csv'),
                  ('config4_recurrence_fwd_inplace_kernel_stats.csv', '%s_config4_recurrence_fwd_kernel_stats.csv'),
                  ('config4_recurrence_bwd_kernel_stats.csv', '%s_config4_recurrence_bwd_kernel_stats.csv'), ('refshape_n360_kernel_stats.csv', '%s_refshape_n360_kernel_stats.csv'),
-                 ('refshape_n360_line.json', '%s_refshape_n360_line.json')] + [
+                 ('refshape_n360_line.json', '%s_refshape_n360_line.json'),
+                 ('config4_layer.txt', '%s_config4_layer.txt'), ('ord_sizes.txt', '%s_ordered_recurrence_sizes.txt'),
+                 ('wide_f32_vs_bf16x3.txt', '%s_wide_f32_vs_bf16x3.txt'), ('pool6.txt', '%s_pool6.txt'),
+                 ('pool6_kernel_stats.csv', '%s_pool6_kernel_stats.csv'),
+                 ('ordered_n6000_kernel_stats.csv', '%s_ordered_n6000_kernel_stats.csv'),
+                 ('ordered_n13000_kernel_stats.csv', '%s_ordered_n13000_kernel_stats.csv'),
+                 ('events_under_rocprof_ordered_n6000.txt', '%s_events_under_rocprof_ordered_n6000.txt'),
+                 ('events_under_rocprof_ordered_n13000.txt', '%s_events_under_rocprof_ordered_n13000.txt')] + [
         ('events_under_rocprof_%s_%s.txt' % (c, k), '%%s_events_under_rocprof_%s_%s.txt' % (c, k))
         for c in ('northstar', 'config4') for k in ('recurrence_fwd_inplace', 'recurrence_fwd', 'recurrence_bwd')]:
     p = os.path.join(SRC, src)

@@ -31,6 +31,12 @@ if lib_ok $GRAFT_REPO_ROOT/build_x/libchebgcn_b64.so; then
   CHEBGCN_LIB=$GRAFT_REPO_ROOT/build_x/libchebgcn_b64.so python3 tools/kbench.py --stamps --B 64 --fin 60 --fout 256 --K 5 --iters 10 --kernels contract_fwd_bf16 contract_bwd_x_bf16_dy16 > $out/stampsb.txt 2>&1
 fi
 python3 tools/config5_probe.py > $out/config5_layer.txt 2>&1
+SHAPE="64 25 64" STEPS=5 python3 tools/config5_probe.py > $out/config4_layer.txt 2>&1
+# round 5: the ordered recurrence over graph sizes beside the kernels of rounds 1-3 on the same box; fp32 against split-bf16
+# contraction kernels at the wide shapes; the pooling ChebNet of SURVEY 8(f)4
+bash tools/ord_sizes.sh 2600 6000 8000 10000 10242 13000 19000 > $out/ord_sizes.txt 2>&1
+bash tools/wide_shapes.sh > $out/wide_f32_vs_bf16x3.txt 2>&1
+python3 tools/pool6_probe.py > $out/pool6.txt 2>&1
 python3 tools/fused_check.py > $out/fused_small_check.txt 2>&1
 # ... and its phase stamps (build_x/libchebgcn_f64.so: tools/fbuild.sh f64 "-DCG_EXPERIMENT=1 -DCG_X=64")
 if lib_ok $GRAFT_REPO_ROOT/build_x/libchebgcn_f64.so; then
@@ -56,12 +62,19 @@ for kern in recurrence_fwd_inplace recurrence_fwd recurrence_bwd; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/profn_$kern -o ns -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --B 256 --iters 100 --kernels $kern > $out/events_under_rocprof_northstar_$kern.txt 2>&1
   find $out/profn_$kern -name "*kernel_stats.csv" -exec cp {} $out/northstar_${kern}_kernel_stats.csv \;
 done
+# round 5: the ordered kernels at N = 6000 (four planes, NG = 3) and N = 13000 (two planes), batch 256; the pooling ChebNet step
+for n in 6000 13000; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/profo_$n -o o -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --nodes $n --B 256 --iters 50 --kernels recurrence_fwd_inplace recurrence_bwd > $out/events_under_rocprof_ordered_n$n.txt 2>&1
+  find $out/profo_$n -name "*kernel_stats.csv" -exec cp {} $out/ordered_n${n}_kernel_stats.csv \;
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/profp -o p -- python3 $GRAFT_REPO_ROOT/tools/pool6_probe.py > $out/profp.log 2>&1
+find $out/profp -name "*kernel_stats.csv" -exec cp {} $out/pool6_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profr -o rs -- python3 $GRAFT_REPO_ROOT/tools/refshape.py --nodes 360 > $out/profr.log 2>&1
 find $out/profr -name "*kernel_stats.csv" -exec cp {} $out/refshape_n360_kernel_stats.csv \;
 grep "^{\"shape\"" $out/profr.log | tail -1 > $out/refshape_n360_line.json
 # what the memory system and the fp32 matrix pipe give with nothing else going on (EXPERIMENTS.md 3b)
 for b in 8 16 32 64; do $GRAFT_REPO_ROOT/tools/probes/hbm_stream_probe $b; done > $out/hbm_stream_probe.txt 2>&1
 $GRAFT_REPO_ROOT/tools/probes/mfma_f32_probe > $out/mfma_f32_probe.txt 2>&1
-rm -rf $out/prof $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr
+rm -rf $out/prof $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr $out/profo_* $out/profp
 cp gpurun_out/parity_measured.jsonl $out/ 2>/dev/null
 ls -la $out
