@@ -590,7 +590,8 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
     }
     // rows of L~ and of L~^T sorted by descending length (the caller relabelled the vertices: graph.length_order in the
     // Python host), isolated vertices last: the ordered images
-    if (rc == CHEBGCN_OK && want_planes == 0 && g->lds_ok) {
+    // (also where the regular images do not fit the LDS -- more than 20478 vertices of which at most 20476 are active)
+    if (rc == CHEBGCN_OK && want_planes == 0) {
         const int nf = sorted_rows(M, rp), na = sorted_rows(M, trp);
         int NT = 0, NQ = 0, NG = 0, PL = 0;
         if (nf >= 0 && nf == na && nf == nactive && ordered_shape(g->Mp / 4, (nactive + 3) / 4, &NT, &NQ, &NG, &PL)) {

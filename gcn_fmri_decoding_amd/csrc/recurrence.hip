@@ -698,6 +698,7 @@ extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, fl
     const int nplanes = B * Fin;
     const size_t slab = (size_t)nplanes * g->Mp;
     const int copy_t0 = (x != stack);
+    if (K > 1 && g->ord_ok && ordered_fits(g, nplanes)) return dispatch_ordered<false>(g, g->ofwd, x, stack, nplanes, K, copy_t0, stream);
     if (K == 1 || !g->lds_ok) {
         if (copy_t0) CG_HIP(hipMemcpyAsync(stack, x, slab * sizeof(float), hipMemcpyDeviceToDevice, stream));
         if (K == 1) return CHEBGCN_OK;
@@ -707,7 +708,6 @@ extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, fl
                              stack + k * slab, nplanes, 2.f, stream);
         return rc;
     }
-    if (g->ord_ok && ordered_fits(g, nplanes)) return dispatch_ordered<false>(g, g->ofwd, x, stack, nplanes, K, copy_t0, stream);
     const Ell& ell = pick_ell(g, false, nplanes);
     if (ell.planes == 4) return dispatch_onchip<4, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
     return dispatch_onchip<2, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);

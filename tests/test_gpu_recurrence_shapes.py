@@ -152,6 +152,82 @@ def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
     assert float(per_plane.max()) <= GREL, '%s: plane %d is %.3e from float64' % (name_a, int(per_plane.argmax()), float(per_plane.max()))
 
 
+# Every ordered kernel shape the library instantiates: (planes, NG, NQ) -> a random graph with exactly that many active and
+# isolated vertices (5 random neighbours per vertex, symmetrised: rows of 5 ... ~16 entries, so the record classes of 8 / 10 / 12
+# and more entries all occur; Gaussian weights).  (Two planes, NG = 5, NQ = 5 cannot occur: two planes are used from 10753 vertices.)
+ORD_TABLE = [(4, ng, nq) for ng in (2, 3, 4, 5) for nq in (ng, ng + 1)] + [(2, 5, 6)] + [(2, ng, nq) for ng in range(6, 11) for nq in (ng, ng + 1)]
+
+
+def _random_graph(n_active, n_iso, seed):
+    import scipy.sparse as sp
+    from gcn_fmri_decoding_amd import graph
+    rs = np.random.RandomState(seed)
+    rows = np.repeat(np.arange(n_active), 5)
+    cols = rs.randint(0, n_active, rows.size)
+    keep = rows != cols
+    W = sp.coo_matrix((np.exp(-rs.rand(int(keep.sum())) * 2).astype(np.float32), (rows[keep], cols[keep])), shape=(n_active, n_active)).tocsr()
+    W = W.maximum(W.T)
+    W = sp.block_diag([W, sp.csr_matrix((n_iso, n_iso), dtype=np.float32)], format='csr')      # isolated vertices: empty rows and columns
+    return graph.laplacian(W.astype(np.float32), normalized=True)
+
+
+@pytest.mark.parametrize('pl,ng,nq', ORD_TABLE, ids=['p%d_ng%d_nq%d' % t for t in ORD_TABLE])
+def test_ordered_shape_table(dev, pl, ng, nq):
+    """One launch per instantiated shape, named; every plane of the forward and of the adjoint against float64 on the device
+    (K = 4, partial last plane group, more plane groups than workgroups, isolated vertices carrying data)."""
+    from gcn_fmri_decoding_amd import _lib, graph, ops
+    from oracle import graph_ref as GR
+    lib = _lib.lib()
+    n_active = 2048 * (ng - 1) + 1000 if not (pl == 2 and ng == 5) else 10240
+    M = n_active + 4 if nq == ng else (2048 * ng + 40 if not (pl == 2 and ng == 5) else 10800)
+    L0 = _random_graph(n_active, M - n_active, 100 * pl + 10 * ng + nq)
+    order = graph.length_order(L0)
+    g = ops.Graph(L0, dev, order=order)
+    assert g.ordered and g.query(16) == pl, (g.ordered, g.query(16))
+    L = graph.permute(L0, order)
+    Mp = g.Mp
+    ent = min(2048 * ng + 16, 160 * 1024 // (4 * pl))
+    stem = '%s<%d,%d,%d,512,' % ('cheb_ord_kernel' if pl == 4 else 'cheb_ord2_kernel', ent, nq, ng)
+    B, Fin, K = 7, 301 if pl == 4 else 151, 4
+    nplanes = B * Fin
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(M)
+    x = torch.randn((B, Fin, Mp), generator=gen, device=dev)
+    x[:, :, M:] = float('nan')
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    stack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, st), 'fwd')
+    assert _lib.last_dispatch() == stem + 'false>', _lib.last_dispatch()
+    L64 = GR.rescale_L(L, 2).astype(np.float64).tocsr()
+    Ld = _sparse64(L64, dev)
+    X = x[:, :, :M].double().reshape(nplanes, M).t().contiguous()
+    T64 = [X, torch.sparse.mm(Ld, X)]
+    for k in range(2, K):
+        T64.append(2 * torch.sparse.mm(Ld, T64[-1]) - T64[-2])
+    worst_f = 0.0
+    for k in range(K):
+        got = stack[k, :, :, :M].reshape(nplanes, M).double()
+        per_plane = (got - T64[k].t()).abs().amax(dim=1) / T64[k].t().abs().amax(dim=1)
+        worst_f = max(worst_f, float(per_plane.max()))
+    assert worst_f <= REL, '%s: %.3e' % (stem, worst_f)
+    del X, T64
+    G = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    G[:, :, :, M:] = float('nan')
+    dx = torch.full((B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, st), 'bwd')
+    assert _lib.last_dispatch() == stem + 'true>', _lib.last_dispatch()
+    LTd = _sparse64(L64.T.tocsr(), dev)
+    Gk = lambda k: G[k, :, :, :M].double().reshape(nplanes, M).t().contiguous()
+    c2, c1 = torch.zeros_like(Gk(0)), Gk(K - 1)
+    for j in range(K - 2, 0, -1):
+        c2, c1 = c1, Gk(j) + 2 * torch.sparse.mm(LTd, c1) - c2
+    dref = (Gk(0) + torch.sparse.mm(LTd, c1) - c2).t()
+    per_plane = (dx[:, :, :M].reshape(nplanes, M).double() - dref).abs().amax(dim=1) / dref.abs().amax(dim=1)
+    record_measured('ordered_shape_table[p%d_ng%d_nq%d]' % (pl, ng, nq), fwd_worst_plane=worst_f, adjoint_worst_plane=float(per_plane.max()))
+    assert float(per_plane.max()) <= GREL, '%s: %.3e' % (stem, float(per_plane.max()))
+
+
 def test_ordered_recurrence_not_for_atlas_sizes(dev):
     """Up to 2048 active vertices the generic on-chip kernel and the fused atlas layer work in the caller's order: a graph in
     length order gets no ordered image there (and cgcnn keeps the reference's tree order, models_gcn.py)."""

@@ -51,7 +51,7 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
             shutil.copy(p, os.path.join(DST, dst % tag))
 
 raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
-names = {'cheb_ord_kernel<10240, 6, 5, 512, false>': 'recurrence_fwd', 'cheb_ord_kernel<10240, 6, 5, 512, true>': 'recurrence_bwd',
+names = {'cheb_ord_kernel<4, 10240, 6, 5, 512, false>': 'recurrence_fwd', 'cheb_ord_kernel<4, 10240, 6, 5, 512, true>': 'recurrence_bwd',
          'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd_2planes', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd_2planes',
          'cheb4_kernel<10240, 20, 6, 512, false,': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true,': 'recurrence_bwd_4planes',
          'contract_fwd_kernel<1>': 'contract_fwd', 'contract_fwd_ring_kernel': 'contract_fwd', 'contract_bwd_w_kernel<5, true>': 'contract_bwd_w',
