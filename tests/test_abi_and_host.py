@@ -168,3 +168,43 @@ def test_best_checkpoint_policy_matches_checkmat(tmp_path):
         'model_checkpoint_path: "best.ckpt-70"', 'all_model_checkpoint_paths: "best.ckpt-50"',
         'all_model_checkpoint_paths: "best.ckpt-20"', 'all_model_checkpoint_paths: "best.ckpt-70"']
     assert best == ['best.ckpt-50', 'best.ckpt-20', 'best.ckpt-70']
+
+
+def test_resolve_precision_rule():
+    """``cgcnn.contraction = 'auto'`` (ops.resolve_precision): exact fp32 products up to 32 filters -- every layer of BASELINE
+    configs[1] and of the reference's training.py (models_gcn.py:611-617 computes in fp32) -- split bf16 where the fp32 matrix
+    cores would bound the layer; explicit choices pass through."""
+    from gcn_fmri_decoding_amd import ops
+    auto = lambda fin, k, fout: ops.resolve_precision('auto', fin, k, fout)
+    assert [auto(15, 5, 32), auto(32, 5, 32), auto(32, 25, 32), auto(15, 10, 32)] == ['f32'] * 4          # configs[1], training.py
+    assert auto(64, 25, 64) == 'bf16x3' and auto(60, 5, 256) == 'bf16x3'                                  # BASELINE configs[3], [4]
+    assert [auto(32, 10, 64), auto(64, 10, 64), auto(64, 5, 128), auto(128, 5, 128)] == ['bf16x3'] * 4    # the pooling ChebNet
+    assert auto(2, 2, 64) == 'f32'                                  # 64 filters but 4 reduction rows: 1.9 flop/B, HBM-bound in fp32
+    for p in ('f32', 'bf16', 'bf16x3'):
+        assert ops.resolve_precision(p, 64, 25, 64) == p
+    assert ops.FP32_MFMA_BALANCE == pytest.approx(157.3e12 / 8e12, rel=0.01)
+
+
+def test_internal_planes_wrapper_keeps_the_order_explicit():
+    """A batch in a model's internal vertex order is a wrapper object (models_gcn.InternalPlanes), not a tensor with a hidden
+    attribute: window slices, clone and detach of the WRAPPER stay wrapped; nothing a tensor operation returns is wrapped;
+    indexing another axis and refilling from a plain tensor are refused."""
+    import torch
+    from gcn_fmri_decoding_amd.models_gcn import InternalPlanes
+    owner = object()
+    x = torch.arange(2 * 3 * 8, dtype=torch.float32).reshape(2, 3, 8)
+    w = InternalPlanes(x, owner)
+    assert w.shape == x.shape and len(w) == 2 and w.planes is x and w.owner is owner
+    for v in (w[:], w[0:1], w.clone(), w.detach(), w[torch.tensor([1, 0])]):
+        assert isinstance(v, InternalPlanes) and v.owner is owner and v.planes.dim() == 3
+    assert w[1].shape == (1, 3, 8) and torch.equal(w[1].planes[0], x[1])
+    assert not isinstance(w.planes[:1], InternalPlanes) and not hasattr(w.planes.clone(), '_chebgcn_internal')
+    with pytest.raises(IndexError):
+        w[:, 0]
+    with pytest.raises(TypeError):
+        w.copy_(x)
+    with pytest.raises(TypeError):
+        w.copy_(InternalPlanes(x.clone(), object()))
+    y = InternalPlanes(torch.zeros_like(x), owner)
+    assert torch.equal(y.copy_(w).planes, x)
+    assert InternalPlanes(w, owner).planes is x                      # wrapping a wrapper does not nest
