@@ -34,6 +34,7 @@ SIGNATURES = {
     'chebgcn_graph_query': (_i, [_p, _i, C.POINTER(_i64)]),
     'chebgcn_recurrence_fwd': (_i, [_p, _p, _p, _i, _i, _i, _p]),
     'chebgcn_recurrence_bwd': (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    'chebgcn_recurrence_fwd_t': (_i, [_p, _p, _p, _i, _i, _i, _p]),
     'chebgcn_contract_fwd': (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_fwd_bf16_workspace': (C.c_size_t, [_i, _i, _i]),
     'chebgcn_contract_fwd_bf16': (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     'chebgcn_contract_bwd_w_relu_mean': (_i, [_p, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_x_relu_mean': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'chebgcn_bias_grad_relu_mean': (_i, [_p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p]),
+    'chebgcn_relu_grad_mean': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p]),
     'chebgcn_fused_layer_supported': (_i, [_p, _i, _i, _i, _i]),
     'chebgcn_fused_layer_workspace': (C.c_size_t, [_p, _i, _i, _i, _i]),
     'chebgcn_fused_layer_fwd': (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),

@@ -145,15 +145,18 @@ struct chebgcn_graph {
 #endif
 namespace chebgcn {
 // the operator image a launch over `nplanes` planes uses
-inline const Ell& pick_ell(const chebgcn_graph* g, bool adjoint, int nplanes) {
+// (`adjoint`: the image of L~^T; `adjoint_kernel`: the Clenshaw kernel runs on it -- chebgcn_recurrence_fwd_t runs the FORWARD
+// kernel on the image of L~^T)
+inline const Ell& pick_ell(const chebgcn_graph* g, bool adjoint, int nplanes, int adjoint_kernel = -1) {
     const Ell& e = adjoint ? g->adj : g->fwd;
+    const bool adjk = adjoint_kernel < 0 ? adjoint : adjoint_kernel != 0;
     if (!g->has_alt2 || e.planes != 4) return e;
     // Beyond 10752 vertices the two-plane kernel has only its 512-thread shapes with 24..40 rows per thread (0.23-0.26 of the
     // HBM roofline at any launch size): four planes win -- except in the forward direction on a graph with more than four
     // isolated vertices per thread (iso_max512: the coarsening's fake vertices), where the four-plane kernel patches them in
     // from memory once per order.  Measured on the level-0 graph of the six-level pooling network (M = 12672, 2672 fake
     // vertices, batch 64, K = 20 and 10): forward 0.97 ms on two planes, 1.49 ms on four; adjoint 0.61 ms on two, 0.43 on four.
-    if (g->M > 10752) return (adjoint || e.iso_max512 <= 4) ? e : g->fwd2;
+    if (g->M > 10752) return (adjk || e.iso_max512 <= 4) ? e : (adjoint ? g->adj2 : g->fwd2);
     // few groups per CU: the two-plane image keeps more workgroups in flight.  Measured in the configs[1] step
     // (M = 10466, 2048 planes per launch): both directions on two planes 4.235 ms, adjoint on four 4.27, both on
     // four 4.37 -- although the isolated adjoint launch is 5 % faster on four planes (tools/kbench.py)

@@ -523,9 +523,9 @@ extern "C" int chebgcn_relu_grad_bf16(const float* dout, const uint8_t* relu_mas
     return CHEBGCN_OK;
 }
 
-extern "C" int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* relu_mask, float* dbias, int bias_kind, int B, int M,
-                                           int F, void* workspace, size_t workspace_bytes, chebgcn_stream stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// gmean [B][Mp]: the gradient of every filter's output (one plane per window); dy (optional): the gated gradient [B][F][Mp]
+static int relu_grad_mean_impl(const float* gmean, const uint8_t* relu_mask, float* dy, float* dbias, int bias_kind, int B, int M,
+                               int F, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     CG_REQUIRE(gmean && relu_mask && dbias, "bias_grad_relu_mean: NULL argument");
     CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "bias_grad_relu_mean: bad shape");
     CG_REQUIRE(bias_kind == CHEBGCN_BIAS_FILTER || bias_kind == CHEBGCN_BIAS_VERTEX, "bias_grad_relu_mean: bad bias kind");
@@ -541,22 +541,33 @@ extern "C" int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* re
         note_dispatch_more("bias_filter_reduce_kernel");
         if (parts == 16)
             hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER, 16>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
-                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+                               dy, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
         else
             hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_FILTER, 4>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
-                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+                               dy, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
         hipLaunchKernelGGL(bias_filter_reduce_kernel, dim3(F), dim3(64), 0, stream, fpart, dbias, nblk);
     } else {
         note_dispatch(parts == 16 ? "bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,16><mean>" : "bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4><mean>");
         if (parts == 16)
             hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX, 16>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
-                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+                               dy, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
         else
             hipLaunchKernelGGL((bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX, 4>), dim3(nblk, F), dim3(256), 0, stream, gmean, relu_mask,
-                               (float*)nullptr, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
+                               dy, dbias, fpart, B, M, Mp, F, (size_t)Mp, (size_t)0);
     }
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* relu_mask, float* dbias, int bias_kind, int B, int M,
+                                           int F, void* workspace, size_t workspace_bytes, chebgcn_stream stream_) {
+    return relu_grad_mean_impl(gmean, relu_mask, nullptr, dbias, bias_kind, B, M, F, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int chebgcn_relu_grad_mean(const float* gmean, const uint8_t* relu_mask, float* dy, float* dbias, int bias_kind, int B,
+                                      int M, int F, void* workspace, size_t workspace_bytes, chebgcn_stream stream_) {
+    CG_REQUIRE(dy, "relu_grad_mean: dy is NULL");
+    return relu_grad_mean_impl(gmean, relu_mask, dy, dbias, bias_kind, B, M, F, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int chebgcn_perm_data(const float* x, const int32_t* perm, const int32_t* sample, float* out, int S,

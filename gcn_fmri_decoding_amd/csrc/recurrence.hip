@@ -713,6 +713,34 @@ extern "C" int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, fl
     return dispatch_onchip<2, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
 }
 
+// T_k(L~^T) x: the forward recurrence on the TRANSPOSED operator (the images every handle carries for the adjoint).  With it the
+// gradient of a layer wrt its input is  dx = sum_k [T_k(L~^T) dy] W_k^T : recurrence on the Fout planes of dy, then a contraction
+// of the stack of dy with the re-indexed W -- the same sum as the Clenshaw form (chebgcn_contract_bwd_x + chebgcn_recurrence_bwd),
+// associated the other way round: for Fout <= Fin it moves no more bytes and runs on the two faster kernels.
+extern "C" int chebgcn_recurrence_fwd_t(const chebgcn_graph* g, const float* x, float* stack, int B,
+                                        int Fin, int K, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(g && x && stack, "recurrence_fwd_t: NULL argument");
+    CG_REQUIRE(B > 0 && Fin > 0 && K >= 1, "recurrence_fwd_t: bad shape B=%d Fin=%d K=%d", B, Fin, K);
+    CG_REQUIRE((int64_t)B * Fin < (1 << 30), "recurrence_fwd_t: too many planes");
+    const int nplanes = B * Fin;
+    const size_t slab = (size_t)nplanes * g->Mp;
+    const int copy_t0 = (x != stack);
+    if (K > 1 && g->ord_ok && ordered_fits(g, nplanes)) return dispatch_ordered<false>(g, g->oadj, x, stack, nplanes, K, copy_t0, stream);
+    if (K == 1 || !g->lds_ok) {
+        if (copy_t0) CG_HIP(hipMemcpyAsync(stack, x, slab * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        if (K == 1) return CHEBGCN_OK;
+        int rc = step_global(g, g->adj, stack, nullptr, nullptr, stack + slab, nplanes, 1.f, stream);
+        for (int k = 2; k < K && rc == CHEBGCN_OK; ++k)
+            rc = step_global(g, g->adj, stack + (k - 1) * slab, stack + (k - 2) * slab, nullptr,
+                             stack + k * slab, nplanes, 2.f, stream);
+        return rc;
+    }
+    const Ell& ell = pick_ell(g, true, nplanes, 0);
+    if (ell.planes == 4) return dispatch_onchip<4, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
+    return dispatch_onchip<2, false>(g, ell, x, stack, nplanes, K, copy_t0, stream);
+}
+
 extern "C" int chebgcn_recurrence_bwd(const chebgcn_graph* g, const float* gstack, float* dx, int B,
                                       int Fin, int K, chebgcn_stream stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -84,6 +84,12 @@ fused_small = os.environ.get('CHEBGCN_FUSED_SMALL', '1') != '0'
 # contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd (dW feeds neither): +1.5 % on the
 # configs[1] step.  Not on instrumented steps, whose per-kernel event times must not include a neighbour.
 overlap_bwd_w = True
+# d(loss)/dx of a layer with Fout <= Fin as  sum_k [T_k(L~^T) dy] W_k^T  -- the FORWARD recurrence on the planes of dy
+# (chebgcn_recurrence_fwd_t, in place in slab 0 of the gradient stack), then the forward contraction kernel with the re-indexed
+# weights -- instead of chebgcn_contract_bwd_x + chebgcn_recurrence_bwd (the same sum in Clenshaw form): as many bytes, on the two
+# faster kernels (the stack of dy is written by a recurrence at 0.49 and read by a contraction at 0.64 of the HBM roofline
+# instead of written by one at 0.55 and read by one at 0.43); False keeps the Clenshaw form everywhere
+dx_by_forward = os.environ.get('CHEBGCN_DX_BY_FORWARD', '1') != '0'
 bias_side_small = True       # fused atlas-size layers: the bias reduction on the second stream as well
 _side_streams = {}
 
@@ -353,7 +359,8 @@ def resolve_precision(precision, Fin, K, Fout):
     return 'bf16x3' if (Fout > 32 and ai > FP32_MFMA_BALANCE) else 'f32'
 
 
-def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision='f32'):
+def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision='f32',
+                      what='contract_fwd'):
     """Launches the forward contraction (models_gcn.py:611-648) into ``out``.
 
     precision 'f32' = chebgcn_contract_fwd (exact fp32 MFMA); 'bf16' / 'bf16x3' =
@@ -364,18 +371,18 @@ def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout
     Mo = M // pool
     nbytes, flops = 4.0 * B * (M * Fin * K + Mo * Fout), 2.0 * B * M * Fin * K * Fout
     if precision == 'f32':
-        _lib.check(_launch('contract_fwd', nbytes, flops,
+        _lib.check(_launch(what, nbytes, flops,
                            lambda: lib.chebgcn_contract_fwd(_p(stack), _p(W), _p(bias), bias_kind, _p(out), _p(argmax), B, M,
                                                             Fin, K, Fout, pool, pool_kind, int(relu), _stream())),
-                   'contract_fwd')
+                   what)
         return
     nws = lib.chebgcn_contract_fwd_bf16_workspace(Fin, K, Fout)
     ws = _workspace(nws, stack.device, 'fwd_bf16')
-    _lib.check(_launch('contract_fwd_' + precision, nbytes, flops,
+    _lib.check(_launch(what + '_' + precision, nbytes, flops,
                        lambda: lib.chebgcn_contract_fwd_bf16(_p(stack), _p(W), _p(bias), bias_kind, _p(out), _p(argmax), B, M,
                                                              Fin, K, Fout, pool, pool_kind, int(relu), PRECISIONS[precision],
                                                              _p(ws), nws, _stream())),
-               'contract_fwd_bf16')
+               what + '_bf16')
 
 
 def _grad_mode(bufs):
@@ -524,7 +531,6 @@ class ChebConv(torch.autograd.Function):
         else:
             gout = gout.contiguous()
         dev = gout.device
-        fold = ctx.fold
         dbias = None
         bias_job = None
         if bias_kind != BIAS_NONE and ctx.needs_input_grad[2]:
@@ -533,10 +539,28 @@ class ChebConv(torch.autograd.Function):
                 dbias = dbias_buf                 # overwritten, like dW: one use per step
             else:
                 dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
+        # gradient wrt the input by the forward recurrence on dy (see dx_by_forward): dy is then materialised (slab 0 of the stack
+        # the recurrence fills), so the ReluGrad is not folded into the contraction gradients of this layer
+        # (not where the forward kernels of this graph are the slow ones: beyond 10752 vertices in the caller's order the forward
+        # recurrence runs on two planes, the Clenshaw adjoint on four -- common.h pick_ell)
+        by_fwd = bool(dx_by_forward and ctx.needs_input_grad[0] and not ctx.fused and K > 1 and Fout <= Fin
+                      and ctx.precision != 'bf16' and (g.ordered or g.M <= 10752)
+                      and (not mean or (ctx.fold and dbias is not None)))
+        fold = ctx.fold and not by_fwd
         Mo = M // pool
         dy16 = bool(bf16_dy16 and not fold and ctx.precision == 'bf16' and pool == 1 and relu and argmax is not None
                     and lib.chebgcn_bf16_dy16_supported(B, M, Fin, K, Fout))
-        if fold:
+        gstack = None
+        if by_fwd and mean:
+            # the last layer under the fused feature mean: every filter's gradient is the plane gout / Fout; one pass gates it
+            # with the ReLU mask into slab 0 of the stack the recurrence fills and reduces the bias gradient
+            gstack = torch.empty((K, B, Fout, g.Mp), dtype=torch.float32, device=dev)
+            dy, mask = gstack[0], None
+            bws, nbws = _brelu_bwd_ws(B, M, Fout, 1, bias_kind, dev)
+            _lib.check(_launch('brelu_pool_bwd', B * M * (4.0 + Fout * 4.25), 0.0, lambda: lib.chebgcn_relu_grad_mean(
+                _p(gout), _p(argmax), _p(dy), _p(dbias), bias_kind, B, M, Fout, _p(bws), nbws, _stream())), 'relu_grad_mean')
+            mean = False                                  # from here on an ordinary layer with a materialised dy
+        elif fold:
             # ReluGrad folded into the two contraction gradients (chebgcn_contract_bwd_*_relu read gout and the
             # mask); what is left of this pass is the bias reduction, which writes nothing but dbias
             dy, mask = gout, argmax
@@ -561,7 +585,11 @@ class ChebConv(torch.autograd.Function):
             _lib.check(_launch('relu_grad_bf16', B * Fout * M * (6.0 + 0.25), 0.0, lambda: lib.chebgcn_relu_grad_bf16(
                 _p(gout), _p(argmax), _p(dy), _p(dbias), bk, B, M, Fout, _p(bws), nbws, _stream())), 'relu_grad_bf16')
         else:
-            dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev), None
+            if by_fwd:
+                gstack = torch.empty((K, B, Fout, g.Mp), dtype=torch.float32, device=dev)
+                dy, mask = gstack[0], None          # T_0 of the recurrence on dy: written in place
+            else:
+                dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev), None
             # with the ReLU mask of a pool == 1 layer `out` is not read (a byte per four vertices instead)
             nbytes = B * Fout * M * (8.0 + 0.25) if out is None else 4.0 * B * Fout * (2 * Mo + M)
             bk = bias_kind if dbias is not None else BIAS_NONE
@@ -625,6 +653,13 @@ class ChebConv(torch.autograd.Function):
             _lib.check(_launch('fused_layer_bwd_x', 4.0 * B * M * (Fin + Fout), 2.0 * B * M * Fin * K * Fout,
                                lambda: lib.chebgcn_fused_layer_bwd_x(g.handle, _p(dy), _p(mask), _p(Wc), _p(dx), B, Fin, K, Fout,
                                                                      _stream())), 'fused_layer_bwd_x')
+        elif by_fwd:
+            _lib.check(_launch('recurrence_bwd', 4.0 * B * M * Fout * K, 0.0, lambda: lib.chebgcn_recurrence_fwd_t(
+                g.handle, _p(dy), _p(gstack), B, Fout, K, _stream())), 'recurrence_fwd_t')
+            Wt = Wc.view(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()     # W'[fo*K + k][fin] = W[fin*K + k][fo]
+            dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
+            contract_fwd_into(gstack, Wt, None, BIAS_NONE, dx, None, B, M, Fout, K, Fin, 1, POOL_MAX, False, ctx.precision,
+                              what='contract_bwd_x')
         elif ctx.needs_input_grad[0]:
             gstack = torch.empty((K, B, Fin, g.Mp), dtype=torch.float32, device=dev)
             passes = PRECISIONS[ctx.precision]

@@ -105,6 +105,16 @@ int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* value);
 int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, float* stack,
                            int B, int Fin, int K, chebgcn_stream stream);
 
+/* ---- the same recurrence on the TRANSPOSED operator: T_k(L~^T) x ------------------------------
+ * (TF autodiff of models_gcn.py:598-617, associated the other way round.)  The gradient of a layer wrt its input is
+ *   dx[b][fin] = sum_{k,fo} W[fin*K+k][fo] * ( T_k(L~^T) dy[b][fo] )
+ * -- the forward recurrence on the Fout planes of dy, then chebgcn_contract_fwd(_bf16) of that stack with the re-indexed
+ * weights W'[fo*K+k][fin] = W[fin*K+k][fo].  For Fout <= Fin this moves no more bytes than chebgcn_contract_bwd_x +
+ * chebgcn_recurrence_bwd (which compute the same sum in Clenshaw form) and runs on the two faster kernels.  Same layouts and
+ * in-place rule as chebgcn_recurrence_fwd. */
+int chebgcn_recurrence_fwd_t(const chebgcn_graph* g, const float* x, float* stack,
+                             int B, int Fin, int K, chebgcn_stream stream);
+
 /* ---- Chebyshev recurrence, adjoint: gradient of the above wrt x -----------------
  * (TF autodiff of models_gcn.py:598-610, reached from :298-303.)
  * c_{K-1} = G_{K-1}; c_j = G_j + 2 L~^T c_{j+1} - c_{j+2}; dx = G_0 + L~^T c_1 - c_2.
@@ -241,6 +251,11 @@ int chebgcn_contract_bwd_x_relu_mean(const float* gmean, const uint8_t* relu_mas
 int chebgcn_bias_grad_relu_mean(const float* gmean, const uint8_t* relu_mask, float* dbias, int bias_kind,
                                 int B, int M, int F, void* workspace, size_t workspace_bytes,
                                 chebgcn_stream stream);
+/* The same pass also writing the gated gradient dy[b][o][m] = relu_mask bit ? gmean[b][m] : 0, [B][F][Mp] -- the input of
+ * chebgcn_recurrence_fwd_t when the layer's gradient wrt its input is formed by the forward recurrence on dy. */
+int chebgcn_relu_grad_mean(const float* gmean, const uint8_t* relu_mask, float* dy, float* dbias, int bias_kind,
+                           int B, int M, int F, void* workspace, size_t workspace_bytes,
+                           chebgcn_stream stream);
 
 /* ---- atlas-sized graphs: one Chebyshev layer per launch, on chip ---------------------------------
  * models_gcn.py:587-629 (chebyshev5 + b1relu / b2relu, no pooling) for graphs of at most 384 vertices (the

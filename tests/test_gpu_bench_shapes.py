@@ -161,12 +161,28 @@ def _run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=T
 # single layers at M = 10466
 # ---------------------------------------------------------------------------------------
 
-def test_config2_layer_32_32_k5(ops, dev, bench_graph):
+@pytest.fixture(params=['forward', 'clenshaw'])
+def dx_form(request, ops, monkeypatch):
+    """How a layer with Fout <= Fin forms its gradient wrt the input (ops.dx_by_forward): 'forward' (default) = the forward
+    recurrence on the planes of dy with the transposed operator + the forward contraction kernel on the re-indexed weights;
+    'clenshaw' = chebgcn_contract_bwd_x + chebgcn_recurrence_bwd.  The same sum, associated the other way round: both are held
+    to the oracle."""
+    monkeypatch.setattr(ops, 'dx_by_forward', request.param == 'forward')
+    return request.param
+
+
+def test_config2_layer_32_32_k5(ops, dev, bench_graph, dx_form):
     """Layers 2-6 of configs[1]: Fin = Fout = 32, K = 5, b2relu, no pooling."""
-    errs = run_layer(ops, dev, bench_graph, B=3, Fin=32, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=1, expect={
-        'contract_fwd': 'contract_fwd_splitk_kernel', 'contract_bwd_x_relu': 'contract_bwd_x_kernel<true,true,true>',
-        'contract_bwd_w': 'contract_bwd_w_kernel<5,true>', 'brelu_pool_bwd': 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>',
-        'recurrence_fwd': 'cheb_onchip_kernel<2,14,4,768,false>', 'recurrence_bwd': 'cheb_onchip_kernel<2,14,4,768,true>'})
+    expect = {'contract_fwd': 'contract_fwd_splitk_kernel', 'brelu_pool_bwd': 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>',
+              'recurrence_fwd': 'cheb_onchip_kernel<2,14,4,768,false>'}
+    if dx_form == 'forward':
+        # dy is materialised (slab 0 of the stack the recurrence fills): plain weight gradient, forward kernels for dx
+        expect.update({'contract_bwd_w': 'contract_bwd_w_kernel<5,false>', 'recurrence_fwd_t': 'cheb_onchip_kernel<2,14,4,768,false>',
+                       'contract_bwd_x': 'contract_fwd_splitk_kernel'})
+    else:
+        expect.update({'contract_bwd_x_relu': 'contract_bwd_x_kernel<true,true,true>', 'contract_bwd_w': 'contract_bwd_w_kernel<5,true>',
+                       'recurrence_bwd': 'cheb_onchip_kernel<2,14,4,768,true>'})
+    errs = run_layer(ops, dev, bench_graph, B=3, Fin=32, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=1, expect=expect)
     print('config2 layer errors', errs)
 
 
@@ -176,13 +192,17 @@ def test_config2_first_layer_15_32_k5(ops, dev, bench_graph):
               expect={'contract_fwd': 'contract_fwd_splitk_kernel', 'contract_bwd_w': 'contract_bwd_w_kernel<3,true>'})
 
 
-def test_config4_layer_64_64_k25(ops, dev, bench_graph):
+def test_config4_layer_64_64_k25(ops, dev, bench_graph, dx_form):
     """configs[3]: K = 25, Fin = Fout = 64 -- Fin*K = 1600 (50 row tiles -> gy = 10 in bwd_w),
     Fout = 64 (two filter tiles in contract_fwd, dy streamed instead of held in bwd_x); one window = a small launch
-    (the big-launch arms of this shape: test_gpu_dispatch.py ``config4_b25``)."""
-    run_layer(ops, dev, bench_graph, B=1, Fin=64, Fout=64, K=25, p=1, pool_kind=0, bias=2, seed=3, expect={
-        'contract_fwd': 'contract_fwd_kernel<2>', 'contract_bwd_x_relu': 'contract_bwd_x_kernel<false,true,true>',
-        'contract_bwd_w': 'contract_bwd_w_kernel<5,true>'})
+    (the big-launch arms of this shape: test_gpu_dispatch.py ``config4_b25``).  (``ops.cheb_conv``'s own default precision is
+    'f32': these are the fp32 kernels; cgcnn's 'auto' would compute this shape in split bf16.)"""
+    expect = {'contract_fwd': 'contract_fwd_kernel<2>'}
+    if dx_form == 'forward':
+        expect.update({'contract_bwd_w': 'contract_bwd_w_kernel<5,false>', 'contract_bwd_x': 'contract_fwd_kernel<2>'})
+    else:
+        expect.update({'contract_bwd_x_relu': 'contract_bwd_x_kernel<false,true,true>', 'contract_bwd_w': 'contract_bwd_w_kernel<5,true>'})
+    run_layer(ops, dev, bench_graph, B=1, Fin=64, Fout=64, K=25, p=1, pool_kind=0, bias=2, seed=3, expect=expect)
 
 
 def test_pooled_layer_full_size(ops, dev, bench_graph):
@@ -201,8 +221,10 @@ def levels(name='layers_n212'):
 
 @pytest.mark.parametrize('Fin,K,rt,gy', [(4, 5, 1, 1), (8, 5, 2, 1), (13, 7, 3, 1), (32, 4, 4, 1), (32, 5, 5, 1),
                                           (11, 17, 5, 2), (64, 25, 5, 10)])
-def test_bwd_w_row_tile_sweep(ops, dev, Fin, K, rt, gy):
-    """contract_bwd_w_kernel<RT> for RT = 1..5 and several row-tile groups (gy > 1)."""
+def test_bwd_w_row_tile_sweep(ops, dev, Fin, K, rt, gy, monkeypatch):
+    """contract_bwd_w_kernel<RT> for RT = 1..5 and several row-tile groups (gy > 1), the ReluGrad folded in (the Clenshaw form
+    of the input gradient: with ``dx_by_forward`` the last shape, Fin = 64 > Fout = 40, would materialise dy)."""
+    monkeypatch.setattr(ops, 'dx_by_forward', False)
     ntiles = (Fin * K + 31) // 32
     assert min(ntiles, 5) == rt and (ntiles + rt - 1) // rt == gy      # the dispatcher's arithmetic (contract.hip bw_rt)
     run_layer(ops, dev, levels()[0], B=2, Fin=Fin, Fout=40, K=K, p=1, pool_kind=0, bias=2, seed=Fin + K,

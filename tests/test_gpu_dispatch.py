@@ -410,15 +410,27 @@ def _network_inputs(onet, M, C, B, seed):
 
 
 STEP_KERNELS = {
-    'recurrence_fwd': {'cheb_ord_kernel<10240,6,5,512,false>'},          # (cgcnn relabels the vertices: graph.length_order)
-    'recurrence_bwd': {'cheb_ord_kernel<10240,6,5,512,true>'},
-    'contract_fwd': {'contract_fwd_ring_kernel'},
-    'contract_bwd_x_relu': {'contract_bwd_x_lds_kernel<true>'},
-    'brelu_pool_bwd': {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>'},
+    # the Clenshaw form of the input gradient (ops.dx_by_forward = False): contract_bwd_x + recurrence_bwd
+    'clenshaw': {
+        'recurrence_fwd': {'cheb_ord_kernel<10240,6,5,512,false>'},          # (cgcnn relabels the vertices: graph.length_order)
+        'recurrence_bwd': {'cheb_ord_kernel<10240,6,5,512,true>'},
+        'contract_fwd': {'contract_fwd_ring_kernel'},
+        'contract_bwd_x_relu': {'contract_bwd_x_lds_kernel<true>'},
+        'brelu_pool_bwd': {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>'},
+    },
+    # the default: the forward recurrence on dy with the transposed operator + the forward contraction on the re-indexed weights
+    'forward': {
+        'recurrence_fwd': {'cheb_ord_kernel<10240,6,5,512,false>'},
+        'recurrence_fwd_t': {'cheb_ord_kernel<10240,6,5,512,false>'},
+        'contract_fwd': {'contract_fwd_ring_kernel'},
+        'contract_bwd_x': {'contract_fwd_ring_kernel'},
+        'brelu_pool_bwd': {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>'},
+    },
 }
 
 
-def test_config2_network_b64_vs_oracle(ops, dev):
+@pytest.mark.parametrize('dx_form', ['forward', 'clenshaw'])
+def test_config2_network_b64_vs_oracle(ops, dev, dx_form, monkeypatch):
     """BASELINE configs[1] as bench.py times it -- 6 x [K=5, F=32, p=1, b2relu], FC 512-256-22, block_dura 15, batch 64 on
     the M = 10466 graph -- logits, loss, EVERY gradient and one TF-form Adam step against the oracle
     (oracle/layers_ref.Net <-> lib_new/models_gcn.py:658-682, :253-276, :296), with the last layer fused with
@@ -437,6 +449,7 @@ def test_config2_network_b64_vs_oracle(ops, dev):
     import bench
     from gcn_fmri_decoding_amd import _lib, models_gcn
     from oracle import layers_ref as R
+    monkeypatch.setattr(ops, 'dx_by_forward', dx_form == 'forward')
     B, seed, reg = 64, 4, 5e-4
     with cf.ProcessPoolExecutor(2, mp_context=mp.get_context('spawn')) as ex:
         futs = [ex.submit(_oracle_worker, ('float32', seed, B)), ex.submit(_oracle_worker, ('float64', seed, B))]
@@ -467,14 +480,21 @@ def test_config2_network_b64_vs_oracle(ops, dev):
             seen = {}
             for what, name in log:
                 seen.setdefault(what, set()).add(name)
-            expect = dict(STEP_KERNELS)
+            expect = dict(STEP_KERNELS[dx_form])
             if fused:
                 expect['contract_fwd_mean'] = {'contract_fwd_ring_kernel<mean>'}
-                expect['contract_bwd_x_relu_mean'] = {'contract_bwd_x_lds_kernel<true>'}
-                expect['bias_grad_relu_mean'] = {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4><mean>'}
+                if dx_form == 'clenshaw':
+                    expect['contract_bwd_x_relu_mean'] = {'contract_bwd_x_lds_kernel<true>'}
+                    expect['bias_grad_relu_mean'] = {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4><mean>'}
+                else:
+                    expect['relu_grad_mean'] = {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4><mean>'}
             for what, names in expect.items():
                 assert seen.get(what) == names, (what, seen.get(what), names)
-            assert all(n.startswith(('contract_bwd_w_kernel<5,true>', 'contract_bwd_w_kernel<3,true>')) for n in seen['contract_bwd_w']), seen['contract_bwd_w']
+            absent = ('recurrence_bwd', 'contract_bwd_x_relu', 'contract_bwd_x_relu_mean') if dx_form == 'forward' else ('recurrence_fwd_t', 'contract_bwd_x')
+            assert not any(a in seen for a in absent), sorted(seen)
+            # layers 2-6 under the forward form read a materialised dy (plain kernel); layer 1 (no input gradient) and the Clenshaw form fold the ReluGrad
+            wnames = ('contract_bwd_w_kernel<5,false>', 'contract_bwd_w_kernel<3,true>') if dx_form == 'forward' else ('contract_bwd_w_kernel<5,true>', 'contract_bwd_w_kernel<3,true>')
+            assert {n.split(' + ')[0] for n in seen['contract_bwd_w']} == set(wnames), seen['contract_bwd_w']
             grads = {}
             for k in params:
                 grads[k] = net.gradient(k).cpu().numpy().astype(np.float64)
@@ -512,7 +532,7 @@ def test_config2_network_b64_vs_oracle(ops, dev):
         R.adam_tf_step(p32, {k: g32[k] for k in params}, state)
         for k in params:
             assert_adam_params_close(after[k], p32[k], state['v/' + k], 0, ill, k, rel=GREL, lr=2e-3, quantile=0.999)
-    record_measured('config2_network_b64_vs_oracle', **measured)
+    record_measured('config2_network_b64_vs_oracle[%s]' % dx_form, **measured)
     # fused and unfused differ only in the order of the sum over the 32 filters of the last layer
     lf, lu = results[True][0], results[False][0]
     assert np.abs(lf - lu).max() <= REL * np.abs(lu).max()
@@ -863,3 +883,80 @@ def test_adam_with_squares_and_loss_bookkeeping(ops, dev, n, dev_scalars):
     e_out = abs(float(out) - ema_ref * corr) / (ema_ref * corr)
     record_measured('adam_sq_loss_bookkeeping[%d]' % n, sum_sq=e_sq, ema=e_ema, loss_average=e_out)
     assert e_sq <= 2e-6 and e_ema <= 1e-6 and e_out <= 1e-6, (e_sq, e_ema, e_out)
+
+
+@pytest.mark.parametrize('n,ordered', [(300, False), (3000, False), (3000, True)])
+def test_recurrence_fwd_t_is_the_forward_recurrence_on_the_transposed_operator(ops, dev, lib, n, ordered):
+    """chebgcn_recurrence_fwd_t: T_k(L~^T) x -- on a NON-symmetric operator (a Laplacian is symmetric and would not tell L~ from
+    its transpose), against float64, copy and in place; with it the gradient of a layer wrt its input is
+    sum_k [T_k(L~^T) dy] W_k^T (TF autodiff of models_gcn.py:598-617), which the layer tests hold to the oracle."""
+    import scipy.sparse as sp
+    from gcn_fmri_decoding_amd import _lib, graph
+    rs = np.random.RandomState(n)
+    rows = np.repeat(np.arange(n), 6)
+    cols = rs.randint(0, n, rows.size)
+    A = sp.coo_matrix((rs.rand(rows.size).astype(np.float32) * 0.3, (rows, cols)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    if ordered:
+        # rows AND columns sorted by descending length are what the ordered image needs: symmetric pattern, asymmetric values
+        A = sp.csr_matrix(((A + A.T) != 0).astype(np.float32))
+        A.data = (rs.rand(A.nnz).astype(np.float32) * 0.3)
+    L = (A + sp.identity(n, dtype=np.float32, format='csr')).tocsr()          # rescale_L subtracts the identity again: L~ = A
+    order = graph.length_order(L) if ordered else None
+    g = ops.Graph(L, dev, order=order)
+    assert g.ordered == ordered
+    if ordered:
+        L = graph.permute(L, order)
+    indptr, indices, data = graph.rescaled_laplacian_csr(L)
+    Lt = sp.csr_matrix((data.astype(np.float64), indices, indptr), shape=(n, n))
+    assert abs(Lt - Lt.T).max() > 1e-3                                         # really not symmetric
+    B, Fin, K, Mp = 3, 5, 4, g.Mp
+    x = torch.full((B, Fin, Mp), float('nan'), device=dev)
+    x[:, :, :n] = torch.as_tensor(rs.randn(B, Fin, n).astype(np.float32)).to(dev)
+    stack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    _lib.check(lib.chebgcn_recurrence_fwd_t(g.handle, P(x), P(stack), B, Fin, K, stream()), 'fwd_t')
+    name = _lib.last_dispatch()
+    X = x[:, :, :n].cpu().numpy().astype(np.float64).reshape(B * Fin, n).T
+    T = [X, Lt.T @ X]
+    for k in range(2, K):
+        T.append(2 * (Lt.T @ T[-1]) - T[-2])
+    ref = np.stack(T).transpose(0, 2, 1).reshape(K, B, Fin, n)
+    e_t = np.abs(stack[..., :n].cpu().numpy() - ref).max() / np.abs(ref).max()
+    wrong = Lt @ X                                                             # the untransposed operator must NOT match
+    assert np.abs(stack[1, ..., :n].cpu().numpy().reshape(B * Fin, n).T - wrong).max() > 1e-3 * np.abs(wrong).max()
+    s2 = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
+    s2[0].copy_(x)
+    _lib.check(lib.chebgcn_recurrence_fwd_t(g.handle, P(s2), P(s2), B, Fin, K, stream()), 'fwd_t in place')
+    assert torch.equal(s2[..., :n], stack[..., :n])
+    # the adjoint identity ties it to chebgcn_recurrence_fwd: <T(L~) u, v_k> summed over k  ==  <u, sum_k T_k(L~^T) v_k>
+    record_measured('recurrence_fwd_t[%d,%s]' % (n, ordered), kernel=name, err=e_t)
+    assert e_t <= REL, (name, e_t)
+    assert name.endswith('false>') or 'false,' in name, name                     # a FORWARD kernel template, on the image of L~^T
+
+
+def test_relu_grad_mean_writes_the_gated_gradient(ops, dev, lib):
+    """chebgcn_relu_grad_mean: dy[b][o][m] = mask bit ? gmean[b][m] : 0 and the bias gradient in one pass (the last layer under
+    the fused feature mean, models_gcn.py:673, when its input gradient is formed by the forward recurrence on dy)."""
+    from gcn_fmri_decoding_amd import _lib
+    B, M, F = 5, 1001, 7
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    gm = torch.zeros((B, Mp), device=dev)
+    gm[:, :M] = torch.randn((B, M), generator=gen, device=dev)
+    mask = torch.randint(0, 16, (B, F, Mp // 4), dtype=torch.uint8, device=dev)
+    bits = torch.stack([(mask >> r) & 1 for r in range(4)], -1).reshape(B, F, Mp).bool()
+    for kind, shape in ((ops.BIAS_VERTEX, (F, Mp)), (ops.BIAS_FILTER, (F,))):
+        dy = torch.full((B, F, Mp), float('nan'), device=dev)
+        db = torch.full(shape, float('nan'), device=dev)
+        n = lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, 1, kind)
+        ws = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        _lib.check(lib.chebgcn_relu_grad_mean(P(gm), P(mask), P(dy), P(db), kind, B, M, F, P(ws), n, stream()), 'relu_grad_mean')
+        ref = torch.where(bits, gm[:, None, :].expand(B, F, Mp), torch.zeros((), device=dev))
+        assert torch.equal(dy[..., :M], ref[..., :M])
+        if kind == ops.BIAS_VERTEX:
+            dbr = ref[..., :M].double().sum(0)
+            assert float((db[:, :M].double() - dbr).abs().max()) <= 1e-6 * float(dbr.abs().max()) and float(db[:, M:].abs().sum()) == 0.0
+        else:
+            dbr = ref[..., :M].double().sum((0, 2))
+            assert float((db.double() - dbr).abs().max()) <= 1e-6 * float(dbr.abs().max())
