@@ -144,6 +144,7 @@ class Graph:
                                                         data.ctypes.data_as(C.c_void_p), int(planes), C.byref(handle))
         _lib.check(rc, 'graph_create')
         self.handle = handle
+        self._ordered = None
         self._finalizer = weakref.finalize(self, _lib.lib().chebgcn_graph_destroy, handle)
 
     def query(self, what):
@@ -157,8 +158,11 @@ class Graph:
 
     @property
     def ordered(self):
-        """Rows sorted by descending length: the recurrence runs on csrc/recurrence_ord.hip."""
-        return bool(self.query(12))
+        """Rows sorted by descending length and a kernel shape that serves the graph: the recurrence runs on the ordered
+        kernels (csrc/recurrence_ord_kernel.h)."""
+        if self._ordered is None:
+            self._ordered = bool(self.query(12))
+        return self._ordered
 
 
 _graph_cache = weakref.WeakValueDictionary()
@@ -541,10 +545,12 @@ class ChebConv(torch.autograd.Function):
                 dbias = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=dev)
         # gradient wrt the input by the forward recurrence on dy (see dx_by_forward): dy is then materialised (slab 0 of the stack
         # the recurrence fills), so the ReluGrad is not folded into the contraction gradients of this layer
-        # (not where the forward kernels of this graph are the slow ones: beyond 10752 vertices in the caller's order the forward
-        # recurrence runs on two planes, the Clenshaw adjoint on four -- common.h pick_ell)
+        # On graphs in length order only: there the forward recurrence kernel is the faster of the two (0.49 against 0.43 of the
+        # HBM roofline in the step).  In the caller's order the Clenshaw kernels are as fast or faster -- measured: the reference's
+        # own shape at N = 1000 / 2000 (batch 128, K = 10) 1.93 / 3.32 ms this way against 1.89 / 3.16 ms; the level-0 layers of
+        # the pooling network run their forward recurrence on two planes, the adjoint on four (common.h pick_ell)
         by_fwd = bool(dx_by_forward and ctx.needs_input_grad[0] and not ctx.fused and K > 1 and Fout <= Fin
-                      and ctx.precision != 'bf16' and (g.ordered or g.M <= 10752)
+                      and ctx.precision != 'bf16' and g.ordered
                       and (not mean or (ctx.fold and dbias is not None)))
         fold = ctx.fold and not by_fwd
         Mo = M // pool

@@ -84,13 +84,13 @@ def from_storage(st, M):
     return st[:, :, :M].permute(0, 2, 1).cpu().numpy()
 
 
-def run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3, expect=None):
+def run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3, expect=None, ordered=False):
     """One conv layer forward + backward, HIP against oracle.  Returns the error dict.  ``expect``: entry point ->
     kernel templates (prefix) the dispatchers must have chosen for it (chebgcn_last_dispatch)."""
     from gcn_fmri_decoding_amd import _lib
     _lib.dispatch_log = log = []
     try:
-        errs = _run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx, wscale)
+        errs = _run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx, wscale, ordered)
         torch.cuda.synchronize()
     finally:
         _lib.dispatch_log = None
@@ -100,9 +100,17 @@ def run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=Tr
     return errs
 
 
-def _run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3):
+def _run_layer(ops, dev, L, B, Fin, Fout, K, p, pool_kind, bias, seed, need_dx=True, wscale=0.3, ordered=False):
     M = L.shape[0]
-    g = ops.graph_for(L, dev)
+    if ordered:
+        # the same layer on the relabelled graph (graph.length_order): the oracle runs on the relabelled Laplacian too
+        from gcn_fmri_decoding_amd import graph as G
+        order = G.length_order(L)
+        g = ops.Graph(L, dev, order=order)
+        assert g.ordered
+        L = G.permute(L, order)
+    else:
+        g = ops.graph_for(L, dev)
     rs = np.random.RandomState(seed)
     x = rs.randn(B, M, Fin).astype(np.float32)
     W = (rs.randn(Fin * K, Fout) * wscale / np.sqrt(Fin * K / 15.0)).astype(np.float32)
@@ -176,13 +184,15 @@ def test_config2_layer_32_32_k5(ops, dev, bench_graph, dx_form):
     expect = {'contract_fwd': 'contract_fwd_splitk_kernel', 'brelu_pool_bwd': 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>',
               'recurrence_fwd': 'cheb_onchip_kernel<2,14,4,768,false>'}
     if dx_form == 'forward':
+        # (the graph in length order, as cgcnn builds it: the forward form applies to ordered graphs only)
         # dy is materialised (slab 0 of the stack the recurrence fills): plain weight gradient, forward kernels for dx
-        expect.update({'contract_bwd_w': 'contract_bwd_w_kernel<5,false>', 'recurrence_fwd_t': 'cheb_onchip_kernel<2,14,4,768,false>',
-                       'contract_bwd_x': 'contract_fwd_splitk_kernel'})
+        expect.update({'recurrence_fwd': 'cheb_ord_kernel<10240,6,5,512,false>', 'contract_bwd_w': 'contract_bwd_w_kernel<5,false>',
+                       'recurrence_fwd_t': 'cheb_ord_kernel<10240,6,5,512,false>', 'contract_bwd_x': 'contract_fwd_splitk_kernel'})
     else:
         expect.update({'contract_bwd_x_relu': 'contract_bwd_x_kernel<true,true,true>', 'contract_bwd_w': 'contract_bwd_w_kernel<5,true>',
                        'recurrence_bwd': 'cheb_onchip_kernel<2,14,4,768,true>'})
-    errs = run_layer(ops, dev, bench_graph, B=3, Fin=32, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=1, expect=expect)
+    errs = run_layer(ops, dev, bench_graph, B=3, Fin=32, Fout=32, K=5, p=1, pool_kind=0, bias=2, seed=1, expect=expect,
+                     ordered=dx_form == 'forward')
     print('config2 layer errors', errs)
 
 
@@ -202,7 +212,8 @@ def test_config4_layer_64_64_k25(ops, dev, bench_graph, dx_form):
         expect.update({'contract_bwd_w': 'contract_bwd_w_kernel<5,false>', 'contract_bwd_x': 'contract_fwd_kernel<2>'})
     else:
         expect.update({'contract_bwd_x_relu': 'contract_bwd_x_kernel<false,true,true>', 'contract_bwd_w': 'contract_bwd_w_kernel<5,true>'})
-    run_layer(ops, dev, bench_graph, B=1, Fin=64, Fout=64, K=25, p=1, pool_kind=0, bias=2, seed=3, expect=expect)
+    run_layer(ops, dev, bench_graph, B=1, Fin=64, Fout=64, K=25, p=1, pool_kind=0, bias=2, seed=3, expect=expect,
+              ordered=dx_form == 'forward')
 
 
 def test_pooled_layer_full_size(ops, dev, bench_graph):
