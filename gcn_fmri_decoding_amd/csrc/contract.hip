@@ -871,6 +871,15 @@ static int num_cus() {
     return cus;
 }
 // a launch of one wave per 128-vertex tile that gives the chip fewer than two workgroups per CU: share the tiles
+// W'[(fo*K + k)][fin] = W[(fin*K + k)][fo]: the weights of the contraction that forms the input gradient from the stack of dy
+__global__ void __launch_bounds__(256)
+reindex_weights_kernel(const float* __restrict__ W, float* __restrict__ Wt, int Fin, int K, int Fout) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;                // over the OUTPUT: consecutive threads write consecutive words
+    if (idx >= Fin * K * Fout) return;
+    const int fin = idx % Fin, kk = idx / Fin, k = kk % K, fo = kk / K;
+    Wt[idx] = W[((size_t)fin * K + k) * Fout + fo];
+}
+
 static bool small_launch(int B, int M) { return ((M + 511) / 512) * B < 2 * num_cus(); }
 static int bw_grid_x(int B, int M) {
     const int cus = num_cus();
@@ -893,6 +902,16 @@ using namespace chebgcn;
 static int check_pool(int pool, int M) {
     if (pool < 1 || pool > 128 || (pool & (pool - 1)) != 0 || (M % pool) != 0) return 0;
     return 1;
+}
+
+extern "C" int chebgcn_reindex_weights(const float* W, float* Wt, int Fin, int K, int Fout, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(W && Wt && W != Wt, "reindex_weights: NULL argument (or in place)");
+    CG_REQUIRE(Fin > 0 && K > 0 && Fout > 0 && (int64_t)Fin * K * Fout < (1ll << 30), "reindex_weights: bad shape");
+    note_dispatch("reindex_weights_kernel");
+    hipLaunchKernelGGL(reindex_weights_kernel, dim3((Fin * K * Fout + 255) / 256), dim3(256), 0, stream, W, Wt, Fin, K, Fout);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
 }
 
 extern "C" int chebgcn_contract_fwd(const float* stack, const float* W, const float* bias, int bias_kind,

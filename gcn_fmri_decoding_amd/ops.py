@@ -662,7 +662,8 @@ class ChebConv(torch.autograd.Function):
         elif by_fwd:
             _lib.check(_launch('recurrence_bwd', 4.0 * B * M * Fout * K, 0.0, lambda: lib.chebgcn_recurrence_fwd_t(
                 g.handle, _p(dy), _p(gstack), B, Fout, K, _stream())), 'recurrence_fwd_t')
-            Wt = Wc.view(Fin, K, Fout).permute(2, 1, 0).reshape(Fout * K, Fin).contiguous()     # W'[fo*K + k][fin] = W[fin*K + k][fo]
+            Wt = torch.empty((Fout * K, Fin), dtype=torch.float32, device=dev)                 # W'[fo*K + k][fin] = W[fin*K + k][fo]
+            _lib.check(lib.chebgcn_reindex_weights(_p(Wc), _p(Wt), Fin, K, Fout, _stream()), 'reindex_weights')
             dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
             contract_fwd_into(gstack, Wt, None, BIAS_NONE, dx, None, B, M, Fout, K, Fin, 1, POOL_MAX, False, ctx.precision,
                               what='contract_bwd_x')

@@ -114,6 +114,9 @@ int chebgcn_recurrence_fwd(const chebgcn_graph* g, const float* x, float* stack,
  * in-place rule as chebgcn_recurrence_fwd. */
 int chebgcn_recurrence_fwd_t(const chebgcn_graph* g, const float* x, float* stack,
                              int B, int Fin, int K, chebgcn_stream stream);
+/* the re-indexed weights of that contraction: Wt[(fo*K + k)*Fin + fin] = W[(fin*K + k)*Fout + fo]  ([Fout*K][Fin] from
+ * [Fin*K][Fout], both row-major; one small launch -- the weights change every step) */
+int chebgcn_reindex_weights(const float* W, float* Wt, int Fin, int K, int Fout, chebgcn_stream stream);
 
 /* ---- Chebyshev recurrence, adjoint: gradient of the above wrt x -----------------
  * (TF autodiff of models_gcn.py:598-610, reached from :298-303.)
