@@ -620,7 +620,12 @@ class base_model(object):
         cgcnn._captures = getattr(cgcnn, '_captures', 0) + 1
         ops.capture_tag = cgcnn._captures
         try:
-            with torch.cuda.graph(graph):
+            # 'thread_local': only what THIS thread does between begin and end can fail the capture.  The backward pass runs on
+            # autograd's device thread; under the default ('global') any potentially-unsafe runtime call of any other thread
+            # while the capture is open -- the caching allocator growing a pool from the autograd thread, a collected
+            # object releasing an event -- invalidates it, and a failed capture leaves the process unusable (seen as a
+            # rare, order-dependent failure of the first capture after the multi-process tests)
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 sg['loss_average'] = self._step_body(self.as_internal(sg['x']), sg['labels'], sg['lr_t'], sg['ema_c'][0])
         finally:
             ops.capture_tag = None
