@@ -100,7 +100,17 @@ def cpu_baseline(Ls, cfg, n_windows, seed=0, repeats=5):
     scipy_step()
     dt_scipy = time.time() - t0
     t_scipy = time.time() - t_all
-    return {'value': n_windows / med, 'unit': 'windows/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+    # the REFERENCE's own NumPy/SciPy path (lib_new/graph.py:155-172 + models_gcn.py:611-616), timed by oracle/time_reference.py
+    # in the build container -- the reference never travels to this box: static, labelled
+    reference = None
+    rpath = os.path.join(ROOT, 'profiles', 'r06_reference_cpu.json')
+    if os.path.exists(rpath):
+        rj = json.load(open(rpath))
+        reference = {'static': True, 'source': 'profiles/r06_reference_cpu.json (oracle/time_reference.py, build container, not this host)',
+                     'what': rj['what'], 'host': rj['host'],
+                     'configs1_six_conv_layers_forward': rj['configs1_network_forward'],
+                     'layer_s': {k: rj[k]['layer_s'] for k in ('configs1_layer1', 'configs1_layers2to6', 'configs3', 'configs4')}}
+    return {'value': n_windows / med, 'unit': 'windows/s', 'cores': int(torch.get_num_threads()), 'kind': 'port', 'reference': reference,
             'sample': '%d windows per step, full 6-layer fwd+loss+bwd+Adam; torch-CPU restatement (oracle/torch_cpu_ref.py, '
                       'torch.sparse_csr SpMM, %d torch threads of %d host CPUs): 1 warm-up + median of %d steps, %.1f s in all'
                       % (n_windows, torch.get_num_threads(), os.cpu_count() or 0, repeats, t_torch),
@@ -618,7 +628,7 @@ def main():
     kern, sampled = {}, 0
     exposed_ms = None
     if args.instrumented_steps > 0:
-        ops.timers = ops.KernelTimers(every=1)
+        ops.timers = ops.KernelTimers(every=1, by_dispatch=True)
         if world > 1:
             net._dp.exposed_events = []
         for i in range(nxt, nxt + args.instrumented_steps):
@@ -657,29 +667,54 @@ def main():
                                             % (repeats, args.steps)},
         }
         if kern:
-            dom = max(kern, key=lambda k: kern[k]['total_ms'])
-            d = kern[dom]
+            # `kern` is keyed 'op | kernel template(s) chebgcn_last_dispatch() reported'.  Two tables come out of it: per op
+            # (`kernels`, as in earlier rounds) and per kernel SYMBOL (`kernels_by_symbol`): the forward recurrence kernel also
+            # serves the input gradient (on dy with the transposed operator), the forward contraction kernel its contraction.
+            # The dominant kernel of the step -- `roofline` -- is chosen by symbol, so that its average launch time can be
+            # compared with the AverageNs rocprofv3 --kernel-trace --stats reports for that symbol on the same command
+            # (profiles/*_bench_kernel_stats_serial.csv: --overlap-bwd-w 0, every kernel alone on the device)
+            def merged(key_of):
+                out = {}
+                for k, v in kern.items():
+                    d = out.setdefault(key_of(k), {'launches': 0, 'total_ms': 0.0, 'bytes': 0.0, 'flops': 0.0})
+                    for f in d:
+                        d[f] += v[f]
+                for d in out.values():
+                    d['avg_ms'] = d['total_ms'] / d['launches']
+                return out
+            raw_keys = list(kern)
+            by_sym = merged(lambda k: k.split(' | ', 1)[1])
+            kern = merged(lambda k: k.split(' | ', 1)[0])
+            dom = max(by_sym, key=lambda k: by_sym[k]['total_ms'])
+            d = by_sym[dom]
             achieved = d['bytes'] / (d['total_ms'] * 1e-3) / 1e9
-            traffic = None
+            traffic = traffic_note = None
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj.get('by_kernel', {}).get(dom)
+                traffic_note = tj.get('_note')
             line['roofline'] = {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                                'traffic_source': 'profiles/traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
-                                                  'tools/pmc_traffic.sh at this shape, not measured in this run)',
+                                'traffic_source': 'profiles/traffic.json by_kernel[%r] (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                                                  'passes of tools/pmc_traffic.sh over this kernel at its Fin = Fout = 32 launch of the '
+                                                  'step, not measured in this run)' % dom,
                                 'avg_launch_ms': d['avg_ms'], 'launches': d['launches'],
-                                'algorithmic_bytes_per_launch': d['bytes'] / d['launches']}
+                                'algorithmic_bytes_per_launch': d['bytes'] / d['launches'],
+                                'chosen_by': 'largest total time per kernel symbol over the instrumented steps',
+                                'ops': sorted(k.split(' | ', 1)[0] for k in raw_keys if k.split(' | ', 1)[1] == dom)}
             step_ms = 1e3 * dt / args.steps            # the same region `value` comes from
             step_bytes = sum(v['bytes'] for v in kern.values()) / max(sampled, 1)
             line['step_roofline'] = {'algorithmic_bytes_per_step': step_bytes, 'frac': step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      'what': 'algorithmic bytes of the hot kernels of one step (SURVEY.md 8d) / ms_per_step / 8 TB/s'}
-            line['kernels'] = {k: {'avg_ms': v['avg_ms'], 'launches': v['launches'],
-                                   'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
-                                   'frac_hbm': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   'TFLOPs': v['flops'] / (v['total_ms'] * 1e-3) / 1e12,
-                                   'share_of_step': v['total_ms'] / max(sampled, 1) / step_ms}
-                               for k, v in kern.items()}
+            table = lambda src: {k: {'avg_ms': v['avg_ms'], 'launches': v['launches'],
+                                     'GBps': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9,
+                                     'frac_hbm': v['bytes'] / (v['total_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     'TFLOPs': v['flops'] / (v['total_ms'] * 1e-3) / 1e12,
+                                     'share_of_step': v['total_ms'] / max(sampled, 1) / step_ms}
+                                 for k, v in src.items()}
+            line['kernels'] = table(kern)
+            line['kernels_by_symbol'] = table(by_sym)
             line['kernel_timing'] = ('HIP events around every launch of these kernels on the launch stream, in a separate '
                                      'instrumented pass of %d steps AFTER the timed regions (the timed steps carry no events)' % sampled)
         if world == 1 and args.kernel_legs:

@@ -54,6 +54,9 @@ SIGNATURES = {
     'chebgcn_brelu_pool_fwd': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'chebgcn_brelu_pool_bwd_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'chebgcn_brelu_pool_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p]),
+    'chebgcn_pool_gather_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'chebgcn_pool_scatter_bwd_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
+    'chebgcn_pool_scatter_bwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p]),
     'chebgcn_contract_bwd_w_workspace': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'chebgcn_contract_bwd_w': (_i, [_p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_x': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

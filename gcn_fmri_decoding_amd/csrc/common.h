@@ -65,6 +65,9 @@ struct Ell {
     // (measured: its gather 27k cycles against 20-22k for the others, and every step waits for it); the host balances the
     // gather cost of the waves instead.
     int ord_NT = 0, ord_NQ = 0, ord_NG = 0, ord_SQ = 0;
+    // first vertex the ordered kernel's ord_NQ quad levels do NOT reach (more than one level of isolated / padding vertices behind
+    // the rows: the fake vertices of a deep coarsening); 0 = none.  [ord_tail, Mp) holds no rows: cheb_ord_tail_kernel streams it
+    int ord_tail = 0;
     int32_t* blkmap = nullptr;    // [NT/64 * ord_NQ]
     uint16_t* rowslot = nullptr;  // [ngroups*64]  rank -> LDS slot of that row, 0xFFFF for padding ranks
     uint16_t* nodeslot = nullptr; // [Mp + 4]      vertex -> LDS slot, 0xFFFF = none (isolated / pad)
@@ -110,7 +113,7 @@ template <bool ADJ>
 int dispatch_onchip4(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
                      hipStream_t stream);
 // recurrence_ord.hip: shape {NQ, NG, planes per workgroup} of the ordered kernel for a graph of Mq vertex quads of which the
-// first SQ have rows; false = not served.  ordered_fits: the launch is addressable by the ordered kernels
+// first SQ have rows; false = not served.  NQ * NT may be less than Mq (NQ is capped at NG + 1): the vertices behind are the tail.  ordered_fits: the launch is addressable by the ordered kernels
 // (one 32-bit buffer descriptor per slab), else the caller takes the regular images
 bool ordered_shape(int Mq, int SQ, int* NT, int* NQ, int* NG, int* planes);
 bool ordered_fits(const chebgcn_graph* g, int nplanes);

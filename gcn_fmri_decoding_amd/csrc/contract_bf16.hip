@@ -127,6 +127,9 @@ struct Bf16Cfg {
     // producer for the bias (2 waves x 8 rows x 512 B), padded with re-reads to NDMA1.  Four compute waves only.
     static constexpr bool RING_BIAS = NW == 4 && !X16 && NDMA1 >= 8;
     static constexpr int BIAS_STEPS = 8;
+    // bias stage: 16 KB of rows + the padding DMAs' kilobyte behind them must lie inside the stage
+    static_assert(!RING_BIAS || STAGE >= 16384, "bias stage");
+    static_assert(!RING_BIAS || (NDMA0 <= 8 && NDMA1 <= 8) || STAGE >= 16384 + 1024, "padding DMAs of a bias stage leave the stage");
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -213,7 +216,10 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
                 // the vertices of tile v / NWF
                 const int i = p_ks - nks;
                 auto bias_dma = [&](int u) __attribute__((always_inline)) {
-                    const int uu = u & 7;                          // (beyond 8: padding, re-reads of the first ones into the unused W part)
+                    // (beyond 8: padding -- re-reads of the first ones, all into ONE kilobyte at the start of the W part, which a bias
+                    // stage does not use and every shape with padding has: see the static_assert of Bf16Cfg.  Round 5 aimed them at
+                    // 16384 + pw*4096 + q*1024, past the end of the stage of <1,4,false,2>: the next slot's first rows)
+                    const int uu = u & 7;
                     const int j = uu >> 2, q = uu & 3;
                     const int v = 2 * pw + j;
                     const int rho = 2 * q + g;
@@ -223,7 +229,7 @@ contract_fwd_bf16_kernel(FwdArgs a, const __bf16* __restrict__ Wp, int nks, int 
                     if (fo >= a.Fout) fo = a.Fout - 1;
                     __builtin_amdgcn_global_load_lds(a.bias + (size_t)fo * a.Mp + m,
                                                      reinterpret_cast<__attribute__((address_space(3))) void*>(
-                                                         u < 8 ? stage + v * 4096 + q * 1024 : stage + 16384 + pw * 4096 + q * 1024), 16, 0, 0);
+                                                         u < 8 ? stage + v * 4096 + q * 1024 : stage + 16384), 16, 0, 0);
                 };
                 // (a stage is the same number of DMA instructions whatever it carries: the vmcnt waits are constants per producer)
                 if (C::NDMA0 != C::NDMA1 && pw == 0) {

@@ -599,6 +599,8 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
             rc = build_ell_ordered(M, NT, NQ, NG, SQ, PL, rp, ci, va, &g->ofwd);
             if (rc == CHEBGCN_OK) rc = build_ell_ordered(M, NT, NQ, NG, SQ, PL, trp, tci, tva, &g->oadj);
             g->ord_ok = rc == CHEBGCN_OK;
+            // quad levels the kernel shape does not reach (ordered_shape caps NQ at NG + 1): the streamed tail
+            g->ofwd.ord_tail = g->oadj.ord_tail = 4 * NT * NQ < g->Mp ? 4 * NT * NQ : 0;
         }
     }
     if (rc != CHEBGCN_OK) {
@@ -640,6 +642,7 @@ extern "C" int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* va
         case 14: *value = g->ord_ok ? g->ofwd.cost_after : 0; break;
         case 15: *value = g->ord_ok ? g->ofwd.cost_ideal : 0; break;
         case 16: *value = g->ord_ok ? g->ofwd.planes : 0; break;
+        case 17: *value = g->ord_ok ? g->ofwd.ord_tail : 0; break;             // first vertex of the streamed tail of the ordered image, 0 = none
         default: return fail(CHEBGCN_EINVAL, "graph_query: unknown item %d", what);
     }
     return CHEBGCN_OK;

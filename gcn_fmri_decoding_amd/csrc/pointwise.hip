@@ -1,6 +1,8 @@
 // HBM-bound streaming kernels around the two hot kernels: gradient of pooling/ReLU/bias,
 // input staging (perm_data_3d gather + layout change), the feature mean in front of the
 // FC head, and the Adam update.  All accesses are coalesced along the vertex axis.
+#include <algorithm>
+
 #include "common.h"
 #ifndef CG_DY_NT
 #define CG_DY_NT 0      // see contract.hip
@@ -153,6 +155,172 @@ bias_filter_reduce_kernel(const float* __restrict__ fpart, float* __restrict__ d
     for (int i = threadIdx.x; i < nblk; i += 64) s += fpart[(size_t)f * nblk + i];
     for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
     if (threadIdx.x == 0) dbias[f] = s;
+}
+
+// ---- pooling between two vertex orders, and its gradient, through LDS --------------------------------------------------
+// mpool1 / apool1 (lib_new/models_gcn.py:631-648) pool p consecutive vertices of the coarsening's tree order.  A model that
+// keeps the vertices of a level in another order (cgcnn.vertex_order = 'length': the ordered recurrence kernels) pools through
+// an index map: pooled vertex j (in ITS level's internal order) takes the source vertices pmap[j*p + i], i < p (positions in
+// the source level's internal order, listed in tree order so that ties resolve as in the reference).  One workgroup = one
+// plane (window, filter): the plane is read once, coalesced, into LDS and gathered from there.
+//   sel (optional): what the gradient needs of the forward -- max: the winning i, 0xFF where `relu` and the maximum is not
+//   positive (the ReLU in front of the pooling passes no gradient); average: bit i = member i was positive.
+__global__ void __launch_bounds__(512)
+pool_gather_fwd_kernel(const float* __restrict__ y, const int32_t* __restrict__ pmap, float* __restrict__ out,
+                       uint8_t* __restrict__ sel, int Mp, int pool, int pool_kind, int relu, int Mo, int Mpo) {
+    extern __shared__ __attribute__((aligned(16))) float pg_plane[];          // [Mp]
+    const size_t pl = blockIdx.x;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4* src = reinterpret_cast<const f32x4*>(y + pl * Mp);
+    for (int i = threadIdx.x; i < (Mp >> 2); i += blockDim.x) reinterpret_cast<f32x4*>(pg_plane)[i] = __builtin_nontemporal_load(src + i);
+    __syncthreads();
+    const float inv = 1.0f / (float)pool;
+    for (int mo = threadIdx.x; mo < Mpo; mo += blockDim.x) {
+        float o = 0.f;
+        int s = 0;
+        if (mo < Mo) {
+            float best = 0.f, sum = 0.f;
+            int arg = 0, mask = 0;
+            for (int i = 0; i < pool; ++i) {
+                const int idx = pmap ? pmap[(size_t)mo * pool + i] : mo * pool + i;
+                const float v = pg_plane[idx];
+                if (i == 0 || v > best) { best = v; arg = i; }
+                sum += v;
+                if (v > 0.f && i < 8) mask |= 1 << i;
+            }
+            if (pool_kind == CHEBGCN_POOL_MAX) {
+                o = best;
+                s = (relu && !(best > 0.f)) ? 0xFF : arg;
+            } else {
+                o = sum * inv;
+                s = mask;
+            }
+        }
+        out[pl * Mpo + mo] = o;
+        if (sel) sel[pl * Mpo + mo] = (uint8_t)s;
+    }
+}
+
+// MaxPoolGrad / AvgPoolGrad + ReluGrad + bias gradient with 16-byte stores (and, with `smap`, across two vertex orders):
+//   dy[b][f][v] = d(loss)/d(pre-bias activation of source vertex v),  v in the source level's internal order,
+//   smap[v] = j*pool + i : v is member i of pooled vertex j (NULL: v itself, the tree order); -1: no gradient (padding).
+// Workgroup (pb, f) walks the windows of batch part pb: per window it stages {dout, sel} of the pooled plane in LDS (8 bytes per
+// pooled vertex, coalesced reads, double-buffered: one barrier per window), every thread then looks its own source quads up
+// and stores whole 16-byte pieces of dy.  The bias gradient of a vertex is a register sum over the part's windows; the NPB
+// partial sums are added in part order by pool_bias_reduce_kernel (fixed order: bit-reproducible, no atomics).
+// `out` (optional): the forward result, read where `sel` carries no dead flag (the fused contraction epilogue's argmax byte).
+template <int BIAS>
+__global__ void __launch_bounds__(512)
+pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const uint8_t* __restrict__ sel,
+                        const int32_t* __restrict__ smap, float* __restrict__ dy, float* __restrict__ part, int B, int M, int Mp,
+                        int F, int lgp, int pool_kind, int relu, int Mo, int Mpo) {
+    extern __shared__ __attribute__((aligned(16))) float2 ps_ent[];            // [2][Mpo]
+    constexpr int QPT = 8;                                 // source quads per thread and pass
+    const int f = blockIdx.y, pb = blockIdx.x, NPB = gridDim.x;
+    const int b0 = (int)((long long)B * pb / NPB), b1 = (int)((long long)B * (pb + 1) / NPB);
+    const int Mq = Mp >> 2, pmask = (1 << lgp) - 1;
+    const float inv = 1.0f / (float)(1 << lgp);
+    for (int q0 = 0; q0 < Mq; q0 += QPT * 512) {           // (graphs beyond 16384 vertices: more than one pass over the windows)
+        int code[QPT][4];
+        float4 acc[QPT];
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const int q = q0 + u * 512 + (int)threadIdx.x;
+            acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int v = 4 * q + i;
+                code[u][i] = (q < Mq && v < M) ? (smap ? smap[v] : v) : -1;
+            }
+        }
+        int buf = 0;
+        for (int b = b0; b < b1; ++b) {
+            const size_t po = ((size_t)b * F + f) * Mpo;
+            float2* ent = ps_ent + (size_t)buf * Mpo;
+            for (int j = threadIdx.x; j < Mpo; j += 512) {
+                float g = 0.f;
+                int s = 0xFF;
+                if (j < Mo) {
+                    g = __builtin_nontemporal_load(dout + po + j);
+                    s = sel ? sel[po + j] : 0;
+                    if (pool_kind == CHEBGCN_POOL_MAX) {
+                        if (out && relu && !(out[po + j] > 0.f)) s = 0xFF;
+                    } else {
+                        g *= inv;
+                        if (!relu) s = 0xFF;                    // every member takes its share
+                    }
+                }
+                ent[j] = make_float2(g, __int_as_float(s));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const int q = q0 + u * 512 + (int)threadIdx.x;
+                if (q < Mq) {
+                    float r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int c = code[u][i];
+                        float g = 0.f;
+                        if (c >= 0) {
+                            const float2 e = ent[c >> lgp];
+                            const int s = __float_as_int(e.y), pos = c & pmask;
+                            const bool take = pool_kind == CHEBGCN_POOL_MAX ? s == pos : ((s >> pos) & 1) != 0;
+                            g = take ? e.x : 0.f;
+                        }
+                        r[i] = g;
+                    }
+                    if (dy) *reinterpret_cast<float4*>(dy + ((size_t)b * F + f) * Mp + 4 * q) = make_float4(r[0], r[1], r[2], r[3]);
+                    acc[u].x += r[0]; acc[u].y += r[1]; acc[u].z += r[2]; acc[u].w += r[3];
+                }
+            }
+            buf ^= 1;
+        }
+        if (BIAS != CHEBGCN_BIAS_NONE) {
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const int q = q0 + u * 512 + (int)threadIdx.x;
+                if (q < Mq) *reinterpret_cast<float4*>(part + ((size_t)pb * F + f) * Mp + 4 * q) = acc[u];
+            }
+        }
+        __syncthreads();                                   // (a further pass refills the buffers)
+    }
+}
+
+// the NPB partial bias gradients of pool_scatter_bwd_kernel, added in part order; b1relu: then over the vertices of a filter
+template <int BIAS>
+__global__ void __launch_bounds__(256)
+pool_bias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int NPB, int F, int Mp) {
+    const int f = blockIdx.y;
+    const int Mq = Mp >> 2;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BIAS == CHEBGCN_BIAS_VERTEX) {
+        const int q = blockIdx.x * 256 + threadIdx.x;
+        if (q >= Mq) return;
+        for (int p = 0; p < NPB; ++p) {
+            const float4 o = *reinterpret_cast<const float4*>(part + ((size_t)p * F + f) * Mp + 4 * q);
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        *reinterpret_cast<float4*>(dbias + (size_t)f * Mp + 4 * q) = t;
+    } else {
+        __shared__ float red[256];
+        float s = 0.f;
+        for (int q = threadIdx.x; q < Mq; q += 256) {
+            t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = 0; p < NPB; ++p) {
+                const float4 o = *reinterpret_cast<const float4*>(part + ((size_t)p * F + f) * Mp + 4 * q);
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            s += (t.x + t.y) + (t.z + t.w);
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int d = 128; d > 0; d >>= 1) {
+            if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) dbias[f] = red[0];
+    }
 }
 
 // ---- standalone bias + ReLU + pooling forward (b1relu / b2relu / mpool1 / apool1 called on
@@ -413,11 +581,18 @@ static int brelu_bwd_blocks(int M, int F, int pool, int relu, bool have_mask, in
     return (M + 256 / parts - 1) / (256 / parts);
 }
 
+extern "C" size_t chebgcn_pool_scatter_bwd_workspace(int B, int M, int F, int pool, int bias_kind);
+static bool pool_scatter_fits(int M, int pool);
+static int pool_scatter_launch(const float* dout, const float* out, const uint8_t* sel, const int32_t* smap, float* dy, float* dbias,
+                               int bias_kind, int B, int M, int F, int pool, int pool_kind, int relu, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream);
+
 extern "C" size_t chebgcn_brelu_pool_bwd_workspace(int B, int M, int F, int pool, int bias_kind) {
-    (void)B;
-    (void)pool;
-    if (bias_kind != CHEBGCN_BIAS_FILTER || M <= 0 || F <= 0) return 0;
-    return (size_t)F * ((size_t)(M + 31) / 32 + 1) * sizeof(float);       // the finest split: 32 vertices per workgroup
+    if (M <= 0 || F <= 0) return 0;
+    // pooled layers: the 16-byte-store kernel (pool_scatter_bwd_kernel) leaves per-batch-part partial bias sums
+    const size_t pooled = (pool > 1 && pool_scatter_fits(M, pool)) ? chebgcn_pool_scatter_bwd_workspace(B, M, F, pool, bias_kind) : 0;
+    const size_t filter = bias_kind == CHEBGCN_BIAS_FILTER ? (size_t)F * ((size_t)(M + 31) / 32 + 1) * sizeof(float) : 0;   // the finest split: 32 vertices per workgroup
+    return std::max(pooled, filter);
 }
 
 extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const uint8_t* argmax, float* dy,
@@ -432,6 +607,14 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
     CG_REQUIRE(pool == 1 || argmax || (pool_kind == CHEBGCN_POOL_AVG && !relu), "brelu_pool_bwd: pooling needs argmax/mask");
     CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || dbias, "brelu_pool_bwd: dbias is NULL");
     const int Mp = plane_stride(M), Mpo = plane_stride(M / pool);
+    // pooled layers: whole 16-byte pieces of dy per store, the pooled plane staged in LDS (pool_scatter_bwd_kernel; the scalar
+    // kernel below ran at 0.18-0.22 of the HBM roofline in the six-level pooling network).  It needs the workspace
+    // chebgcn_brelu_pool_bwd_workspace() reports; a caller without one gets the scalar kernel.
+    if (pool > 1 && dy && pool_scatter_fits(M, pool) && (pool_kind == CHEBGCN_POOL_MAX || pool <= 8 || !relu) &&
+        (bias_kind == CHEBGCN_BIAS_NONE ||
+         (workspace && workspace_bytes >= chebgcn_pool_scatter_bwd_workspace(B, M, F, pool, bias_kind))))
+        return pool_scatter_launch(dout, out, argmax, nullptr, dy, dbias, bias_kind, B, M, F, pool, pool_kind, relu, workspace,
+                                   workspace_bytes, stream);
     int parts = 0;
     const int nblk = brelu_bwd_blocks(M, F, pool, relu, argmax != nullptr, &parts);
     float* fpart = nullptr;
@@ -482,6 +665,103 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
         CG_HIP(hipGetLastError());
     }
     return CHEBGCN_OK;
+}
+
+// batch parts of pool_scatter_bwd_kernel: enough workgroups for the chip; with a bias gradient each part leaves a partial
+// sum per vertex (written and read back once), so at most an eighth of the windows' own traffic goes into them
+static int pool_bwd_parts(int B, int F, int bias_kind) {
+    int n = (512 + F - 1) / F;
+    if (bias_kind != CHEBGCN_BIAS_NONE) n = std::min(n, std::max(1, B / 8));
+    return std::max(1, std::min(n, B));
+}
+
+extern "C" int chebgcn_pool_gather_fwd(const float* y, const int32_t* pmap, float* out, uint8_t* sel, int B, int M, int F,
+                                       int pool, int pool_kind, int relu, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(y && out, "pool_gather_fwd: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && F > 0 && (int64_t)B * F < (1ll << 31), "pool_gather_fwd: bad shape");
+    CG_REQUIRE(pool >= 2 && (pool & (pool - 1)) == 0 && pool <= 128 && M % pool == 0, "pool_gather_fwd: bad pool %d", pool);
+    CG_REQUIRE(pool_kind == CHEBGCN_POOL_MAX || pool_kind == CHEBGCN_POOL_AVG, "pool_gather_fwd: bad pool kind");
+    CG_REQUIRE(!(pool_kind == CHEBGCN_POOL_AVG && relu && sel && pool > 8), "pool_gather_fwd: average pooling keeps a ReLU mask only for pool <= 8");
+    const int Mp = plane_stride(M), Mo = M / pool, Mpo = plane_stride(Mo);
+    const size_t lds = (size_t)Mp * sizeof(float);
+    CG_REQUIRE(lds <= 160 * 1024, "pool_gather_fwd: a plane of %d vertices does not fit the LDS", M);
+    const int nt = Mp >= 8192 ? 512 : 256;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_gather_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    note_dispatch(pmap ? "pool_gather_fwd_kernel<map>" : "pool_gather_fwd_kernel");
+    hipLaunchKernelGGL(pool_gather_fwd_kernel, dim3((unsigned)(B * F)), dim3(nt), lds, stream, y, pmap, out, sel, Mp, pool, pool_kind, relu,
+                       Mo, Mpo);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" size_t chebgcn_pool_scatter_bwd_workspace(int B, int M, int F, int pool, int bias_kind) {
+    (void)pool;
+    if (bias_kind == CHEBGCN_BIAS_NONE || B <= 0 || M <= 0 || F <= 0) return 0;
+    return (size_t)pool_bwd_parts(B, F, bias_kind) * F * plane_stride(M) * sizeof(float);
+}
+
+static bool pool_scatter_fits(int M, int pool) { return (size_t)2 * plane_stride(M / pool) * sizeof(float2) <= 160 * 1024; }
+
+static int pool_scatter_launch(const float* dout, const float* out, const uint8_t* sel, const int32_t* smap, float* dy, float* dbias,
+                               int bias_kind, int B, int M, int F, int pool, int pool_kind, int relu, void* workspace,
+                               size_t workspace_bytes, hipStream_t stream) {
+    const int Mp = plane_stride(M), Mo = M / pool, Mpo = plane_stride(Mo);
+    int lgp = 0;
+    while ((1 << lgp) < pool) ++lgp;
+    const int NPB = pool_bwd_parts(B, F, bias_kind);
+    float* part = nullptr;
+    if (bias_kind != CHEBGCN_BIAS_NONE) {
+        CG_REQUIRE(workspace && workspace_bytes >= (size_t)NPB * F * Mp * sizeof(float),
+                   "pool_scatter_bwd: the bias gradient needs a workspace of chebgcn_pool_scatter_bwd_workspace() bytes");
+        part = static_cast<float*>(workspace);
+    }
+    const size_t lds = (size_t)2 * Mpo * sizeof(float2);
+    const dim3 grid(NPB, F);
+#define CG_PSB(BK)                                                                                                              \
+    do {                                                                                                                        \
+        static size_t lds_set = 0;                                                                                              \
+        if (lds > lds_set) {                                                                                                    \
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_scatter_bwd_kernel<BK>),                              \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
+            lds_set = lds;                                                                                                      \
+        }                                                                                                                       \
+        note_dispatch(smap ? "pool_scatter_bwd_kernel<" #BK "><map>" : "pool_scatter_bwd_kernel<" #BK ">");                     \
+        hipLaunchKernelGGL((pool_scatter_bwd_kernel<BK>), grid, dim3(512), lds, stream, dout, out, sel, smap, dy, part, B, M, Mp, F, lgp, \
+                           pool_kind, relu, Mo, Mpo);                                                                           \
+    } while (0)
+    if (bias_kind == CHEBGCN_BIAS_VERTEX) CG_PSB(CHEBGCN_BIAS_VERTEX);
+    else if (bias_kind == CHEBGCN_BIAS_FILTER) CG_PSB(CHEBGCN_BIAS_FILTER);
+    else CG_PSB(CHEBGCN_BIAS_NONE);
+#undef CG_PSB
+    CG_HIP(hipGetLastError());
+    if (bias_kind == CHEBGCN_BIAS_VERTEX) {
+        note_dispatch_more("pool_bias_reduce_kernel<CHEBGCN_BIAS_VERTEX>");
+        hipLaunchKernelGGL((pool_bias_reduce_kernel<CHEBGCN_BIAS_VERTEX>), dim3((Mp / 4 + 255) / 256, F), dim3(256), 0, stream, part, dbias,
+                           NPB, F, Mp);
+    } else if (bias_kind == CHEBGCN_BIAS_FILTER) {
+        note_dispatch_more("pool_bias_reduce_kernel<CHEBGCN_BIAS_FILTER>");
+        hipLaunchKernelGGL((pool_bias_reduce_kernel<CHEBGCN_BIAS_FILTER>), dim3(1, F), dim3(256), 0, stream, part, dbias, NPB, F, Mp);
+    }
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_pool_scatter_bwd(const float* dout, const uint8_t* sel, const int32_t* smap, float* dy, float* dbias,
+                                        int bias_kind, int B, int M, int F, int pool, int pool_kind, int relu, void* workspace,
+                                        size_t workspace_bytes, chebgcn_stream stream_) {
+    CG_REQUIRE(dout && (dy || (dbias && bias_kind != CHEBGCN_BIAS_NONE)), "pool_scatter_bwd: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && F > 0 && F <= 65535, "pool_scatter_bwd: bad shape");
+    CG_REQUIRE(pool >= 2 && (pool & (pool - 1)) == 0 && pool <= 128 && M % pool == 0, "pool_scatter_bwd: bad pool %d", pool);
+    CG_REQUIRE(sel || (pool_kind == CHEBGCN_POOL_AVG && !relu), "pool_scatter_bwd: pooling needs the forward's selection bytes");
+    CG_REQUIRE(bias_kind == CHEBGCN_BIAS_NONE || dbias, "pool_scatter_bwd: dbias is NULL");
+    CG_REQUIRE(pool_scatter_fits(M, pool), "pool_scatter_bwd: a pooled plane of %d vertices does not fit the LDS", M / pool);
+    return pool_scatter_launch(dout, nullptr, sel, smap, dy, dbias, bias_kind, B, M, F, pool, pool_kind, relu, workspace,
+                               workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int chebgcn_relu_grad_bf16(const float* dout, const uint8_t* relu_mask, uint16_t* dy16, float* dbias, int bias_kind,

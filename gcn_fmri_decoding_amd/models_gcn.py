@@ -32,15 +32,16 @@ from ._lib import BIAS_FILTER, BIAS_NONE, BIAS_VERTEX, POOL_AVG, POOL_MAX, plane
 
 
 class _Spec:
-    __slots__ = ('name', 'shape', 'kind', 'regularized', 'fan_in', 'group', 'ref_shape', 'vaxis')
+    __slots__ = ('name', 'shape', 'kind', 'regularized', 'fan_in', 'group', 'ref_shape', 'vaxis', 'vkey')
 
-    def __init__(self, name, shape, kind, regularized, fan_in, group, ref_shape, vaxis=None):
+    def __init__(self, name, shape, kind, regularized, fan_in, group, ref_shape, vaxis=None, vkey=None):
         self.name, self.shape, self.kind, self.regularized = name, tuple(shape), kind, regularized
         self.fan_in, self.group, self.ref_shape = fan_in, group, tuple(ref_shape)
         # axis of the STORED tensor that runs over the graph's vertices (per-vertex biases [F, Mp]: 1; the first FC layer's
         # weights [M, O]: 0), None otherwise: under a relabelled vertex order (cgcnn.vertex_order) that axis is stored in
-        # the internal order and the accessors (variable / set_variable / state_dict) translate
-        self.vaxis = vaxis
+        # the internal order and the accessors (variable / set_variable / state_dict) translate.  ``vkey`` names WHICH order:
+        # the conv layer's index (the order of that layer's graph level) or 'head' (the order the last conv layer's output is in)
+        self.vaxis, self.vkey = vaxis, vkey
 
 
 class InternalPlanes(object):
@@ -111,8 +112,16 @@ class base_model(object):
         self._dp = None                 # optional data-parallel helper (dist.DataParallel)
         self._step_graph_on, self._sg, self._sg_warm = False, None, 0      # enable_step_graph()
         self._step_graph_user = None    # the caller's explicit enable_step_graph(True / False), None = never asked
-        self._order = None              # internal vertex order (cgcnn: graph.length_order), None = the caller's
+        self._order = None              # internal vertex order of the INPUT level (cgcnn: graph.length_order), None = the caller's
+        self._vtabs = {}                # per-variable vertex orders (_Spec.vkey -> index tables), empty = the caller's everywhere
         self.record_fit = False         # keep the sampled indices and the loss_average series of fit()
+        # How the reported ``loss_average`` reads the 0.9-EMA of the loss (:269-275).  The reference calls
+        # ``tf.train.ExponentialMovingAverage(0.9)`` on the loss TENSOR and never passes ``zero_debias``: TensorFlow >= 1.0
+        # (what ``tf.contrib`` at :337 and the py3.6 bytecode imply) then keeps a zero-initialised shadow and reports it as
+        # is -- the first printed value is 0.1 * loss -- while TensorFlow 0.12 debiased every tensor's average
+        # (shadow / (1 - 0.9^t): the first value is the loss).  Reporting only; the default follows TF >= 1.0, set
+        # ``ema_zero_debias = True`` (or CHEBGCN_EMA_ZERO_DEBIAS=1) for the 0.12 reading.  Unverifiable here (no TensorFlow).
+        self.ema_zero_debias = os.environ.get('CHEBGCN_EMA_ZERO_DEBIAS', '0') not in ('0', '', 'false', 'False')
 
     # ---------------------------------------------------------------- run-time API
 
@@ -420,8 +429,9 @@ class base_model(object):
     def _ref_tensor(self, t, spec):
         """A stored tensor (a variable, its gradient, an Adam moment) in the reference's shape and vertex order: a view
         where the layouts agree, a gathered copy under a relabelled vertex order."""
-        if self._order is not None and spec.vaxis is not None:
-            t = t.index_select(spec.vaxis, self._inv_order_dev if spec.vaxis == 0 else self._inv_order_pad[:spec.ref_shape[1]])
+        tab = self._vtabs.get(spec.vkey) if spec.vaxis is not None else None
+        if tab is not None:
+            t = t.index_select(spec.vaxis, tab['inv'])
         if spec.group == 'convb':
             if len(spec.shape) == 2:                               # storage [F, Mp] -> [1, M, F]
                 return t[:, :spec.ref_shape[1]].t().unsqueeze(0)
@@ -434,15 +444,17 @@ class base_model(object):
         if spec.group == 'convb':
             if len(spec.shape) == 2:
                 v = v.reshape(spec.ref_shape)[0].t()               # [1, M, F] -> [F, M]
-                if self._order is not None:
-                    v = v.index_select(1, self._order_dev.long())
+                tab = self._vtabs.get(spec.vkey)
+                if tab is not None:
+                    v = v.index_select(1, tab['order'])
                 t[:, :spec.ref_shape[1]].copy_(v)
                 return
             t.copy_(v.reshape(t.shape))
             return
         v = v.reshape(spec.shape)
-        if self._order is not None and spec.vaxis == 0:
-            v = v.index_select(0, self._order_dev.long())
+        tab = self._vtabs.get(spec.vkey) if spec.vaxis == 0 else None
+        if tab is not None:
+            v = v.index_select(0, tab['order'])
         t.copy_(v)
 
     def variable(self, name):
@@ -499,10 +511,14 @@ class base_model(object):
                 and ops.timers is None):
             return self._train_step_graphed(x_storage, labels)
         t = self.global_step + 1
-        loss_average = self._step_body(x_storage, labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
+        loss_average = self._step_body(x_storage, labels, self._adam_lr_t(t), self._ema_read(t))
         reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
         self.global_step += 1
         return reported_lr, loss_average
+
+    def _ema_read(self, t):
+        """Factor between the EMA shadow after ``t`` updates and the reported ``loss_average`` (``ema_zero_debias``)."""
+        return 1.0 / (1 - 0.9 ** t) if self.ema_zero_debias else 1.0
 
     @staticmethod
     def _adam_lr_t(t, lr=0.001, b1=0.9, b2=0.999):
@@ -536,7 +552,7 @@ class base_model(object):
         if self.momentum != 0 and self.device.type == 'cuda':
             # the loss of this step is evaluated on the PRE-update variables: Adam's pass over the regularised variables leaves
             # the partial sums of their squares (reg * sum l2_loss, :262-266), and one launch finishes the bookkeeping --
-            # loss, tf.train.ExponentialMovingAverage(0.9) over it (zero-initialised shadow, zero-debiased on read, :269-275)
+            # loss, tf.train.ExponentialMovingAverage(0.9) over it (zero-initialised shadow; read as is or zero-debiased: ema_zero_debias, :269-275)
             nparts = self._apply_adam(grad_scale, lr_t, want_sq=True)
             corr = ema_correction if isinstance(ema_correction, torch.Tensor) and ema_correction.is_cuda else float(ema_correction)
             if isinstance(corr, torch.Tensor) and corr.dim() == 0:
@@ -560,7 +576,7 @@ class base_model(object):
         """Run ``train_step`` as ONE captured HIP graph (``torch.cuda.CUDAGraph`` on ROCm = hipGraph): the first two
         calls run eagerly (library initialisation), the third captures -- forward, loss, backward, Adam and the loss
         bookkeeping, the second stream of ``contract_bwd_w`` included -- and every later call copies the batch into
-        the graph's input buffers, writes this step's two scalars (Adam's lr_t, the EMA's debiasing factor) and
+        the graph's input buffers, writes this step's two scalars (Adam's lr_t, the EMA's read factor) and
         replays.  Same kernels, same arithmetic, same results as the eager step; the batch shape must stay fixed.
         Under ``dist.DataParallel`` on RCCL the gradient all-reduces are captured with the step (they are enqueued on
         streams like kernels, forked from and joined to the capture stream) and replayed with it; on other backends
@@ -590,7 +606,7 @@ class base_model(object):
             if self._sg_warm < 2:
                 self._sg_warm += 1
                 t = self.global_step + 1
-                loss_average = self._step_body(self.as_internal(x_storage), labels, self._adam_lr_t(t), 1.0 / (1 - 0.9 ** t))
+                loss_average = self._step_body(self.as_internal(x_storage), labels, self._adam_lr_t(t), self._ema_read(t))
                 self.global_step += 1
                 return self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum), loss_average
             self._drop_step_graph()
@@ -600,7 +616,7 @@ class base_model(object):
         sg['labels'].copy_(labels)
         t = self.global_step + 1
         sg['lr_t'].fill_(self._adam_lr_t(t))
-        sg['ema_c'].fill_(1.0 / (1 - 0.9 ** t))
+        sg['ema_c'].fill_(self._ema_read(t))
         sg['graph'].replay()
         reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
         self.global_step += 1
@@ -784,7 +800,11 @@ class base_model(object):
         if self._specs is not None:                     # build pass: record and hand out a meta tensor
             if any(s.name == name for s in self._specs):
                 raise ValueError('variable %s already exists' % name)
-            self._specs.append(_Spec(name, shape, kind, regularization, fan_in, group, ref_shape or shape, vaxis))
+            vkey = None
+            if vaxis is not None:
+                scope0 = self._scope[0] if self._scope else ''
+                vkey = int(scope0[4:]) - 1 if (group != 'head' and scope0.startswith('conv') and scope0[4:].isdigit()) else 'head'
+            self._specs.append(_Spec(name, shape, kind, regularization, fan_in, group, ref_shape or shape, vaxis, vkey))
             return torch.empty(tuple(shape), device='meta')
         p = self._params[name]
         if tuple(p.shape) != tuple(shape):
@@ -862,37 +882,67 @@ class cgcnn(base_model):
         self.initial = initial
         self.channel = channel
         self._M0 = int(M_0)
-        # Internal vertex order.  The network does not depend on how the vertices are numbered as long as everything
-        # per-vertex follows: with no pooling (one graph for every layer -- what model.py:272 builds) the model relabels
-        # the vertices by descending number of neighbours (graph.length_order), for which the library has faster recurrence
-        # kernels (csrc/recurrence_ord.hip); activations, per-vertex biases and the rows of the first FC layer live in that
-        # order, the accessors (variable / set_variable / gradient / state_dict) and the input staging translate.
-        # 'reference' (or CHEBGCN_VERTEX_ORDER=reference) keeps the caller's numbering; pooling needs the tree order of
-        # coarsening.compute_perm and always does.
+        # Internal vertex order.  The network does not depend on how the vertices of a level are numbered as long as everything
+        # per-vertex follows: the model relabels the vertices of every graph level that is large enough by descending number
+        # of neighbours (graph.length_order), for which the library has faster recurrence kernels (csrc/recurrence_ord*.hip,
+        # 2049 ... 20476 active vertices); activations, per-vertex biases and the rows of the first FC layer live in the order of
+        # THEIR level, the accessors (variable / set_variable / gradient / state_dict) and the input staging translate.
+        # Pooling (models_gcn.py:631-648: p consecutive vertices of the coarsening's tree order) between two levels of which
+        # either is relabelled runs through index maps (ops.pool_maps, chebgcn_pool_gather_fwd / _scatter_bwd) instead of
+        # through adjacency in memory.  'reference' (or CHEBGCN_VERTEX_ORDER=reference) keeps the caller's numbering everywhere.
         self.vertex_order = os.environ.get('CHEBGCN_VERTEX_ORDER', 'length')
         self.graphs = []
+        self._orders = [None] * len(self.L)             # per conv layer: internal position -> reference vertex of its level
+        self._pool_maps = [None] * len(self.L)
+        self._relabelled = False
         if self.device.type == 'cuda':
-            order = None
             force = self.vertex_order == 'length!'          # experiments: relabel even where no kernel gains from it
             if force:
                 self.vertex_order = 'length'
-            if (self.vertex_order == 'length' and all(pp == 1 for pp in p) and all(Li is self.L[0] for Li in self.L)
-                    and self._fusable()):
-                order = graph_mod.length_order(self.L[0])
-                g = ops.Graph(self.L[0], self.device, order=order)
+            levels = {}                                     # id(Laplacian) -> (order or None, device graph)
+            for Li in self.L:
+                if id(Li) in levels:
+                    continue
+                order = g = None
                 # Who gains from sorted rows: the ordered recurrence kernels (big graphs).  The on-chip layer of atlas-sized
                 # graphs (csrc/fused_small.hip) would gain 3 % (its waves then gather rows of equal length; captured step at
                 # N = 360 0.943 -> 0.911 ms) -- not taken: in the coarsening's tree order spatial neighbours are adjacent and
                 # the weight gradients' long cancelling sums over the vertices come out within 2e-7 of float64; in degree
                 # order they carry plain fp32 summation noise (1e-4 of their scale, like NumPy's fp32).
-                if g.ordered or force:
-                    self.graphs = [g] * len(self.L)
-                else:
-                    order = None                        # no ordered kernel for this graph size: nothing to gain
-            if order is None:
+                if self.vertex_order == 'length' and self._fusable() and (Li.shape[0] > 2048 or force):
+                    order = graph_mod.length_order(Li)
+                    g = ops.Graph(Li, self.device, order=order)
+                    if not (g.ordered or force):
+                        order = g = None                    # no ordered kernel for this graph size: nothing to gain
+                if g is None:
+                    g = ops.graph_for(Li, self.device)
+                levels[id(Li)] = (order, g)
+            self.graphs = [levels[id(Li)][1] for Li in self.L]
+            self._orders = [levels[id(Li)][0] for Li in self.L]
+            self._relabelled = any(o is not None for o in self._orders)
+            if not self._relabelled:
                 self.vertex_order = 'reference'
-                self.graphs = [ops.graph_for(Li, self.device) for Li in self.L]
-            else:
+            dev = self.device
+
+            def table(order):
+                inv = np.empty_like(order)
+                inv[order] = np.arange(len(order))
+                return {'order': torch.as_tensor(order).to(dev), 'inv': torch.as_tensor(inv).to(dev)}
+            for i, o in enumerate(self._orders):
+                if o is not None:
+                    self._vtabs[i] = table(o)
+            nl = len(self.p)
+            for i in range(nl):
+                if self.p[i] > 1:
+                    src = self._orders[i]
+                    dst = self._orders[i + 1] if i + 1 < nl else None      # the head reads the last pooled level in the reference's order
+                    if src is not None or dst is not None:
+                        self._pool_maps[i] = ops.pool_maps(int(self.p[i]), src, dst, self.L[i].shape[0], dev)
+            # the order the LAST conv layer's output is in: what the first FC layer's rows follow
+            if self.p[-1] == 1 and self._orders[-1] is not None:
+                self._vtabs['head'] = self._vtabs[nl - 1]
+            if self._orders[0] is not None:                 # the input level: staging and batches (InternalPlanes)
+                order = self._orders[0]
                 Mp = plane_stride(self._M0)
                 inv = np.empty_like(order)
                 inv[order] = np.arange(len(order))
@@ -908,6 +958,22 @@ class cgcnn(base_model):
                           regularization=regularization, dropout=dropout, batch_size=batch_size,
                           eval_frequency=eval_frequency, dir_name=dir_name)
         self.build_graph((M_0, channel))
+
+    @property
+    def contraction(self):
+        return self._contraction
+
+    @contraction.setter
+    def contraction(self, value):
+        # (a typo in CHEBGCN_CONTRACTION used to surface as a KeyError deep inside the first backward pass)
+        if value != 'auto' and value not in ops.PRECISIONS:
+            raise ValueError("contraction must be 'auto' or one of %s, got %r" % (sorted(ops.PRECISIONS), value))
+        self._contraction = value
+
+    def layer_precisions(self):
+        """The arithmetic each conv layer's contraction (and its two gradients) resolves to under ``contraction``."""
+        fins = [self.channel] + list(self.F[:-1])
+        return [ops.resolve_precision(self.contraction, fi, k, fo) for fi, k, fo in zip(fins, self.K, self.F)]
 
     def _architecture(self):
         """What a checkpoint needs to rebuild this model without the script that made it (the
@@ -967,7 +1033,7 @@ class cgcnn(base_model):
 
     def _graph_of(self, L):
         """Device graph for a layer called on its own (logical tensors in the caller's vertex order)."""
-        if self._order is None:
+        if not self._relabelled:
             for Li, g in zip(self.L, self.graphs):
                 if Li is L:
                     return g
@@ -1061,7 +1127,7 @@ class cgcnn(base_model):
         recurrence + (contraction, bias, ReLU, pooling) and writes straight into slab 0 of
         the next layer's Chebyshev stack."""
         if not self._fusable():
-            if self._order is not None:
+            if self._relabelled:
                 raise RuntimeError('this model keeps its per-vertex variables in a relabelled vertex order (vertex_order = '
                                    "'length'), which the layer-by-layer path does not know: construct it with "
                                    "CHEBGCN_VERTEX_ORDER=reference to replace filter / brelu / pool methods")
@@ -1091,7 +1157,7 @@ class cgcnn(base_model):
             x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
                               BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out,
                               dW=W.grad if direct else None, dbias=b.grad if direct else None,
-                              precision=self.contraction, done=done, mean=mean)
+                              precision=self.contraction, done=done, mean=mean, pool_maps=self._pool_maps[i])
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
         if mean:

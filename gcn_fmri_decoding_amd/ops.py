@@ -452,6 +452,7 @@ class ChebConv(torch.autograd.Function):
             ctx.grad_bufs = (bufs.dW, bufs.dbias)
             ctx.done = bufs.done
             ctx.precision = 'f32'
+            ctx.pool_maps = None
             return y[:, :M]                   # the logical [B, M] mean (row stride Mp): its gradient arrives dense
         if out is None:
             out = plane_empty(B, Fout, Mo, x.device)
@@ -460,12 +461,33 @@ class ChebConv(torch.autograd.Function):
             if tuple(out.shape) != (B, Fout, plane_stride(Mo)) or not out.is_contiguous():
                 raise ValueError('out buffer has the wrong shape')
         argmax = None
+        maps = bufs.pool_maps if (bufs is not None and pool > 1) else None
+        wants_grad = _grad_mode(bufs) and any(ctx.needs_input_grad[:3])       # inference: no mask is written
+        if maps is not None:
+            # pooling between two vertex orders: the contraction (bias, ReLU) leaves the unpooled result in the source order,
+            # one more pass gathers the clusters through LDS (csrc/pointwise.hip pool_gather_fwd_kernel)
+            b = bias.detach() if bias is not None else None
+            if b is not None and not b.is_contiguous():
+                b = b.contiguous()
+            y_full = plane_empty(B, Fout, M, x.device)
+            contract_fwd_into(stack, Wc, b, bias_kind, y_full, None, B, M, Fin, K, Fout, 1, pool_kind, relu, precision)
+            sel = torch.empty(out.shape, dtype=torch.uint8, device=x.device) if wants_grad else None
+            _lib.check(_launch('pool_gather_fwd', B * Fout * (4.0 * (M + Mo) + Mo), 0.0, lambda: lib.chebgcn_pool_gather_fwd(
+                _p(y_full), _p(maps[0]), _p(out), _p(sel), B, M, Fout, pool, pool_kind, int(relu), _stream())), 'pool_gather_fwd')
+            ctx.save_for_backward(stack, Wc, None, sel)
+            ctx.fold, ctx.mean, ctx.fused = False, False, False
+            ctx.graph, ctx.cfg = graph, (B, M, Fin, K, Fout, pool, pool_kind, int(relu), bias_kind)
+            ctx.bias_shape = None if bias is None else tuple(bias.shape)
+            ctx.grad_bufs = (bufs.dW, bufs.dbias)
+            ctx.done = bufs.done
+            ctx.precision = precision
+            ctx.pool_maps = maps
+            return out
         if pool > 1 and (pool_kind == POOL_MAX or relu):
             argmax = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
         # pool == 1 with ReLU: contract_fwd leaves a bit per vertex (the ReLU mask) and the gradients of the
         # contraction gate the incoming gradient themselves -- no dy tensor, no pass over `out` in backward
         fold = bool(fold_relu_grad and pool == 1 and relu and precision == 'f32')
-        wants_grad = _grad_mode(bufs) and any(ctx.needs_input_grad[:3])       # inference: no mask is written
         if pool == 1 and relu and wants_grad:
             # the mask also serves the separate ReluGrad pass (bf16 gradients): a byte per four vertices instead of `out`
             argmax = torch.empty((B, Fout, Mp // 4), dtype=torch.uint8, device=x.device)
@@ -480,6 +502,7 @@ class ChebConv(torch.autograd.Function):
         ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
         ctx.done = bufs.done if bufs is not None else None
         ctx.precision = precision
+        ctx.pool_maps = None
         return out
 
     @staticmethod
@@ -516,6 +539,7 @@ class ChebConv(torch.autograd.Function):
         ctx.grad_bufs = (bufs.dW, bufs.dbias) if bufs is not None else (None, None)
         ctx.done = bufs.done if bufs is not None else None
         ctx.precision = 'f32'
+        ctx.pool_maps = None
         return out
 
     @staticmethod
@@ -563,7 +587,7 @@ class ChebConv(torch.autograd.Function):
             gstack = torch.empty((K, B, Fout, g.Mp), dtype=torch.float32, device=dev)
             dy, mask = gstack[0], None
             bws, nbws = _brelu_bwd_ws(B, M, Fout, 1, bias_kind, dev)
-            _lib.check(_launch('brelu_pool_bwd', B * M * (4.0 + Fout * 4.25), 0.0, lambda: lib.chebgcn_relu_grad_mean(
+            _lib.check(_launch('relu_grad_mean', B * M * (4.0 + Fout * 4.25), 0.0, lambda: lib.chebgcn_relu_grad_mean(
                 _p(gout), _p(argmax), _p(dy), _p(dbias), bias_kind, B, M, Fout, _p(bws), nbws, _stream())), 'relu_grad_mean')
             mean = False                                  # from here on an ordinary layer with a materialised dy
         elif fold:
@@ -596,13 +620,21 @@ class ChebConv(torch.autograd.Function):
                 dy, mask = gstack[0], None          # T_0 of the recurrence on dy: written in place
             else:
                 dy, mask = torch.empty((B, Fout, g.Mp), dtype=torch.float32, device=dev), None
-            # with the ReLU mask of a pool == 1 layer `out` is not read (a byte per four vertices instead)
-            nbytes = B * Fout * M * (8.0 + 0.25) if out is None else 4.0 * B * Fout * (2 * Mo + M)
             bk = bias_kind if dbias is not None else BIAS_NONE
-            bws, nbws = _brelu_bwd_ws(B, M, Fout, pool, bk, dev)
-            _lib.check(_launch('brelu_pool_bwd', nbytes, 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
-                _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bk, B, M, Fout,
-                pool, pool_kind, relu, _p(bws), nbws, _stream())), 'brelu_pool_bwd')
+            if ctx.pool_maps is not None:
+                # pooled between two vertex orders: the forward's selection bytes carry the ReLU of the maximum as well
+                nbws = lib.chebgcn_pool_scatter_bwd_workspace(B, M, Fout, pool, bk)
+                bws = torch.empty(nbws, dtype=torch.uint8, device=dev) if nbws else None
+                _lib.check(_launch('pool_scatter_bwd', B * Fout * (4.0 * M + 5.0 * Mo), 0.0, lambda: lib.chebgcn_pool_scatter_bwd(
+                    _p(gout), _p(argmax), _p(ctx.pool_maps[1]), _p(dy), _p(dbias), bk, B, M, Fout, pool, pool_kind, relu,
+                    _p(bws), nbws, _stream())), 'pool_scatter_bwd')
+            else:
+                # with the ReLU mask of a pool == 1 layer `out` is not read (a byte per four vertices instead)
+                nbytes = B * Fout * M * (8.0 + 0.25) if out is None else 4.0 * B * Fout * (2 * Mo + M)
+                bws, nbws = _brelu_bwd_ws(B, M, Fout, pool, bk, dev)
+                _lib.check(_launch('brelu_pool_bwd', nbytes, 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
+                    _p(gout), _p(out), _p(argmax), _p(dy), _p(dbias), bk, B, M, Fout,
+                    pool, pool_kind, relu, _p(bws), nbws, _stream())), 'brelu_pool_bwd')
         dW = None
         if ctx.needs_input_grad[1]:
             passes = PRECISIONS[ctx.precision]
@@ -660,7 +692,7 @@ class ChebConv(torch.autograd.Function):
                                lambda: lib.chebgcn_fused_layer_bwd_x(g.handle, _p(dy), _p(mask), _p(Wc), _p(dx), B, Fin, K, Fout,
                                                                      _stream())), 'fused_layer_bwd_x')
         elif by_fwd:
-            _lib.check(_launch('recurrence_bwd', 4.0 * B * M * Fout * K, 0.0, lambda: lib.chebgcn_recurrence_fwd_t(
+            _lib.check(_launch('recurrence_fwd_t', 4.0 * B * M * Fout * K, 0.0, lambda: lib.chebgcn_recurrence_fwd_t(
                 g.handle, _p(dy), _p(gstack), B, Fout, K, _stream())), 'recurrence_fwd_t')
             Wt = torch.empty((Fout * K, Fin), dtype=torch.float32, device=dev)                 # W'[fo*K + k][fin] = W[fin*K + k][fo]
             _lib.check(lib.chebgcn_reindex_weights(_p(Wc), _p(Wt), Fin, K, Fout, _stream()), 'reindex_weights')
@@ -718,10 +750,13 @@ class Buffers:
     kernels are enqueued (dist.DataParallel starts the layer's all-reduce from it).  ``mean``: the
     layer is followed by ``tf.reduce_mean(x, -1)`` (models_gcn.py:673) and returns that mean, storage
     [B, Mp], instead of its output (chebgcn_contract_fwd_mean; the gradients read one plane per window)."""
-    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean', 'grad_mode')
+    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean', 'grad_mode', 'pool_maps')
 
-    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False):
+    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None):
         self.stack, self.out, self.dW, self.dbias, self.precision, self.done = stack, out, dW, dbias, precision, done
+        # a pooled layer whose input and / or output vertices are not in the coarsening's tree order: (pmap, smap), int32 device
+        # tensors of M entries each (``pool_maps``); the layer then pools through them (chebgcn_pool_gather_fwd / _scatter_bwd)
+        self.pool_maps = pool_maps
         self.mean = mean          # the layer returns the mean over its filters, [B, Mp] (see conv_mean_supported)
         # the caller's grad mode: inside Function.forward grad mode is always off, and ``ctx.needs_input_grad`` is True for a
         # Parameter even under torch.no_grad() -- with this off nothing that only a backward pass would read is written
@@ -730,19 +765,40 @@ class Buffers:
 
 
 def conv_mean_supported(B, M, Fin, K, Fout, pool, relu, precision='f32'):
-    precision = resolve_precision(precision, Fin, K, Fout)
     """Can ``cheb_conv(..., mean=True)`` serve this layer?  (pool 1, ReLU, fp32 contraction, a shape of the ring kernel.)"""
+    precision = resolve_precision(precision, Fin, K, Fout)
     return bool(fold_relu_grad and pool == 1 and relu and precision == 'f32'
                 and _lib.lib().chebgcn_contract_fwd_mean_supported(B, M, Fin, K, Fout))
 
 
+def pool_maps(pool, src_order, dst_order, M, device):
+    """Index maps of a pooled layer between two vertex orders (include/chebgcn.h, chebgcn_pool_gather_fwd): the reference pools
+    the consecutive vertices ``pool*j .. pool*j + pool - 1`` of its (tree) order into vertex ``j`` (models_gcn.py:631-648).
+    ``src_order[v']`` = reference vertex at position ``v'`` of the source level's internal order (None: identity), ``dst_order``
+    likewise for the pooled level.  Returns (pmap, smap) int32 device tensors:
+    ``pmap[j'*pool + i]`` = source position of member i of pooled position j'; ``smap[v']`` = ``j'*pool + i``."""
+    M = int(M)
+    Mo = M // pool
+    src = np.arange(M, dtype=np.int64) if src_order is None else np.asarray(src_order, np.int64)
+    dst = np.arange(Mo, dtype=np.int64) if dst_order is None else np.asarray(dst_order, np.int64)
+    if src.shape != (M,) or dst.shape != (Mo,):
+        raise ValueError('pool_maps: orders of %d / %d vertices expected' % (M, Mo))
+    inv_src = np.empty(M, np.int64)
+    inv_src[src] = np.arange(M)
+    pmap = inv_src[(pool * dst[:, None] + np.arange(pool)[None, :]).reshape(-1)]
+    smap = np.empty(M, np.int64)
+    smap[pmap] = np.arange(M)
+    dev = torch.device(device)
+    return (torch.as_tensor(pmap.astype(np.int32)).to(dev), torch.as_tensor(smap.astype(np.int32)).to(dev))
+
+
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
-              dW=None, dbias=None, precision='f32', done=None, mean=False):
+              dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None):
     """``precision``: arithmetic of the contraction and of its two gradients ('auto': resolve_precision; 'f32', 'bf16', 'bf16x3':
     chebgcn_contract_fwd_bf16 / _bwd_x_bf16 / _bwd_w_bf16 with 1 or 3 passes); storage, the recurrence, its adjoint
     and the bias / ReLU / pooling gradients stay fp32."""
     precision = resolve_precision(precision, x.shape[1], K, W.shape[1])
-    bufs = Buffers(stack, out, dW, dbias, precision, done, mean)
+    bufs = Buffers(stack, out, dW, dbias, precision, done, mean, pool_maps if pool > 1 else None)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 

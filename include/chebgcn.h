@@ -199,15 +199,39 @@ int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bias_kind, flo
  * forward; dy: [B][F][Mp(M)] receives d(loss)/d(pre-bias activation); dbias: [F] or
  * [F][Mp(M)] (overwritten) or NULL.  pool == 1 with relu: a non-NULL argmax is the ReLU mask of
  * contract_fwd and replaces `out` (which may then be NULL).  dy == NULL: only dbias is computed.
- * workspace: device scratch of at least chebgcn_brelu_pool_bwd_workspace() bytes -- 0 (NULL allowed)
- * unless bias_kind is CHEBGCN_BIAS_FILTER: the per-filter sum of b1relu (models_gcn.py:619-623) is a
- * two-stage reduction in a fixed order (per-workgroup partials, then one wave per filter), so every
- * gradient this library returns is bit-reproducible from run to run. */
+ * workspace: device scratch of at least chebgcn_brelu_pool_bwd_workspace() bytes.  bias_kind CHEBGCN_BIAS_FILTER needs
+ * it: the per-filter sum of b1relu (models_gcn.py:619-623) is a two-stage reduction in a fixed order (per-workgroup
+ * partials, then one wave per filter), so every gradient this library returns is bit-reproducible from run to run.  A
+ * pooled layer (pool > 1) WITH the workspace runs the 16-byte-store kernel of chebgcn_pool_scatter_bwd (its bias sums
+ * are per-batch-part partials added in part order); without it (NULL allowed for the other bias kinds) a scalar kernel. */
 size_t chebgcn_brelu_pool_bwd_workspace(int B, int M, int F, int pool, int bias_kind);
 int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const uint8_t* argmax,
                            float* dy, float* dbias, int bias_kind, int B, int M, int F,
                            int pool, int pool_kind, int relu, void* workspace, size_t workspace_bytes,
                            chebgcn_stream stream);
+
+/* ---- pooling between two vertex orders (mpool1 / apool1, models_gcn.py:631-648, under a relabelling) ----
+ * The reference pools `pool` CONSECUTIVE vertices of the tree order coarsening.compute_perm builds (coarsening.py:168-215).
+ * A caller that keeps the vertices of a level in another order -- cgcnn relabels each level by descending row length so that
+ * the ordered recurrence kernels serve it (HCP_task_fmri_gcn_test8.py:1632-1635: the six-level pooling network) -- pools
+ * through index maps instead of through adjacency in memory:
+ *   chebgcn_pool_gather_fwd: y [B][F][Mp(M)] (bias and ReLU already applied: chebgcn_contract_fwd with pool = 1) ->
+ *       out[b][f][j] = max_i / mean_i  y[b][f][ pmap[j*pool + i] ],  j < M/pool, [B][F][Mp(M/pool)] (padding zeroed).
+ *       pmap: int32 [M] on the device, positions in the source order, the members of a cluster listed in the reference's
+ *       order (ties resolve alike); NULL = the identity (the tree order itself).  sel [B][F][Mp(M/pool)] (optional, for the
+ *       gradient): max -- the winning member, 0xFF where `relu` says y was rectified and the maximum is not positive;
+ *       average -- bit i set where member i was positive (pool <= 8).
+ *   chebgcn_pool_scatter_bwd: dy[b][f][v] = gradient of source vertex v (MaxPoolGrad / AvgPoolGrad + ReluGrad) from
+ *       dout [B][F][Mp(M/pool)] and sel; smap: int32 [M], smap[v] = j*pool + i (v is member i of pooled vertex j), NULL =
+ *       the identity; dbias as chebgcn_brelu_pool_bwd (fixed-order sums: per-batch-part partials in `workspace`, at least
+ *       chebgcn_pool_scatter_bwd_workspace() bytes, added in part order).  16-byte stores of dy; the pooled plane is staged
+ *       in LDS, so planes of more than 10240 pooled vertices are refused (CHEBGCN_EINVAL). */
+int chebgcn_pool_gather_fwd(const float* y, const int32_t* pmap, float* out, uint8_t* sel, int B, int M, int F,
+                            int pool, int pool_kind, int relu, chebgcn_stream stream);
+size_t chebgcn_pool_scatter_bwd_workspace(int B, int M, int F, int pool, int bias_kind);
+int chebgcn_pool_scatter_bwd(const float* dout, const uint8_t* sel, const int32_t* smap, float* dy, float* dbias,
+                             int bias_kind, int B, int M, int F, int pool, int pool_kind, int relu, void* workspace,
+                             size_t workspace_bytes, chebgcn_stream stream);
 
 /* ---- gradients of the contraction (MatMul grads) ---------------------------------
  * dW[fin*K+k][o] = sum_{b,m} stack[k][b][fin][m] * dy[b][o][m]      (overwritten)

@@ -11,8 +11,11 @@ NumPy restatement of ``base_model.predict`` (lib_new/models_gcn.py:31-71), ``eva
 * ``fit``: ``int(num_epochs * S / batch_size)`` steps (:131); every sample is used before one
   is used a second time -- a deque refilled with ``np.random.permutation(S)`` from the GLOBAL
   NumPy RNG whenever fewer than ``batch_size`` indices are left (:137-140); one TF-form Adam
-  step per batch (:146, :296); reported ``loss_average`` = zero-debiased 0.9-EMA of the
-  pre-update loss (:269-275); every ``eval_frequency`` steps and at the last step the
+  step per batch (:146, :296); reported ``loss_average`` = 0.9-EMA of the pre-update loss with a
+  zero-initialised shadow (:269-275).  ASSUMPTION (TensorFlow is absent):
+  ``tf.train.ExponentialMovingAverage(0.9)`` without ``zero_debias`` on TF >= 1.0 reports the shadow
+  as is (first value 0.1 * loss) -- ``zero_debias=False``, the default here; TF 0.12 debiased averages
+  of tensors (shadow / (1 - 0.9^t)) -- ``zero_debias=True``; every ``eval_frequency`` steps and at the last step the
   validation set is scored with ``predict`` (:153-158).
 * dropout: ``keep_prob`` is fed (:145); the oracle supports keep_prob == 1 only (TF's dropout
   RNG stream cannot be reproduced).
@@ -55,7 +58,7 @@ def accuracy(predictions, labels):
     return 100.0 * float(np.mean(np.asarray(predictions) == np.asarray(labels)))
 
 
-def fit(net, params, train_data, train_labels, val_data, val_labels, num_epochs, batch_size, eval_frequency):
+def fit(net, params, train_data, train_labels, val_data, val_labels, num_epochs, batch_size, eval_frequency, zero_debias=False):
     """models_gcn.py:112-184 with dropout keep_prob = 1.  ``params`` is updated in place.
     Consumes ``np.random`` exactly like the reference (one permutation per refill)."""
     n = train_data.shape[0]
@@ -74,8 +77,8 @@ def fit(net, params, train_data, train_labels, val_data, val_labels, num_epochs,
         loss, dlogits = net.loss(params, logits, y)
         grads = net.backward(params, cache, dlogits)
         R.adam_tf_step(params, grads, state)
-        shadow = 0.9 * shadow + 0.1 * loss                       # ExponentialMovingAverage(0.9), zero-debiased
-        log['loss_average'].append(shadow / (1 - 0.9 ** step))
+        shadow = 0.9 * shadow + 0.1 * loss                       # ExponentialMovingAverage(0.9), zero-initialised shadow
+        log['loss_average'].append(shadow / (1 - 0.9 ** step) if zero_debias else shadow)
         if step % eval_frequency == 0 or step == num_steps:
             pred, vloss = predict(net, params, val_data, val_labels, batch_size)
             log['eval_steps'].append(step)

@@ -587,7 +587,7 @@ def test_train_step_vs_oracle(ops, dev, name):
                 ref = grads[k] - (reg * params[k] if onet.regularized(k) else 0)
                 got = net_grad_in_ref_shape(net, k)
                 close(got, ref, rel=5e-5, what='grad ' + k)
-            assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
+            assert abs(float(loss_avg) - 0.1 * loss) <= 2e-5 * abs(0.1 * loss)      # (first read of the zero-initialised 0.9-EMA)
         R.adam_tf_step(params, grads, state)
         for k in params:
             assert_adam_params_close(net.get_var(k), params[k], state['v/' + k], step, ill, k, rel=2e-5 if step == 0 else 1e-4, quantile=1.0 if step == 0 else 0.999)

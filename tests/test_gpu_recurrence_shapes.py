@@ -37,6 +37,10 @@ SHAPES = [
     ((9000, 1), ('cheb_ord_kernel', 10240, 5, 5)),
     ((10000, 0), ('cheb_ord_kernel', 10240, 5, 5)),         # the benchmark's points without a coarsening level
     ((10000, 1), ('cheb_ord_kernel', 10240, 6, 5)),         # the benchmark graph
+    # six coarsening levels (the pooling network of HCP_task_fmri_gcn_test8.py:1632-1635): 2672 fake vertices behind the 10000 real
+    # ones = more than one quad level of isolated vertices: the kernel's NQ stops at NG + 1, cheb_ord_tail_kernel streams the rest
+    ((10000, 6), ('cheb_ord_kernel', 10240, 6, 5)),
+    ((5000, 6), ('cheb_ord_kernel', 6160, 4, 3)),
     # 2560 quads of rows are two entries too many for 16-byte entries; up to 10752 vertices the two-plane kernel of recurrence.hip
     # on the CALLER's order is the faster one (recurrence_ord.hip ordered_shape): no ordered image, that kernel by name
     ((10239, 0), ('cheb_onchip_kernel', 2, 14, 4)),
@@ -87,6 +91,11 @@ def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
     nt = 512 if ordered else 768
     name_f = '%s<%d,%d,%d,%d,false>' % (family, ENT, NQ, NG, nt)
     name_a = '%s<%d,%d,%d,%d,true>' % (family, ENT, NQ, NG, nt)
+    if ordered and Mp > 4 * 512 * NQ:             # vertices behind the kernel's quad levels: the streamed tail
+        assert g.query(17) == 4 * 512 * NQ
+        name_f, name_a = name_f + ' + cheb_ord_tail_kernel<false>', name_a + ' + cheb_ord_tail_kernel<true>'
+    elif ordered:
+        assert g.query(17) == 0
     # more plane groups than the launch has workgroups (256 CUs x at most 2 workgroups), partial last group
     B, Fin = 7, 301 if PL == 4 else 151
     nplanes = B * Fin
@@ -156,6 +165,8 @@ def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
 # isolated vertices (5 random neighbours per vertex, symmetrised: rows of 5 ... ~16 entries, so the record classes of 8 / 10 / 12
 # and more entries all occur; Gaussian weights).  (Two planes, NG = 5, NQ = 5 cannot occur: two planes are used from 10753 vertices.)
 ORD_TABLE = [(4, ng, nq) for ng in (2, 3, 4, 5) for nq in (ng, ng + 1)] + [(2, 5, 6)] + [(2, ng, nq) for ng in range(6, 11) for nq in (ng, ng + 1)]
+# nq = ng + 2 / ng + 3: more isolated vertices than one quad level -- the NQ = NG + 1 kernel + cheb_ord_tail_kernel
+ORD_TABLE += [(4, 2, 4), (4, 5, 7), (2, 6, 8), (4, 3, 6)]
 
 
 def _random_graph(n_active, n_iso, seed):
@@ -179,7 +190,7 @@ def test_ordered_shape_table(dev, pl, ng, nq):
     from oracle import graph_ref as GR
     lib = _lib.lib()
     n_active = 2048 * (ng - 1) + 1000 if not (pl == 2 and ng == 5) else 10240
-    M = n_active + 4 if nq == ng else (2048 * ng + 40 if not (pl == 2 and ng == 5) else 10800)
+    M = n_active + 4 if nq == ng else (2048 * (nq - 1) + 40 if not (pl == 2 and ng == 5) else 10800)
     L0 = _random_graph(n_active, M - n_active, 100 * pl + 10 * ng + nq)
     order = graph.length_order(L0)
     g = ops.Graph(L0, dev, order=order)
@@ -187,7 +198,9 @@ def test_ordered_shape_table(dev, pl, ng, nq):
     L = graph.permute(L0, order)
     Mp = g.Mp
     ent = min(2048 * ng + 16, 160 * 1024 // (4 * pl))
-    stem = '%s<%d,%d,%d,512,' % ('cheb_ord_kernel' if pl == 4 else 'cheb_ord2_kernel', ent, nq, ng)
+    stem = '%s<%d,%d,%d,512,' % ('cheb_ord_kernel' if pl == 4 else 'cheb_ord2_kernel', ent, min(nq, ng + 1), ng)
+    tail_f, tail_a = (' + cheb_ord_tail_kernel<false>', ' + cheb_ord_tail_kernel<true>') if nq > ng + 1 else ('', '')
+    assert g.query(17) == (2048 * (ng + 1) if nq > ng + 1 else 0)
     B, Fin, K = 7, 301 if pl == 4 else 151, 4
     nplanes = B * Fin
     gen = torch.Generator(device=dev)
@@ -198,7 +211,7 @@ def test_ordered_shape_table(dev, pl, ng, nq):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     stack = torch.full((K, B, Fin, Mp), float('nan'), device=dev)
     _lib.check(lib.chebgcn_recurrence_fwd(g.handle, P(x), P(stack), B, Fin, K, st), 'fwd')
-    assert _lib.last_dispatch() == stem + 'false>', _lib.last_dispatch()
+    assert _lib.last_dispatch() == stem + 'false>' + tail_f, _lib.last_dispatch()
     L64 = GR.rescale_L(L, 2).astype(np.float64).tocsr()
     Ld = _sparse64(L64, dev)
     X = x[:, :, :M].double().reshape(nplanes, M).t().contiguous()
@@ -216,7 +229,7 @@ def test_ordered_shape_table(dev, pl, ng, nq):
     G[:, :, :, M:] = float('nan')
     dx = torch.full((B, Fin, Mp), float('nan'), device=dev)
     _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, st), 'bwd')
-    assert _lib.last_dispatch() == stem + 'true>', _lib.last_dispatch()
+    assert _lib.last_dispatch() == stem + 'true>' + tail_a, _lib.last_dispatch()
     LTd = _sparse64(L64.T.tocsr(), dev)
     Gk = lambda k: G[k, :, :, :M].double().reshape(nplanes, M).t().contiguous()
     c2, c1 = torch.zeros_like(Gk(0)), Gk(K - 1)

@@ -177,7 +177,7 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
     assert np.abs(got - logits64).max() <= 1e-5 * np.abs(logits64).max()       # the north star's 1e-5, against float64
     ld = torch.as_tensor(labels).to(dev)
     _, loss_avg = net.train_step(xs, ld)
-    assert abs(float(loss_avg) - loss) <= 2e-5 * abs(loss)
+    assert abs(float(loss_avg) - 0.1 * loss) <= 2e-5 * abs(0.1 * loss)      # (first read of the zero-initialised 0.9-EMA)
     measured = {}
     for k in params:
         spec = next(s for s in net._spec_list if s.name == k)

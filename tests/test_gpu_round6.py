@@ -1,0 +1,240 @@
+"""Round 6: pooling between two vertex orders and the pooling network on relabelled levels.  Needs an MI355X: ``-m gpu``.
+
+Reference semantics: ``mpool1`` / ``apool1`` (lib_new/models_gcn.py:631-648) pool ``p`` CONSECUTIVE vertices of the tree order
+``coarsening.compute_perm`` builds (lib_new/coarsening.py:168-215).  ``cgcnn`` keeps every level that an ordered recurrence
+kernel serves in descending-row-length order, so a pooled layer there pools through index maps
+(``ops.pool_maps`` -> ``chebgcn_pool_gather_fwd`` / ``chebgcn_pool_scatter_bwd``): bit-exact against a NumPy restatement of the
+reference's pooling composed with the two permutations.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import csr_from, load_golden, record_measured
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def _P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pool_ref(y_ref, p, kind, relu):
+    """Reference pooling on [B, F, M] in the REFERENCE order: (out, grad-selector [B, F, M]) -- the selector is d(out_j)/d(y_v)
+    for v in cluster j (first maximum wins; zero where ``relu`` and the maximum is not positive / the member was not positive)."""
+    B, F, M = y_ref.shape
+    c = y_ref.reshape(B, F, M // p, p)
+    if kind == 0:
+        out = c.max(axis=3)
+        arg = c.argmax(axis=3)                               # first maximum
+        sel = np.zeros_like(c)
+        np.put_along_axis(sel, arg[..., None], 1.0, axis=3)
+        if relu:
+            sel *= (out > 0)[..., None]
+    else:
+        out = c[..., 0].copy()
+        for i in range(1, p):                                # members added in order, like the kernels (and TF's AvgPool window)
+            out = out + c[..., i]
+        out = out * np.float32(1.0 / p)
+        sel = np.full_like(c, 1.0 / p)
+        if relu:
+            sel *= (c > 0)
+    return out.astype(np.float32), sel.reshape(B, F, M).astype(np.float32)
+
+
+@pytest.mark.parametrize('M,p,F,B', [(12672, 4, 8, 5), (3168, 4, 16, 7), (792, 2, 5, 3), (20480, 8, 3, 2), (40, 4, 3, 9)])
+@pytest.mark.parametrize('kind', [0, 1])
+@pytest.mark.parametrize('bias_kind', [0, 1, 2])
+@pytest.mark.parametrize('mapped', [True, False])
+def test_pool_gather_scatter_vs_numpy(dev, M, p, F, B, kind, bias_kind, mapped):
+    """chebgcn_pool_gather_fwd / chebgcn_pool_scatter_bwd against NumPy: random source and pooled orders (or the identity),
+    max and average pooling, the three bias kinds; pads poisoned.  Outputs and dy bit-exact (selection, no arithmetic but the
+    1/p of the average); bias sums to fp32 round-off (another, fixed, order)."""
+    from gcn_fmri_decoding_amd import _lib, ops
+    lib = _lib.lib()
+    if bias_kind and (M, kind) not in ((12672, 0), (3168, 0), (792, 1), (40, 0), (40, 1)) and not mapped:
+        pytest.skip('bias kinds on a subset of the unmapped shapes')
+    rs = np.random.RandomState(M + 7 * p + kind)
+    Mo, Mp, Mpo = M // p, ops.plane_stride(M), ops.plane_stride(M // p)
+    src = rs.permutation(M) if mapped else None
+    dst = rs.permutation(Mo) if mapped else None
+    relu = 1
+    y_ref = rs.randn(B, F, M).astype(np.float32)
+    y_ref = np.maximum(y_ref, 0)                             # what contract_fwd(pool = 1, relu) leaves
+    y_ref[0, 0, :2 * p] = 0                                  # whole clusters at zero: no gradient through the ReLU
+    if M >= 16:
+        y_ref[0, 0, 4 * p:4 * p + p] = 1.5                   # a tie: the first member (in the reference's order) wins
+    y_int = y_ref[:, :, src] if mapped else y_ref
+    y = torch.full((B, F, Mp), float('nan'), device=dev)
+    y[:, :, :M] = torch.as_tensor(y_int).to(dev)
+    pmap = smap = None
+    if mapped:
+        pmap, smap = ops.pool_maps(p, src, dst, M, dev)
+        # the maps against their definition
+        pm, sm = pmap.cpu().numpy(), smap.cpu().numpy()
+        inv_src = np.argsort(src)
+        assert np.array_equal(pm.reshape(Mo, p), inv_src[p * dst[:, None] + np.arange(p)[None, :]])
+        assert np.array_equal(sm[pm], np.arange(M))
+    out = torch.full((B, F, Mpo), float('nan'), device=dev)
+    sel = torch.zeros((B, F, Mpo), dtype=torch.uint8, device=dev)
+    _lib.check(lib.chebgcn_pool_gather_fwd(_P(y), _P(pmap), _P(out), _P(sel), B, M, F, p, kind, relu, _stream()), 'pool_gather_fwd')
+    assert _lib.last_dispatch() == ('pool_gather_fwd_kernel<map>' if mapped else 'pool_gather_fwd_kernel')
+    o_ref, s_ref = _pool_ref(y_ref, p, kind, relu)
+    o_int = o_ref[:, :, dst] if mapped else o_ref
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :, :Mo], o_int), 'pooled output differs'
+    assert np.all(got[:, :, Mo:] == 0)                       # the padding of the pooled planes is zeroed
+    # backward
+    do_ref = rs.randn(B, F, Mo).astype(np.float32)
+    dout = torch.full((B, F, Mpo), float('nan'), device=dev)
+    dout[:, :, :Mo] = torch.as_tensor(do_ref[:, :, dst] if mapped else do_ref).to(dev)
+    dy = torch.full((B, F, Mp), float('nan'), device=dev)
+    dbias = None if bias_kind == 0 else torch.full((F,) if bias_kind == 1 else (F, Mp), float('nan'), device=dev)
+    nws = lib.chebgcn_pool_scatter_bwd_workspace(B, M, F, p, bias_kind)
+    assert (nws > 0) == (bias_kind != 0)
+    ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=dev)
+    _lib.check(lib.chebgcn_pool_scatter_bwd(_P(dout), _P(sel), _P(smap), _P(dy), _P(dbias), bias_kind, B, M, F, p, kind, relu, _P(ws),
+                                            nws, _stream()), 'pool_scatter_bwd')
+    kname = ['CHEBGCN_BIAS_NONE', 'CHEBGCN_BIAS_FILTER', 'CHEBGCN_BIAS_VERTEX'][bias_kind]
+    want = 'pool_scatter_bwd_kernel<%s>%s' % (kname, '<map>' if mapped else '') + (' + pool_bias_reduce_kernel<%s>' % kname if bias_kind else '')
+    assert _lib.last_dispatch() == want, _lib.last_dispatch()
+    dy_ref = (np.repeat(do_ref, p, axis=2) * s_ref).astype(np.float32)           # [B, F, M], reference order
+    dy_int = dy_ref[:, :, src] if mapped else dy_ref
+    gdy = dy.cpu().numpy()
+    assert np.array_equal(gdy[:, :, :M], dy_int), 'dy differs'
+    assert np.all(gdy[:, :, M:] == 0)
+    if bias_kind == 2:
+        db = dbias.cpu().numpy()
+        ref = dy_int.astype(np.float64).sum(axis=0)
+        assert np.abs(db[:, :M] - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-30) * np.sqrt(B)
+        assert np.all(db[:, M:] == 0)
+    elif bias_kind == 1:
+        db = dbias.cpu().numpy()
+        ref = dy_int.astype(np.float64).sum(axis=(0, 2))
+        assert np.abs(db - ref).max() <= 2e-6 * np.abs(dy_int).sum(axis=(0, 2)).max()
+    # the same gradient from chebgcn_brelu_pool_bwd (tree order only): with the workspace it asks for -> this kernel; with none
+    # -> the scalar kernel of rounds 1-5.  Both bit-identical in dy.
+    if not mapped and bias_kind != 1:
+        for give_ws in (True, False):
+            dy2 = torch.full((B, F, Mp), float('nan'), device=dev)
+            db2 = None if bias_kind == 0 else torch.zeros((F, Mp), device=dev)
+            n2 = lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, p, bias_kind) if give_ws else 0
+            w2 = torch.empty(max(n2, 1), dtype=torch.uint8, device=dev)
+            # (the fused contraction epilogue's byte: the winning member / the positive-member mask, and `out` for the ReLU)
+            arg = sel.clone()
+            if kind == 0:
+                arg[arg == 0xFF] = 0
+            _lib.check(lib.chebgcn_brelu_pool_bwd(_P(dout), _P(out), _P(arg), _P(dy2), _P(db2), bias_kind, B, M, F, p, kind, relu,
+                                                  _P(w2) if give_ws else None, n2, _stream()), 'brelu_pool_bwd')
+            name = _lib.last_dispatch()
+            assert name.startswith('pool_scatter_bwd_kernel<' if (give_ws or bias_kind == 0) else 'brelu_pool_bwd_kernel<'), name
+            assert np.array_equal(dy2.cpu().numpy()[:, :, :M], dy_int), name
+            if bias_kind == 2:
+                ref = dy_int.astype(np.float64).sum(axis=0)
+                assert np.abs(db2.cpu().numpy()[:, :M] - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-30) * np.sqrt(B)
+
+
+@pytest.mark.parametrize('name', ['inference_pool_n212', 'inference_pool6_n512'])
+@pytest.mark.parametrize('pool_kind', ['mpool1', 'apool1'])
+def test_relabelled_levels_are_invisible_with_pooling(dev, name, pool_kind):
+    """A pooling network whose levels are FORCED into the length order (``vertex_order = 'length!'``: these fixtures' graphs are
+    too small for an ordered kernel, the relabelling and the pooling maps are exercised all the same) against the same network
+    in the reference's order: logits, every gradient and the variables after a step agree to fp32 summation order, biases and
+    the first FC layer's rows cross the boundary in the reference's order, checkpoints are interchangeable."""
+    from gcn_fmri_decoding_amd import models_gcn, ops
+    z = load_golden(name)
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    F, K, p, M = z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist()
+    params = {k[len('param:'):]: z[k].copy() for k in z.files if k.startswith('param:')}
+    x = torch.as_tensor(z['x']).to(dev)
+    B = x.shape[0]
+    labels = torch.as_tensor(np.arange(B) % M[-1]).to(dev)
+    nets = {}
+    import os
+    for mode in ('reference', 'length!'):
+        os.environ['CHEBGCN_VERTEX_ORDER'] = mode
+        try:
+            net = models_gcn.cgcnn({'device': dev}, Ls, F, K, p, M, channel=int(z['channel']), brelu=str(z['brelu']), pool=pool_kind,
+                                   batch_size=B, regularization=5e-4, dropout=1, verbose=False)
+        finally:
+            os.environ.pop('CHEBGCN_VERTEX_ORDER', None)
+        net.contraction = 'f32'
+        for k, v in params.items():
+            net.set_variable(k, v)
+        nets[mode] = net
+    ref, rel = nets['reference'], nets['length!']
+    assert ref.vertex_order == 'reference' and not ref._relabelled
+    assert rel.vertex_order == 'length' and all(o is not None for o in rel._orders)
+    assert any(m is not None for m in rel._pool_maps) and all(m is None for m in ref._pool_maps)
+    for k in params:                                         # what was set is what is read, in the reference's shape and order
+        assert np.array_equal(rel.get_var(k), params[k]), k
+    with torch.no_grad():
+        la = ref.inference(x, 1).cpu().numpy()
+        lb = rel.inference(x, 1).cpu().numpy()
+    if pool_kind == 'mpool1' and 'logits' in z.files:
+        assert np.abs(la - z['logits']).max() <= 2e-5 * np.abs(z['logits']).max()       # the reference-generated vector
+    e_logits = np.abs(la - lb).max() / np.abs(la).max()
+    assert e_logits <= 1e-5, e_logits
+    xs = ops.plane_storage(x)
+    ref.train_step(xs, labels)
+    rel.train_step(xs, labels)
+    worst = {}
+    for k in params:
+        ga, gb = ref.gradient(k).cpu().numpy().astype(np.float64), rel.gradient(k).cpu().numpy().astype(np.float64)
+        worst[k] = float(np.abs(ga - gb).max() / max(np.abs(ga).max(), 1e-30))
+        assert worst[k] <= 5e-5, (k, worst[k])
+    record_measured('relabelled_levels_invisible[%s,%s]' % (name, pool_kind), logits=float(e_logits), **worst)
+    sd = rel.state_dict()
+    twin = models_gcn.cgcnn.from_checkpoint(sd, config={'device': dev})
+    for k in params:
+        assert np.array_equal(twin.get_var(k), rel.get_var(k)), k
+    ref.load_state_dict(sd)                                  # a relabelled model's checkpoint in a reference-order model
+    with torch.no_grad():
+        lc = ref.inference(x, 1).cpu().numpy()
+        ld = rel.inference(x, 1).cpu().numpy()
+    assert np.abs(lc - ld).max() <= 1e-5 * np.abs(lc).max()
+
+
+def test_contraction_value_is_validated(dev):
+    from gcn_fmri_decoding_amd import models_gcn
+    z = load_golden('inference_flat_n212')
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    net = models_gcn.cgcnn({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                           channel=int(z['channel']), brelu=str(z['brelu']), batch_size=2, verbose=False)
+    with pytest.raises(ValueError):
+        net.contraction = 'bf16x2'
+    net.contraction = 'bf16x3'
+    assert net.layer_precisions() == ['bf16x3'] * len(z['F'])
+
+
+def test_loss_average_reading_switch(dev):
+    """``ema_zero_debias`` (models_gcn.py:269-275 read two ways, see cgcnn): default = TF >= 1.0 (the zero-initialised shadow as
+    is: 0.1 * loss after one step), True = TF 0.12 (debiased: the loss itself)."""
+    from gcn_fmri_decoding_amd import models_gcn, ops
+    z = load_golden('inference_flat_n212')
+    Ls = [csr_from(z, 'L%d' % i) for i in range(int(z['nlevels']))]
+    x = ops.plane_storage(torch.as_tensor(z['x']).to(dev))
+    labels = torch.as_tensor(np.arange(x.shape[0]) % int(z['M'][-1])).to(dev)
+    vals = {}
+    for zd in (False, True):
+        torch.manual_seed(0)
+        net = models_gcn.cgcnn({'device': dev}, Ls, z['F'].tolist(), z['K'].tolist(), z['p'].tolist(), z['M'].tolist(),
+                               channel=int(z['channel']), brelu=str(z['brelu']), batch_size=x.shape[0], dropout=1, verbose=False)
+        assert net.ema_zero_debias is False
+        net.ema_zero_debias = zd
+        vals[zd] = [float(net.train_step(x, labels)[1]) for _ in range(3)]
+    raw, deb = np.array(vals[False]), np.array(vals[True])
+    t = np.arange(1, 4)
+    np.testing.assert_allclose(raw, deb * (1 - 0.9 ** t), rtol=2e-6)

@@ -13,9 +13,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'refresh')
 DST = os.path.join(ROOT, 'profiles')
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 
 for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats.csv', '%s_bench_kernel_stats.csv'),
+                 ('bench_kernel_stats_serial.csv', '%s_bench_kernel_stats_serial.csv'), ('bench_line_serial.json', '%s_bench_line_serial.json'),
                  ('kbench.txt', '%s_kbench.txt'), ('kbench.json', '%s_kbench.json'),
                  ('kbench_config4.txt', '%s_kbench_config4_K25_F64.txt'), ('kbench_config5.txt', '%s_kbench_config5_bf16.txt'),
                  ('hbm_stream_probe.txt', '%s_hbm_stream_probe.txt'), ('mfma_f32_probe.txt', '%s_mfma_f32_probe.txt'),
@@ -51,21 +52,29 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
             shutil.copy(p, os.path.join(DST, dst % tag))
 
 raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
-names = {'cheb_ord_kernel<4, 10240, 6, 5, 512, false>': 'recurrence_fwd', 'cheb_ord_kernel<4, 10240, 6, 5, 512, true>': 'recurrence_bwd',
-         'cheb_onchip_kernel<2, 14, 4, 768, false>': 'recurrence_fwd_2planes', 'cheb_onchip_kernel<2, 14, 4, 768, true>': 'recurrence_bwd_2planes',
-         'cheb4_kernel<10240, 20, 6, 512, false,': 'recurrence_fwd_4planes', 'cheb4_kernel<10240, 20, 6, 512, true,': 'recurrence_bwd_4planes',
-         'contract_fwd_kernel<1>': 'contract_fwd', 'contract_fwd_ring_kernel': 'contract_fwd', 'contract_bwd_w_kernel<5, true>': 'contract_bwd_w',
-         'contract_bwd_x_kernel<true, true>': 'contract_bwd_x', 'contract_bwd_x_lds_kernel<true>': 'contract_bwd_x',
-         'contract_bwd_x_lds_kernel<false>': 'contract_bwd_x_unfolded', 'bias_grad_relu_kernel<2': 'bias_grad',
-         'contract_bwd_w_kernel<5, false>': 'contract_bwd_w_unfolded', 'contract_bwd_x_kernel<true, false>': 'contract_bwd_x_unfolded',
-         'brelu_pool_bwd_kernel<2, 1>': 'brelu_pool_bwd_unfolded'}
+# rocprofv3's kernel name (substring) -> the name chebgcn_last_dispatch() reports for that template (what bench.py's
+# `kernels_by_symbol` / `roofline.kernel` are keyed by); kbench launches each at the shape of the step (B=64, Fin=Fout=32, K=5)
+names = {'cheb_ord_kernel<4, 10240, 6, 5, 512, false>': 'cheb_ord_kernel<10240,6,5,512,false>',
+         'cheb_ord_kernel<4, 10240, 6, 5, 512, true>': 'cheb_ord_kernel<10240,6,5,512,true>',
+         'contract_fwd_ring_kernel<true>': 'contract_fwd_ring_kernel', 'contract_fwd_ring_kernel<false>': 'contract_fwd_ring_kernel<pool>',
+         'contract_bwd_w_kernel<5, true>': 'contract_bwd_w_kernel<5,true> + reduce_partials_wide',
+         'contract_bwd_w_kernel<5, false>': 'contract_bwd_w_kernel<5,false> + reduce_partials_wide',
+         'contract_bwd_x_lds_kernel<true>': 'contract_bwd_x_lds_kernel<true>', 'contract_bwd_x_lds_kernel<false>': 'contract_bwd_x_lds_kernel<false>',
+         'bias_grad_relu_kernel<2': 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>', 'reduce_partials_wide': 'reduce_partials_wide'}
 out = {'_note': 'HBM bytes per launch at the bench shape (B=64, Fin=Fout=32, K=5, M=10466), rocprofv3 --pmc FETCH_SIZE and '
                 'WRITE_SIZE in separate passes with --kernel-trace only (tools/pmc_traffic.sh); bytes = (2*FETCH_SIZE + '
                 'WRITE_SIZE) KiB -- FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; '
-                'raw counters in %s_traffic_raw.json' % tag}
+                'raw counters in %s_traffic_raw.json.  by_kernel: keyed by the template name chebgcn_last_dispatch() reports; a '
+                'kernel that kbench launches on several operands (the forward recurrence on x and on dy, the forward contraction '
+                'with and without bias) has the mean over those launches' % tag,
+       'by_kernel': {}, 'by_rocprof_name': {}}
 for k, v in raw.items():
+    if 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
+        continue
+    nbytes = (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0
+    out['by_rocprof_name'][k] = nbytes
     for pat, name in names.items():
-        if pat in k:
-            out[name] = (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0
+        if pat in k and name not in out['by_kernel']:
+            out['by_kernel'][name] = nbytes
 json.dump(out, open(os.path.join(DST, 'traffic.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))

@@ -27,7 +27,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_fwd_inplace', 'recurrence_bwd', 'contract_fwd',
                                                      'contract_bwd_w_relu', 'contract_bwd_x_relu', 'bias_grad_relu', 'contract_bwd_w', 'contract_bwd_x',
-                                                     'brelu_pool_bwd'])
+                                                     'brelu_pool_bwd', 'recurrence_fwd_t', 'contract_fwd_dx', 'brelu_pool_bwd_mask'])
     ap.add_argument('--nodes', type=int, default=10000, help='points of the synthetic kNN graph (10000 -> M = 10466)')
     ap.add_argument('--levels', type=int, default=1, help='coarsening levels of the synthetic graph (1 -> fake vertices behind the real ones)')
     ap.add_argument('--json', default=None)
@@ -78,12 +78,15 @@ def main():
 
     for B in args.B:
         Fin, Fout, K = args.fin, args.fout, args.K
+        if Fin != Fout:
+            args.kernels = [k for k in args.kernels if k not in ('recurrence_fwd_t', 'contract_fwd_dx')]
         torch.manual_seed(0)
         x = torch.randn(B, Fin, Mp, device=dev)
         stack = torch.randn(K, B, Fin, Mp, device=dev)
         gstack = torch.randn(K, B, Fin, Mp, device=dev)
         dx = torch.empty(B, Fin, Mp, device=dev)
         W = torch.randn(Fin * K, Fout, device=dev) * 0.1
+        Wt = torch.randn(Fout * K, Fin, device=dev) * 0.1       # (gstack below is [K, B, Fin, Mp]: the dx entries assume Fin == Fout)
         bias = torch.randn(Fout, Mp, device=dev)
         out = torch.empty(B, Fout, Mp, device=dev)
         dy = torch.randn(B, Fout, Mp, device=dev)
@@ -105,6 +108,14 @@ def main():
                                        4.0 * M * Fin * K * B, 0.0),
             'recurrence_bwd': (lambda: lib.chebgcn_recurrence_bwd(g.handle, P(gstack), P(dx), B, Fin, K, st),
                                4.0 * M * Fin * (K + 1) * B, 0.0),
+            # the input gradient as the training step forms it (ops.dx_by_forward): the FORWARD kernel on the planes of dy with the
+            # transposed operator, in place in slab 0 of the gradient stack, then the forward contraction on the re-indexed weights
+            # (no bias, no ReLU, no mask)
+            'recurrence_fwd_t': (lambda: lib.chebgcn_recurrence_fwd_t(g.handle, P(gstack), P(gstack), B, Fout, K, st),
+                                 4.0 * M * Fout * K * B, 0.0),
+            'contract_fwd_dx': (lambda: lib.chebgcn_contract_fwd(P(gstack), P(Wt), None, 0, P(dx), None, B, M, Fout, K, Fin,
+                                                                 1, 0, 0, st),
+                                4.0 * B * M * (Fout * K + Fin), 2.0 * B * M * Fin * K * Fout),
             'contract_fwd': (lambda: lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), 2, P(out), None, B, M, Fin, K, Fout,
                                                               1, 0, 1, st),
                              4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),

@@ -46,6 +46,11 @@ cp gpurun_out/pmcmfma_refresh/available.txt $out/mfma_counters_available.txt 2>/
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-windows 0 --kernel-legs 0 > $out/prof.log 2>&1
 find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
+# the same command with every kernel ALONE on the device (no second stream for contract_bwd_w): the AverageNs of a kernel symbol
+# here is what `roofline` / `kernels_by_symbol` of the bench line (HIP events, instrumented pass) must agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/profs -o benchs -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-windows 0 --kernel-legs 0 --overlap-bwd-w 0 > $out/profs.log 2>&1
+find $out/profs -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats_serial.csv \;
+grep '^{"metric"' $out/profs.log | tail -1 > $out/bench_line_serial.json
 # configs[3] (K = 25, Fin = Fout = 64, batch 64): one program per recurrence entry, 30 launches each (the three warm-up launches of
 # kbench are in the average: with 5 launches, as in round 2, they skewed it by 10-15 %)
 for kern in recurrence_fwd_inplace recurrence_bwd; do
@@ -75,6 +80,6 @@ grep "^{\"shape\"" $out/profr.log | tail -1 > $out/refshape_n360_line.json
 # what the memory system and the fp32 matrix pipe give with nothing else going on (EXPERIMENTS.md 3b)
 for b in 8 16 32 64; do $GRAFT_REPO_ROOT/tools/probes/hbm_stream_probe $b; done > $out/hbm_stream_probe.txt 2>&1
 $GRAFT_REPO_ROOT/tools/probes/mfma_f32_probe > $out/mfma_f32_probe.txt 2>&1
-rm -rf $out/prof $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr $out/profo_* $out/profp
+rm -rf $out/prof $out/profs $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr $out/profo_* $out/profp
 cp gpurun_out/parity_measured.jsonl $out/ 2>/dev/null
 ls -la $out
