@@ -209,18 +209,46 @@ pool_gather_fwd_kernel(const float* __restrict__ y, const int32_t* __restrict__ 
 // and stores whole 16-byte pieces of dy.  The bias gradient of a vertex is a register sum over the part's windows; the NPB
 // partial sums are added in part order by pool_bias_reduce_kernel (fixed order: bit-reproducible, no atomics).
 // `out` (optional): the forward result, read where `sel` carries no dead flag (the fused contraction epilogue's argmax byte).
-template <int BIAS>
-__global__ void __launch_bounds__(512)
+template <int BIAS, bool HAS_OUT, int EPT>
+__global__ void __launch_bounds__(512, 4)        // (two workgroups per CU: four waves per SIMD)
 pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const uint8_t* __restrict__ sel,
                         const int32_t* __restrict__ smap, float* __restrict__ dy, float* __restrict__ part, int B, int M, int Mp,
                         int F, int lgp, int pool_kind, int relu, int Mo, int Mpo) {
     extern __shared__ __attribute__((aligned(16))) float2 ps_ent[];            // [2][Mpo]
-    constexpr int QPT = 8;                                 // source quads per thread and pass
+    constexpr int QPT = 4;                                 // source quads per thread and pass
+    // EPT: pooled vertices a thread stages per window (prefetched one window ahead while Mpo <= EPT * 512): 2 or 8
     const int f = blockIdx.y, pb = blockIdx.x, NPB = gridDim.x;
     const int b0 = (int)((long long)B * pb / NPB), b1 = (int)((long long)B * (pb + 1) / NPB);
     const int Mq = Mp >> 2, pmask = (1 << lgp) - 1;
+    // blockIdx.z: the source quads are split between gridDim.z workgroups (each stages the whole pooled plane: an L2 hit for
+    // all but the first) where batch parts x filters alone leave the chip short of workgroups
+    const int qpz = (Mq + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int qs = (int)blockIdx.z * qpz, qe = min(Mq, qs + qpz);
     const float inv = 1.0f / (float)(1 << lgp);
-    for (int q0 = 0; q0 < Mq; q0 += QPT * 512) {           // (graphs beyond 16384 vertices: more than one pass over the windows)
+    const bool pre = Mpo <= EPT * 512;
+    const bool is_max = pool_kind == CHEBGCN_POOL_MAX;
+    // One pooled vertex of a window: {gradient (scaled for the average), selection byte with the dead flag}.  Requests and
+    // their use are separate and free of data-dependent branches: every load of a window is in flight before the first is used
+    // (a conditional load behind a loaded value made hipcc wait for each of them in turn)
+    const uint8_t* sel8 = sel ? sel : reinterpret_cast<const uint8_t*>(dout);     // (no selection bytes: average without ReLU, ignored)
+    auto request = [&](int b, int j, float& g, int& sb, float& o) __attribute__((always_inline)) {
+        const size_t po = ((size_t)b * F + f) * Mpo;           // uniform: scalar base + one 32-bit lane offset per load
+        const int jj = min(j, Mo - 1);
+        g = __builtin_nontemporal_load(dout + po + jj);
+        sb = (int)(sel8 + po)[jj];
+        o = HAS_OUT ? (out + po)[jj] : 1.f;
+    };
+    auto finish = [&](int j, float g, int sb, float o) __attribute__((always_inline)) -> float2 {
+        if (is_max) {
+            if (HAS_OUT && relu && !(o > 0.f)) sb = 0xFF;
+        } else {
+            g *= inv;
+            if (!relu) sb = 0xFF;                    // every member takes its share
+        }
+        const bool live = j < Mo;
+        return make_float2(live ? g : 0.f, __int_as_float(live ? sb : 0xFF));
+    };
+    for (int q0 = qs; q0 < qe; q0 += QPT * 512) {           // (more than 8192 vertices per split: another pass over the windows)
         int code[QPT][4];
         float4 acc[QPT];
 #pragma unroll
@@ -230,45 +258,53 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int v = 4 * q + i;
-                code[u][i] = (q < Mq && v < M) ? (smap ? smap[v] : v) : -1;
+                code[u][i] = (q < qe && v < M) ? (smap ? smap[v] : v) : -1;
             }
+        }
+        float ng[EPT], no[EPT];                            // the next window's entries, requested while this one is computed
+        int ns[EPT];
+        if (pre && b0 < b1) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) request(b0, k * 512 + (int)threadIdx.x, ng[k], ns[k], no[k]);     // (unconditional: clamped)
         }
         int buf = 0;
         for (int b = b0; b < b1; ++b) {
-            const size_t po = ((size_t)b * F + f) * Mpo;
             float2* ent = ps_ent + (size_t)buf * Mpo;
-            for (int j = threadIdx.x; j < Mpo; j += 512) {
-                float g = 0.f;
-                int s = 0xFF;
-                if (j < Mo) {
-                    g = __builtin_nontemporal_load(dout + po + j);
-                    s = sel ? sel[po + j] : 0;
-                    if (pool_kind == CHEBGCN_POOL_MAX) {
-                        if (out && relu && !(out[po + j] > 0.f)) s = 0xFF;
-                    } else {
-                        g *= inv;
-                        if (!relu) s = 0xFF;                    // every member takes its share
-                    }
+            if (pre) {
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) {
+                    const int j = k * 512 + (int)threadIdx.x;
+                    if (j < Mpo) ent[j] = finish(j, ng[k], ns[k], no[k]);
                 }
-                ent[j] = make_float2(g, __int_as_float(s));
+            } else {
+                for (int j = threadIdx.x; j < Mpo; j += 512) {
+                    float g, o;
+                    int sb;
+                    request(b, j, g, sb, o);
+                    ent[j] = finish(j, g, sb, o);
+                }
             }
-            __syncthreads();
+            // LDS-only barrier: __syncthreads() also waits (s_waitcnt vmcnt(0)) for the previous window's dy STORES to be
+            // acknowledged by memory -- a store round trip per window, 21k cycles of a window's ~2k (measured: 0.21 of the roofline)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (pre && b + 1 < b1) {
+#pragma unroll
+                for (int k = 0; k < EPT; ++k) request(b + 1, k * 512 + (int)threadIdx.x, ng[k], ns[k], no[k]);
+            }
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
                 const int q = q0 + u * 512 + (int)threadIdx.x;
-                if (q < Mq) {
+                if (q < qe) {
+                    float2 e[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) e[i] = ent[max(code[u][i], 0) >> lgp];
                     float r[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int c = code[u][i];
-                        float g = 0.f;
-                        if (c >= 0) {
-                            const float2 e = ent[c >> lgp];
-                            const int s = __float_as_int(e.y), pos = c & pmask;
-                            const bool take = pool_kind == CHEBGCN_POOL_MAX ? s == pos : ((s >> pos) & 1) != 0;
-                            g = take ? e.x : 0.f;
-                        }
-                        r[i] = g;
+                        const int sb = __float_as_int(e[i].y), pos = c & pmask;
+                        const bool take = c >= 0 && (is_max ? sb == pos : ((sb >> pos) & 1) != 0);
+                        r[i] = take ? e[i].x : 0.f;
                     }
                     if (dy) *reinterpret_cast<float4*>(dy + ((size_t)b * F + f) * Mp + 4 * q) = make_float4(r[0], r[1], r[2], r[3]);
                     acc[u].x += r[0]; acc[u].y += r[1]; acc[u].z += r[2]; acc[u].w += r[3];
@@ -280,7 +316,7 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
                 const int q = q0 + u * 512 + (int)threadIdx.x;
-                if (q < Mq) *reinterpret_cast<float4*>(part + ((size_t)pb * F + f) * Mp + 4 * q) = acc[u];
+                if (q < qe) *reinterpret_cast<float4*>(part + ((size_t)pb * F + f) * Mp + 4 * q) = acc[u];
             }
         }
         __syncthreads();                                   // (a further pass refills the buffers)
@@ -590,7 +626,7 @@ static int pool_scatter_launch(const float* dout, const float* out, const uint8_
 extern "C" size_t chebgcn_brelu_pool_bwd_workspace(int B, int M, int F, int pool, int bias_kind) {
     if (M <= 0 || F <= 0) return 0;
     // pooled layers: the 16-byte-store kernel (pool_scatter_bwd_kernel) leaves per-batch-part partial bias sums
-    const size_t pooled = (pool > 1 && pool_scatter_fits(M, pool)) ? chebgcn_pool_scatter_bwd_workspace(B, M, F, pool, bias_kind) : 0;
+    const size_t pooled = (pool > 1 && plane_stride(M) >= 2048 && pool_scatter_fits(M, pool)) ? chebgcn_pool_scatter_bwd_workspace(B, M, F, pool, bias_kind) : 0;
     const size_t filter = bias_kind == CHEBGCN_BIAS_FILTER ? (size_t)F * ((size_t)(M + 31) / 32 + 1) * sizeof(float) : 0;   // the finest split: 32 vertices per workgroup
     return std::max(pooled, filter);
 }
@@ -610,7 +646,9 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
     // pooled layers: whole 16-byte pieces of dy per store, the pooled plane staged in LDS (pool_scatter_bwd_kernel; the scalar
     // kernel below ran at 0.18-0.22 of the HBM roofline in the six-level pooling network).  It needs the workspace
     // chebgcn_brelu_pool_bwd_workspace() reports; a caller without one gets the scalar kernel.
-    if (pool > 1 && dy && pool_scatter_fits(M, pool) && (pool_kind == CHEBGCN_POOL_MAX || pool <= 8 || !relu) &&
+    // (planes of fewer than 2048 vertices: a workgroup's 512 threads have less than a quad each and a window is a latency chain --
+    // the scalar kernel with its batch split over thread groups is faster there: 0.033 against 0.055 ms at M = 792, F = 128)
+    if (pool > 1 && dy && Mp >= 2048 && pool_scatter_fits(M, pool) && (pool_kind == CHEBGCN_POOL_MAX || pool <= 8 || !relu) &&
         (bias_kind == CHEBGCN_BIAS_NONE ||
          (workspace && workspace_bytes >= chebgcn_pool_scatter_bwd_workspace(B, M, F, pool, bias_kind))))
         return pool_scatter_launch(dout, out, argmax, nullptr, dy, dbias, bias_kind, B, M, F, pool, pool_kind, relu, workspace,
@@ -721,22 +759,37 @@ static int pool_scatter_launch(const float* dout, const float* out, const uint8_
         part = static_cast<float*>(workspace);
     }
     const size_t lds = (size_t)2 * Mpo * sizeof(float2);
-    const dim3 grid(NPB, F);
-#define CG_PSB(BK)                                                                                                              \
+    // (source quads split between up to four workgroups where batch parts x filters leave fewer than two workgroups per CU)
+    // ... and where one workgroup's four quads per thread do not cover the plane
+    const int VS = std::max(std::min(8, (Mp / 4 + 2047) / 2048), std::max(1, std::min(std::min(4, (512 + NPB * F - 1) / (NPB * F)), (Mp / 4 + 511) / 512)));
+    const dim3 grid(NPB, F, VS);
+#define CG_PSB3(BK, HO, EP)                                                                                                     \
     do {                                                                                                                        \
         static size_t lds_set = 0;                                                                                              \
         if (lds > lds_set) {                                                                                                    \
-            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_scatter_bwd_kernel<BK>),                              \
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_scatter_bwd_kernel<BK, HO, EP>),                      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
             lds_set = lds;                                                                                                      \
         }                                                                                                                       \
+        hipLaunchKernelGGL((pool_scatter_bwd_kernel<BK, HO, EP>), grid, dim3(512), lds, stream, dout, out, sel, smap, dy, part, B, M, Mp, F, \
+                           lgp, pool_kind, relu, Mo, Mpo);                                                                      \
+    } while (0)
+#define CG_PSB2(BK, HO)                                                                                                         \
+    do {                                                                                                                        \
+        if (Mpo <= 1024) CG_PSB3(BK, HO, 2);                                                                                    \
+        else CG_PSB3(BK, HO, 8);                                                                                                \
+    } while (0)
+#define CG_PSB(BK)                                                                                                              \
+    do {                                                                                                                        \
         note_dispatch(smap ? "pool_scatter_bwd_kernel<" #BK "><map>" : "pool_scatter_bwd_kernel<" #BK ">");                     \
-        hipLaunchKernelGGL((pool_scatter_bwd_kernel<BK>), grid, dim3(512), lds, stream, dout, out, sel, smap, dy, part, B, M, Mp, F, lgp, \
-                           pool_kind, relu, Mo, Mpo);                                                                           \
+        if (out) CG_PSB2(BK, true);                                                                                             \
+        else CG_PSB2(BK, false);                                                                                                \
     } while (0)
     if (bias_kind == CHEBGCN_BIAS_VERTEX) CG_PSB(CHEBGCN_BIAS_VERTEX);
     else if (bias_kind == CHEBGCN_BIAS_FILTER) CG_PSB(CHEBGCN_BIAS_FILTER);
     else CG_PSB(CHEBGCN_BIAS_NONE);
+#undef CG_PSB2
+#undef CG_PSB3
 #undef CG_PSB
     CG_HIP(hipGetLastError());
     if (bias_kind == CHEBGCN_BIAS_VERTEX) {

@@ -245,14 +245,16 @@ def test_bwd_w_row_tile_sweep(ops, dev, Fin, K, rt, gy, monkeypatch):
 @pytest.mark.parametrize('lvl,F,parts', [(0, 256, 4), (0, 24, 8), (2, 33, 8)])
 @pytest.mark.parametrize('bias', [0, 1, 2])
 def test_brelu_pool_bwd_parts_small_graph(ops, dev, lvl, F, parts, bias):
-    """The gradient of a POOLED layer on small graphs, all bias kinds: since round 6 the 16-byte-store kernel
-    (pool_scatter_bwd_kernel: the pooled plane staged in LDS, per-batch-part bias partials added in part order) -- ops hands
-    chebgcn_brelu_pool_bwd the workspace it asks for.  (The scalar brelu_pool_bwd_kernel<BIAS, PARTS> a caller without a
-    workspace gets: tests/test_gpu_round6.py.)"""
+    """brelu_pool_bwd_kernel<BIAS, PARTS> with PARTS = 4 / 8 (small graphs), all bias kinds, with
+    pooling.  (From 2048 vertices a pooled layer takes the 16-byte-store kernel pool_scatter_bwd_kernel: the M = 10466 test
+    below and tests/test_gpu_round6.py.)"""
     L = levels()[lvl]
+    M = L.shape[0]
+    got = 1 if ((M + 255) // 256) * F >= 1024 else 4 if ((M + 63) // 64) * F >= 1024 else 8
+    assert got == parts                                                # the dispatcher's arithmetic (pointwise.hip)
     kind = ['CHEBGCN_BIAS_NONE', 'CHEBGCN_BIAS_FILTER', 'CHEBGCN_BIAS_VERTEX'][bias]
-    name = 'pool_scatter_bwd_kernel<%s>' % kind + (' + pool_bias_reduce_kernel<%s>' % kind if bias else '')
-    run_layer(ops, dev, L, B=5, Fin=2, Fout=F, K=2, p=2, pool_kind=0, bias=bias, seed=F + bias, expect={'brelu_pool_bwd': name})
+    run_layer(ops, dev, L, B=5, Fin=2, Fout=F, K=2, p=2, pool_kind=0, bias=bias, seed=F + bias,
+              expect={'brelu_pool_bwd': 'brelu_pool_bwd_kernel<%s,%d>' % (kind, parts)})
 
 
 @pytest.mark.parametrize('bias,p,pool_kind', [(0, 1, 0), (1, 1, 0), (2, 2, 0), (2, 2, 1)])     # M = 10466 = 2 * 5233

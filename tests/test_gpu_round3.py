@@ -42,7 +42,8 @@ def test_b1relu_bias_gradient_is_a_fixed_order_sum(ops, dev, M, F, B, pool, relu
     gout = torch.randn((B, F, Mpo), generator=gen, device=dev)
     gout[:, :, Mo:] = 1e30                                  # plane pads must not leak into the sums
     nws = lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, ops.BIAS_FILTER)
-    assert nws > 0 and lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, ops.BIAS_VERTEX) == 0
+    # (a per-vertex bias needs none at pool 1; a pooled layer's 16-byte-store kernel keeps per-batch-part partials since round 6)
+    assert nws > 0 and (lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, pool, ops.BIAS_VERTEX) == 0) == (pool == 1 or Mp < 2048)
     ws = torch.empty(nws, dtype=torch.uint8, device=dev)
     if relu_mask:                                           # pool == 1 layer: the ReLU bit mask contract_fwd leaves
         bits = torch.randint(0, 16, (B, F, Mp // 4), generator=gen, device=dev, dtype=torch.uint8)

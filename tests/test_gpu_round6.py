@@ -124,8 +124,8 @@ def test_pool_gather_scatter_vs_numpy(dev, M, p, F, B, kind, bias_kind, mapped):
         db = dbias.cpu().numpy()
         ref = dy_int.astype(np.float64).sum(axis=(0, 2))
         assert np.abs(db - ref).max() <= 2e-6 * np.abs(dy_int).sum(axis=(0, 2)).max()
-    # the same gradient from chebgcn_brelu_pool_bwd (tree order only): with the workspace it asks for -> this kernel; with none
-    # -> the scalar kernel of rounds 1-5.  Both bit-identical in dy.
+    # the same gradient from chebgcn_brelu_pool_bwd (tree order only): from 2048 vertices and with the workspace it asks for -> this
+    # kernel; smaller planes or no workspace -> the scalar kernel of rounds 1-5.  Both bit-identical in dy.
     if not mapped and bias_kind != 1:
         for give_ws in (True, False):
             dy2 = torch.full((B, F, Mp), float('nan'), device=dev)
@@ -139,7 +139,7 @@ def test_pool_gather_scatter_vs_numpy(dev, M, p, F, B, kind, bias_kind, mapped):
             _lib.check(lib.chebgcn_brelu_pool_bwd(_P(dout), _P(out), _P(arg), _P(dy2), _P(db2), bias_kind, B, M, F, p, kind, relu,
                                                   _P(w2) if give_ws else None, n2, _stream()), 'brelu_pool_bwd')
             name = _lib.last_dispatch()
-            assert name.startswith('pool_scatter_bwd_kernel<' if (give_ws or bias_kind == 0) else 'brelu_pool_bwd_kernel<'), name
+            assert name.startswith('pool_scatter_bwd_kernel<' if ((give_ws or bias_kind == 0) and Mp >= 2048) else 'brelu_pool_bwd_kernel<'), name
             assert np.array_equal(dy2.cpu().numpy()[:, :, :M], dy_int), name
             if bias_kind == 2:
                 ref = dy_int.astype(np.float64).sum(axis=0)
