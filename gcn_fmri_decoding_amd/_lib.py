@@ -87,6 +87,7 @@ SIGNATURES = {
     'chebgcn_metis_one_level_f32p': (_i, [_i64, _p, _p, _p, _p, _p, _i64, _p]),
     'chebgcn_metis_one_level_f64': (_i, [_i64, _p, _p, _p, _p, _p, _i64, _p]),
     'chebgcn_compute_perm_level': (_i, [_p, _i64, _p, _i64, _p]),
+    'chebgcn_bank_order': (_i, [_i, _p, _p, _i, _p, _p]),
 }
 
 _lib = None

@@ -611,6 +611,116 @@ extern "C" int chebgcn_graph_create_planes(int M, int64_t nnz, const int32_t* ro
     return CHEBGCN_OK;
 }
 
+// Relabelling of a length-sorted graph INSIDE its classes of equal row length that spreads the gather's LDS reads over the banks
+// (host only, no device needed).  The ordered kernel gives vertex v the LDS slot (v & 3)*SQ + (v >> 2) and its row the lane
+// (v >> 2) & 63 of block (v >> 2) >> 6, slice v & 3: the label decides both which bank group v's entry lives in and which lane set
+// (the 16 -- two planes: 32 -- lanes the LDS serves together) v's row gathers with.  A lane set reads entry position e of its
+// rows in as many passes as the fullest bank group holds DISTINCT entries; place_group() chooses the positions, but with the
+// neighbours' bank groups as random as a graph leaves them the fullest of 16 groups holds ~1.6x the average, and no placement
+// gets below that (round 5: 46 % of the LDS-active cycles of the recurrence were conflict cycles).  Here the labels themselves
+// are chosen: vertices of ONE lane set (whose own slots always cover every bank group once) swap labels pairwise -- their rows
+// stay in the set, only their bank groups as gather TARGETS change -- whenever that lowers the sum over all lane sets of the
+// squared bank-group counts of the entries they gather.  Deterministic (fixed sweep order), rows stay sorted by length.
+// perm_out[new label] = old label.  stats (optional, 3 values): sum over the lane sets of the fullest bank group's count
+// before, after, and the number of swaps.
+extern "C" int chebgcn_bank_order(int M, const int32_t* rowptr, const int32_t* colidx, int sweeps, int32_t* perm_out,
+                                  int64_t* stats) {
+    CG_REQUIRE(M > 0 && rowptr && perm_out && sweeps >= 0, "bank_order: bad argument");
+    const int64_t nnz = rowptr[M];
+    CG_REQUIRE(nnz == 0 || colidx, "bank_order: colidx is NULL");
+    for (int v = 0; v < M; ++v) perm_out[v] = v;
+    if (stats) stats[0] = stats[1] = stats[2] = 0;
+    std::vector<int32_t> rp(rowptr, rowptr + M + 1);
+    const int nactive = sorted_rows(M, rp);
+    if (nactive <= 0) return CHEBGCN_OK;                   // not sorted by descending length: nothing to refine
+    int NT = 0, NQ = 0, NG = 0, PL = 0;
+    const int SQ = (nactive + 3) / 4;
+    if (!ordered_shape(plane_stride(M) / 4, SQ, &NT, &NQ, &NG, &PL)) return CHEBGCN_OK;     // no ordered kernel: nothing to gain
+    const int nb = PL == 4 ? 16 : 32, nsets = PL == 4 ? 4 : 2;
+    auto lane_set = [&](int lane) {
+        if (PL != 4) return lane >> 5;
+        static const int blk[16] = {0, 1, 1, 0, 1, 0, 0, 1, 2, 3, 3, 2, 3, 2, 2, 3};
+        return blk[lane >> 2];
+    };
+    auto cls_of = [&](int label) { return (int)(((int64_t)(label & 3) * SQ + (label >> 2)) % nb); };
+    auto set_of = [&](int label) { const int q = label >> 2; return (((q >> 6) * 4 + (label & 3)) * nsets) + lane_set(q & 63); };
+    const int nset_ids = ((SQ + 63) / 64) * 4 * nsets;
+    // who gathers from u: the rows r with u in row r (the transpose's structure)
+    std::vector<int32_t> tp(M + 1, 0), tr(nnz);
+    for (int64_t e = 0; e < nnz; ++e) {
+        CG_REQUIRE(colidx[e] >= 0 && colidx[e] < M, "bank_order: column out of range");
+        tp[colidx[e] + 1]++;
+    }
+    for (int v = 0; v < M; ++v) tp[v + 1] += tp[v];
+    {
+        std::vector<int32_t> cur(tp.begin(), tp.end() - 1);
+        for (int r = 0; r < M; ++r)
+            for (int e = rp[r]; e < rp[r + 1]; ++e) tr[cur[colidx[e]]++] = r;
+    }
+    std::vector<int32_t> lab(M), at(M);                    // vertex -> label, label -> vertex
+    for (int v = 0; v < M; ++v) lab[v] = at[v] = v;
+    std::vector<int32_t> H((size_t)nset_ids * nb, 0);      // entries of lane set s that point into bank group k
+    for (int r = 0; r < nactive; ++r)
+        for (int e = rp[r]; e < rp[r + 1]; ++e)
+            if (colidx[e] < nactive) H[(size_t)set_of(r) * nb + cls_of(colidx[e])]++;
+    auto sum_max = [&]() {
+        int64_t t = 0;
+        for (int s = 0; s < nset_ids; ++s) t += *std::max_element(H.begin() + (size_t)s * nb, H.begin() + (size_t)(s + 1) * nb);
+        return t;
+    };
+    if (stats) stats[0] = sum_max();
+    // the labels of every lane set
+    std::vector<std::vector<int32_t>> members(nset_ids);
+    for (int l = 0; l < nactive; ++l) members[set_of(l)].push_back(l);
+    auto len_of = [&](int v) { return rp[v + 1] - rp[v]; };
+    int64_t swaps = 0;
+    for (int sweep = 0; sweep < sweeps; ++sweep) {
+        int64_t moved = 0;
+        for (int s = 0; s < nset_ids; ++s) {
+            const auto& mem = members[s];
+            for (size_t a = 0; a < mem.size(); ++a)
+                for (size_t b = a + 1; b < mem.size(); ++b) {
+                    const int la = mem[a], lb = mem[b];
+                    const int x = at[la], y = at[lb];
+                    if (len_of(x) != len_of(y)) continue;
+                    const int ca = cls_of(la), cb = cls_of(lb);
+                    if (ca == cb) continue;
+                    // rows that gather from x lose an entry in group ca and gain one in cb; those that gather from y the reverse
+                    int64_t d = 0;
+                    for (int e = tp[x]; e < tp[x + 1]; ++e) {
+                        int32_t* h = &H[(size_t)set_of(lab[tr[e]]) * nb];
+                        d += 2 * (h[cb] - h[ca]) + 2;
+                        h[ca]--; h[cb]++;
+                    }
+                    for (int e = tp[y]; e < tp[y + 1]; ++e) {
+                        int32_t* h = &H[(size_t)set_of(lab[tr[e]]) * nb];
+                        d += 2 * (h[ca] - h[cb]) + 2;
+                        h[cb]--; h[ca]++;
+                    }
+                    if (d < 0) {
+                        lab[x] = lb; lab[y] = la;
+                        at[la] = y; at[lb] = x;
+                        ++moved;
+                    } else {
+                        for (int e = tp[x]; e < tp[x + 1]; ++e) {
+                            int32_t* h = &H[(size_t)set_of(lab[tr[e]]) * nb];
+                            h[ca]++; h[cb]--;
+                        }
+                        for (int e = tp[y]; e < tp[y + 1]; ++e) {
+                            int32_t* h = &H[(size_t)set_of(lab[tr[e]]) * nb];
+                            h[cb]++; h[ca]--;
+                        }
+                    }
+                }
+        }
+        swaps += moved;
+        if (moved == 0) break;
+    }
+    for (int l = 0; l < M; ++l) perm_out[l] = at[l];
+    if (stats) { stats[1] = sum_max(); stats[2] = swaps; }
+    return CHEBGCN_OK;
+}
+
 extern "C" void chebgcn_graph_destroy(chebgcn_graph* g) {
     if (!g) return;
     free_ell(g->fwd);

@@ -129,6 +129,25 @@ def length_order(L):
     return np.argsort(-lengths.astype(np.int64), kind='stable').astype(np.int64)
 
 
+def bank_order(L, sweeps=4, stats=None):
+    """``length_order(L)`` refined inside its classes of equal row length so that the LDS reads of the ordered recurrence
+    kernels' gather spread over the banks (``chebgcn_bank_order``, csrc/graph.hip: pairwise label swaps inside the gather's
+    lane sets, host only, deterministic).  Still sorted by descending row length: everything said of ``length_order`` holds.
+    ``stats``: a list that receives [fullest-bank sum before, after, swaps]."""
+    import ctypes as C
+    from . import _lib
+    order = length_order(L)
+    indptr, indices, _ = rescaled_laplacian_csr(permute(L, order))
+    M = int(L.shape[0])
+    perm = np.empty(M, np.int32)
+    st = np.zeros(3, np.int64)
+    _lib.check(_lib.lib().chebgcn_bank_order(M, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p), int(sweeps),
+                                             perm.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)), 'bank_order')
+    if stats is not None:
+        stats[:] = [int(v) for v in st]
+    return order[perm.astype(np.int64)]
+
+
 def permute(L, order):
     """``P L P^T``: row / column ``i`` of the result is row / column ``order[i]`` of ``L`` (CSR, sorted indices)."""
     L = sp.csr_matrix(L)

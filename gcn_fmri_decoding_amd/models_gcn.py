@@ -910,7 +910,11 @@ class cgcnn(base_model):
                 # the weight gradients' long cancelling sums over the vertices come out within 2e-7 of float64; in degree
                 # order they carry plain fp32 summation noise (1e-4 of their scale, like NumPy's fp32).
                 if self.vertex_order == 'length' and self._fusable() and (Li.shape[0] > 2048 or force):
-                    order = graph_mod.length_order(Li)
+                    # (CHEBGCN_BANK_ORDER=1: the length order refined inside its classes of equal row length against the gather's
+                    # LDS bank conflicts, graph.bank_order -- measured in round 6: the conflict cost of the image drops by 16 %, the
+                    # kernel by 0-2 %, the configs[1] step not at all (EXPERIMENTS 8.2): off by default)
+                    order = (graph_mod.bank_order(Li) if os.environ.get('CHEBGCN_BANK_ORDER', '0') == '1'
+                             else graph_mod.length_order(Li))
                     g = ops.Graph(Li, self.device, order=order)
                     if not (g.ordered or force):
                         order = g = None                    # no ordered kernel for this graph size: nothing to gain

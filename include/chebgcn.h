@@ -395,6 +395,18 @@ int chebgcn_metis_one_level_f64(int64_t nnz, const int64_t* rr, const int64_t* c
 int chebgcn_compute_perm_level(const int32_t* parent, int64_t n_fine, const int64_t* order,
                                int64_t n_order, int64_t* out);
 
+
+/* ---- vertex order for the ordered recurrence kernels (host only) ----
+ * The reference leaves the numbering of a graph's vertices to its caller (the coarsening's tree order, coarsening.py:168-215);
+ * the network is invariant under a relabelling as long as everything per-vertex follows (cgcnn.vertex_order).  A graph whose
+ * rows come sorted by descending length (graph.length_order) runs the ordered kernels; chebgcn_bank_order refines such an
+ * order INSIDE its classes of equal row length so that the LDS reads of the gather spread over the banks (csrc/graph.hip).
+ *   rowptr / colidx: CSR structure of the rescaled Laplacian in the length-sorted numbering (host memory);
+ *   sweeps: passes of the pairwise-swap descent (0 = identity); perm_out[new label] = old label, M entries;
+ *   stats (optional, 3 values): sum over the gather's lane sets of the fullest bank group before / after, swaps made.
+ * Returns the identity where no ordered kernel serves the graph (nothing to gain).  Deterministic. */
+int chebgcn_bank_order(int M, const int32_t* rowptr, const int32_t* colidx, int sweeps, int32_t* perm_out, int64_t* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,3 +208,47 @@ def test_internal_planes_wrapper_keeps_the_order_explicit():
     y = InternalPlanes(torch.zeros_like(x), owner)
     assert torch.equal(y.copy_(w).planes, x)
     assert InternalPlanes(w, owner).planes is x                      # wrapping a wrapper does not nest
+
+
+def test_bank_order_is_a_length_sorted_permutation():
+    """``graph.bank_order`` (chebgcn_bank_order, host only): a permutation that keeps the rows sorted by descending length, lowers
+    the gather's fullest-bank count, is deterministic, and is the plain length order where no ordered kernel serves the graph.
+    ``ops.pool_maps``: the two maps of a pooled layer between vertex orders are inverse to each other and list the members of a
+    cluster in the reference's order (models_gcn.py:631-648, coarsening.py:168-215)."""
+    import scipy.sparse as sp
+    from gcn_fmri_decoding_amd import graph
+    rs = np.random.RandomState(3)
+    n = 3000
+    rows = np.repeat(np.arange(n), 6)
+    cols = rs.randint(0, n, rows.size)
+    keep = rows != cols
+    W = sp.coo_matrix((np.exp(-rs.rand(int(keep.sum()))).astype(np.float32), (rows[keep], cols[keep])), shape=(n, n)).tocsr()
+    W = W.maximum(W.T)
+    L = graph.laplacian(W.astype(np.float32), normalized=True)
+    st, st2 = [], []
+    order = graph.bank_order(L, sweeps=4, stats=st)
+    assert sorted(order.tolist()) == list(range(n))
+    lens = np.diff(graph.rescaled_laplacian_csr(graph.permute(L, order))[0])
+    assert (np.diff(lens) <= 0).all()                              # still sorted by descending row length
+    assert st[1] < st[0] and st[2] > 0, st
+    assert np.array_equal(order, graph.bank_order(L, sweeps=4, stats=st2)) and st == st2
+    assert np.array_equal(graph.bank_order(L, sweeps=0), graph.length_order(L))
+    small = graph.laplacian(W[:500][:, :500].astype(np.float32), normalized=True)           # no ordered kernel at this size
+    assert np.array_equal(graph.bank_order(small), graph.length_order(small))
+
+
+def test_pool_maps_definition():
+    torch = pytest.importorskip('torch')
+    from gcn_fmri_decoding_amd import ops
+    rs = np.random.RandomState(0)
+    M, p = 48, 4
+    src, dst = rs.permutation(M), rs.permutation(M // p)
+    pm, sm = ops.pool_maps(p, src, dst, M, 'cpu')
+    pm, sm = pm.numpy(), sm.numpy()
+    # pooled position j' is reference vertex dst[j']: its members are the reference vertices p*dst[j'] + i, found at inv_src[...]
+    for j in range(M // p):
+        for i in range(p):
+            assert src[pm[j * p + i]] == p * dst[j] + i
+    assert np.array_equal(sm[pm], np.arange(M))
+    ident = ops.pool_maps(p, None, None, M, 'cpu')
+    assert np.array_equal(ident[0].numpy(), np.arange(M)) and np.array_equal(ident[1].numpy(), np.arange(M))

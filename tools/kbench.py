@@ -32,7 +32,7 @@ def main():
     ap.add_argument('--levels', type=int, default=1, help='coarsening levels of the synthetic graph (1 -> fake vertices behind the real ones)')
     ap.add_argument('--json', default=None)
     ap.add_argument('--planes', type=int, default=0, help='planes per workgroup of the recurrence kernel (0 = automatic, 2, 4)')
-    ap.add_argument('--order', default='length', choices=['length', 'reference'],
+    ap.add_argument('--order', default='length', choices=['bank', 'length', 'reference'],
                     help="vertex order of the graph: 'length' = relabelled by descending row length as cgcnn does for a network "
                          "without pooling (ordered recurrence kernels); 'reference' = the caller's numbering")
     ap.add_argument('--stamps', action='store_true', help='print the in-kernel phase stamps of a CG_X&64 build (tools/xbuild.sh 64)')
@@ -55,10 +55,12 @@ def main():
         tune(3, args.wide)
         tune(4, args.stagger)
     from gcn_fmri_decoding_amd import graph as G
-    g = ops.Graph(Ls[0], dev, planes=args.planes, order=G.length_order(Ls[0]) if (args.order == 'length' and not args.planes) else None)
+    # 'bank': the length order refined inside its equal-length classes against LDS bank conflicts (graph.bank_order; experiment)
+    order = None if (args.order == 'reference' or args.planes) else G.length_order(Ls[0]) if args.order == 'length' else G.bank_order(Ls[0])
+    g = ops.Graph(Ls[0], dev, planes=args.planes, order=order)
     print('ordered recurrence kernels:', bool(g.query(12)), ' planes of the ordered image:', g.query(16), flush=True)
     print('planes per workgroup:', g.query(6), ' gather LDS cost (before, after placement, ideal):', g.query(9), g.query(10),
-          g.query(11), flush=True)
+          g.query(11), ' ordered image:', g.query(13), g.query(14), g.query(15), flush=True)
     M, Mp = g.M, g.Mp
     print('M = %d, Mp = %d (plane stride %d bytes)' % (M, Mp, 4 * Mp), flush=True)
     results = []
