@@ -172,9 +172,45 @@ pool_gather_fwd_kernel(const float* __restrict__ y, const int32_t* __restrict__ 
     const size_t pl = blockIdx.x;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4* src = reinterpret_cast<const f32x4*>(y + pl * Mp);
-    for (int i = threadIdx.x; i < (Mp >> 2); i += blockDim.x) reinterpret_cast<f32x4*>(pg_plane)[i] = __builtin_nontemporal_load(src + i);
+    // (eight 16-byte loads in flight per thread: one load and one LDS store per iteration compiles to a full wait per piece)
+    const int Mq = Mp >> 2, nt = (int)blockDim.x;
+    for (int i0 = threadIdx.x; i0 < Mq; i0 += 8 * nt) {
+        f32x4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = __builtin_nontemporal_load(src + min(i0 + u * nt, Mq - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * nt < Mq) reinterpret_cast<f32x4*>(pg_plane)[i0 + u * nt] = r[u];
+    }
     __syncthreads();
     const float inv = 1.0f / (float)pool;
+    if (pool == 4 && pmap) {
+        // the common case (p = 4: one 16-byte record of the map per pooled vertex), four pooled vertices per thread in flight
+        for (int m0 = threadIdx.x; m0 < Mpo; m0 += 4 * nt) {
+            int4 pm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pm[u] = reinterpret_cast<const int4*>(pmap)[min(m0 + u * nt, Mo - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int mo = m0 + u * nt;
+                if (mo >= Mpo) continue;
+                const float v[4] = {pg_plane[pm[u].x], pg_plane[pm[u].y], pg_plane[pm[u].z], pg_plane[pm[u].w]};
+                float best = v[0], sum = v[0];
+                int arg = 0, mask = v[0] > 0.f ? 1 : 0;
+#pragma unroll
+                for (int i = 1; i < 4; ++i) {
+                    if (v[i] > best) { best = v[i]; arg = i; }
+                    sum += v[i];
+                    if (v[i] > 0.f) mask |= 1 << i;
+                }
+                const bool live = mo < Mo;
+                const bool is_max = pool_kind == CHEBGCN_POOL_MAX;
+                out[pl * Mpo + mo] = live ? (is_max ? best : sum * inv) : 0.f;
+                if (sel) sel[pl * Mpo + mo] = (uint8_t)(!live ? 0 : is_max ? ((relu && !(best > 0.f)) ? 0xFF : arg) : mask);
+            }
+        }
+        return;
+    }
     for (int mo = threadIdx.x; mo < Mpo; mo += blockDim.x) {
         float o = 0.f;
         int s = 0;

@@ -397,7 +397,8 @@ def test_pooling_chebnet_full_size_vs_oracle(ops, dev, contraction):
     assert seen['recurrence_bwd'] == {'cheb_ord_kernel<4112,2,2,512,true>', 'cheb_onchip_kernel<4,4,1,256,true>'}, seen['recurrence_bwd']
     assert seen['pool_gather_fwd'] == {'pool_gather_fwd_kernel<map>'} and seen['pool_scatter_bwd'] == {
         'pool_scatter_bwd_kernel<CHEBGCN_BIAS_VERTEX><map> + pool_bias_reduce_kernel<CHEBGCN_BIAS_VERTEX>'}, (seen['pool_gather_fwd'], seen['pool_scatter_bwd'])
-    assert seen['brelu_pool_bwd'] >= {'pool_scatter_bwd_kernel<CHEBGCN_BIAS_VERTEX> + pool_bias_reduce_kernel<CHEBGCN_BIAS_VERTEX>'}, seen['brelu_pool_bwd']
+    # (level 4 -> 6, tree order on both sides, 792 vertices: below 2048 vertices the scalar kernel with its batch split is the faster one)
+    assert seen['brelu_pool_bwd'] == {'brelu_pool_bwd_kernel<CHEBGCN_BIAS_VERTEX,4>', 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>'}, seen['brelu_pool_bwd']
     from conftest import record_measured
     measured = {}
     for k in params:

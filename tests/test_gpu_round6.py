@@ -246,7 +246,10 @@ def test_fit_tracks_float64_oracle_under_auto(dev, contraction, tmp_path, monkey
     fixture (F up to 128: split bf16 in the wide layers under ``contraction = 'auto'``) against the FLOAT64 oracle's loop --
     the reported ``loss_average`` series and the validation losses.  Under 'auto' single gradient elements differ by flipped
     ReLU / max-pool decisions (tests/test_gpu_bench_shapes.py: 99 % quantile bound 2e-3); over 20 Adam steps the loss
-    trajectory stays within 1e-3 of the float64 one, as the exact-product path ('f32') does."""
+    trajectory stays as close to the float64 one as the exact-product path ('f32') does -- fp32 itself drifts from float64 at
+    the 1e-3 level over 20 Adam steps (the first updates are +-lr whatever the gradient's size, and decisions flip).  Measured
+    (profiles/r06_parity_measured.jsonl): 'auto' 1.5e-3 (loss_average series) / 1.2e-3 (validation losses), 'f32' 1.8e-4 / 2.3e-3;
+    bound 5e-3 for both."""
     from gcn_fmri_decoding_amd import models_gcn
     from oracle import layers_ref as R
     from oracle import loop_ref as LR
@@ -290,4 +293,4 @@ def test_fit_tracks_float64_oracle_under_auto(dev, contraction, tmp_path, monkey
     e_val = float(np.abs(np.array(losses) - np.array(log['losses'])).max() / np.abs(np.array(log['losses'])).max())
     record_measured('fit_tracks_float64_oracle[%s]' % contraction, loss_average_series=e_series, validation_losses=e_val,
                     final_loss_average=float(la[-1]))
-    assert e_series <= 1e-3 and e_val <= 1e-3, (contraction, e_series, e_val)
+    assert e_series <= 5e-3 and e_val <= 5e-3, (contraction, e_series, e_val)
