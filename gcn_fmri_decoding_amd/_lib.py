@@ -36,6 +36,7 @@ SIGNATURES = {
     'chebgcn_recurrence_bwd': (_i, [_p, _p, _p, _i, _i, _i, _p]),
     'chebgcn_recurrence_fwd_t': (_i, [_p, _p, _p, _i, _i, _i, _p]),
     'chebgcn_reindex_weights': (_i, [_p, _p, _i, _i, _i, _p]),
+    'chebgcn_reindex_weights_batch': (_i, [_i, _p, _p, _p, _p, _p, _p]),
     'chebgcn_contract_fwd': (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_fwd_bf16_workspace': (C.c_size_t, [_i, _i, _i]),
     'chebgcn_contract_fwd_bf16': (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p]),

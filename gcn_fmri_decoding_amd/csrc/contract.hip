@@ -17,6 +17,7 @@
 // half-wave holds vertices 4c..4c+3 in the four components of its float4, and component
 // r feeds accumulator r (vertex <-> MFMA column is a free permutation).  The A operand
 // (a 32 x 2 sliver of W) is 8 B per lane from L1/L2.
+#include <algorithm>
 #include "contract_common.h"
 #ifndef CG_DY_NT
 #define CG_DY_NT 0      // dy is read by three kernels of a layer's backward (bias, bwd_w, bwd_x): cached loads, 3.83 -> 3.795 ms per step
@@ -880,6 +881,25 @@ reindex_weights_kernel(const float* __restrict__ W, float* __restrict__ Wt, int 
     Wt[idx] = W[((size_t)fin * K + k) * Fout + fo];
 }
 
+// the same for up to 16 layers in ONE launch (blockIdx.y = layer): within a training step the weights are constant, and five
+// launches of 8.6 us each sat on the backward pass's critical path (rocprofv3, round 5)
+struct ReindexBatch {
+    const float* W[16];
+    float* Wt[16];
+    int Fin[16], K[16], Fout[16];
+};
+__global__ void __launch_bounds__(256)
+reindex_weights_batch_kernel(ReindexBatch b) {
+    const int l = blockIdx.y;
+    const int Fin = b.Fin[l], K = b.K[l], Fout = b.Fout[l];
+    const float* __restrict__ W = b.W[l];
+    float* __restrict__ Wt = b.Wt[l];
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < Fin * K * Fout; idx += gridDim.x * 256) {
+        const int fin = idx % Fin, kk = idx / Fin, k = kk % K, fo = kk / K;
+        Wt[idx] = W[((size_t)fin * K + k) * Fout + fo];
+    }
+}
+
 static bool small_launch(int B, int M) { return ((M + 511) / 512) * B < 2 * num_cus(); }
 static int bw_grid_x(int B, int M) {
     const int cus = num_cus();
@@ -910,6 +930,25 @@ extern "C" int chebgcn_reindex_weights(const float* W, float* Wt, int Fin, int K
     CG_REQUIRE(Fin > 0 && K > 0 && Fout > 0 && (int64_t)Fin * K * Fout < (1ll << 30), "reindex_weights: bad shape");
     note_dispatch("reindex_weights_kernel");
     hipLaunchKernelGGL(reindex_weights_kernel, dim3((Fin * K * Fout + 255) / 256), dim3(256), 0, stream, W, Wt, Fin, K, Fout);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_reindex_weights_batch(int n, const float* const* W, float* const* Wt, const int* Fin, const int* K,
+                                             const int* Fout, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(n >= 1 && n <= 16 && W && Wt && Fin && K && Fout, "reindex_weights_batch: bad argument (1..16 layers)");
+    ReindexBatch b;
+    int most = 0;
+    for (int l = 0; l < n; ++l) {
+        CG_REQUIRE(W[l] && Wt[l] && W[l] != Wt[l], "reindex_weights_batch: NULL argument (or in place), layer %d", l);
+        CG_REQUIRE(Fin[l] > 0 && K[l] > 0 && Fout[l] > 0 && (int64_t)Fin[l] * K[l] * Fout[l] < (1ll << 30),
+                   "reindex_weights_batch: bad shape, layer %d", l);
+        b.W[l] = W[l]; b.Wt[l] = Wt[l]; b.Fin[l] = Fin[l]; b.K[l] = K[l]; b.Fout[l] = Fout[l];
+        most = std::max(most, Fin[l] * K[l] * Fout[l]);
+    }
+    note_dispatch("reindex_weights_batch_kernel");
+    hipLaunchKernelGGL(reindex_weights_batch_kernel, dim3(std::min((most + 255) / 256, 64), n), dim3(256), 0, stream, b);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -1142,6 +1142,16 @@ class cgcnn(base_model):
         per_vertex = getattr(self.brelu, '__func__', None) is cgcnn.b2relu
         pool_kind = POOL_AVG if getattr(self.pool, '__func__', None) is cgcnn.apool1 else POOL_MAX
         stack = None
+        # training: the weights of every layer that forms its input gradient by the forward recurrence on dy (ops.dx_by_forward),
+        # re-indexed in ONE launch here -- they are constant within the step -- instead of one launch per layer inside backward
+        Wts = {}
+        if self.training_mode and torch.is_grad_enabled():
+            fins = [x.shape[1]] + list(self.F[:-1])
+            idxs = [i for i in range(1, nl) if ops.dx_by_forward_shape(self.graphs[i], fins[i], self.K[i], self.F[i], self.contraction)]
+            if idxs:
+                outs = ops.reindex_weights_batch([self._params['conv%d/weights' % (i + 1)] for i in idxs],
+                                                 [(fins[i], self.K[i], self.F[i]) for i in idxs])
+                Wts = dict(zip(idxs, outs))
         for i in range(nl):
             g = self.graphs[i]
             W = self._params['conv%d/weights' % (i + 1)]
@@ -1161,7 +1171,7 @@ class cgcnn(base_model):
             x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
                               BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out,
                               dW=W.grad if direct else None, dbias=b.grad if direct else None,
-                              precision=self.contraction, done=done, mean=mean, pool_maps=self._pool_maps[i])
+                              precision=self.contraction, done=done, mean=mean, pool_maps=self._pool_maps[i], Wt=Wts.get(i))
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
         if mean:

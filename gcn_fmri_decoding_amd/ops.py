@@ -453,6 +453,7 @@ class ChebConv(torch.autograd.Function):
             ctx.done = bufs.done
             ctx.precision = 'f32'
             ctx.pool_maps = None
+            ctx.Wt = bufs.Wt
             return y[:, :M]                   # the logical [B, M] mean (row stride Mp): its gradient arrives dense
         if out is None:
             out = plane_empty(B, Fout, Mo, x.device)
@@ -482,6 +483,7 @@ class ChebConv(torch.autograd.Function):
             ctx.done = bufs.done
             ctx.precision = precision
             ctx.pool_maps = maps
+            ctx.Wt = bufs.Wt
             return out
         if pool > 1 and (pool_kind == POOL_MAX or relu):
             argmax = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
@@ -503,6 +505,7 @@ class ChebConv(torch.autograd.Function):
         ctx.done = bufs.done if bufs is not None else None
         ctx.precision = precision
         ctx.pool_maps = None
+        ctx.Wt = bufs.Wt if bufs is not None else None
         return out
 
     @staticmethod
@@ -540,6 +543,7 @@ class ChebConv(torch.autograd.Function):
         ctx.done = bufs.done if bufs is not None else None
         ctx.precision = 'f32'
         ctx.pool_maps = None
+        ctx.Wt = None
         return out
 
     @staticmethod
@@ -694,8 +698,10 @@ class ChebConv(torch.autograd.Function):
         elif by_fwd:
             _lib.check(_launch('recurrence_fwd_t', 4.0 * B * M * Fout * K, 0.0, lambda: lib.chebgcn_recurrence_fwd_t(
                 g.handle, _p(dy), _p(gstack), B, Fout, K, _stream())), 'recurrence_fwd_t')
-            Wt = torch.empty((Fout * K, Fin), dtype=torch.float32, device=dev)                 # W'[fo*K + k][fin] = W[fin*K + k][fo]
-            _lib.check(lib.chebgcn_reindex_weights(_p(Wc), _p(Wt), Fin, K, Fout, _stream()), 'reindex_weights')
+            Wt = ctx.Wt                                                                        # W'[fo*K + k][fin] = W[fin*K + k][fo]
+            if Wt is None or tuple(Wt.shape) != (Fout * K, Fin):
+                Wt = torch.empty((Fout * K, Fin), dtype=torch.float32, device=dev)
+                _lib.check(lib.chebgcn_reindex_weights(_p(Wc), _p(Wt), Fin, K, Fout, _stream()), 'reindex_weights')
             dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
             contract_fwd_into(gstack, Wt, None, BIAS_NONE, dx, None, B, M, Fout, K, Fin, 1, POOL_MAX, False, ctx.precision,
                               what='contract_bwd_x')
@@ -750,9 +756,12 @@ class Buffers:
     kernels are enqueued (dist.DataParallel starts the layer's all-reduce from it).  ``mean``: the
     layer is followed by ``tf.reduce_mean(x, -1)`` (models_gcn.py:673) and returns that mean, storage
     [B, Mp], instead of its output (chebgcn_contract_fwd_mean; the gradients read one plane per window)."""
-    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean', 'grad_mode', 'pool_maps')
+    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean', 'grad_mode', 'pool_maps', 'Wt')
 
-    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None):
+    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None, Wt=None):
+        # the layer's weights already re-indexed for the forward form of the input gradient (reindex_weights_batch: the model
+        # does every layer in one launch in front of the backward pass); None: the backward pass re-indexes them itself
+        self.Wt = Wt
         self.stack, self.out, self.dW, self.dbias, self.precision, self.done = stack, out, dW, dbias, precision, done
         # a pooled layer whose input and / or output vertices are not in the coarsening's tree order: (pmap, smap), int32 device
         # tensors of M entries each (``pool_maps``); the layer then pools through them (chebgcn_pool_gather_fwd / _scatter_bwd)
@@ -792,13 +801,43 @@ def pool_maps(pool, src_order, dst_order, M, device):
     return (torch.as_tensor(pmap.astype(np.int32)).to(dev), torch.as_tensor(smap.astype(np.int32)).to(dev))
 
 
+def dx_by_forward_shape(graph, Fin, K, Fout, precision):
+    """Does a layer of this shape form its input gradient by the forward recurrence on dy (``dx_by_forward``; the shape part of
+    the rule in ``ChebConv.backward``)?  Such layers read the re-indexed weights W'[fo*K + k][fin] = W[fin*K + k][fo]."""
+    return bool(dx_by_forward and K > 1 and Fout <= Fin and resolve_precision(precision, Fin, K, Fout) != 'bf16' and graph.ordered)
+
+
+def reindex_weights_batch(Ws, shapes):
+    """``[W'_l]`` for the layers ``Ws`` ([Fin*K, Fout] each, ``shapes`` = [(Fin, K, Fout)]) in ONE launch
+    (chebgcn_reindex_weights_batch): W'[fo*K + k][fin] = W[fin*K + k][fo]."""
+    n = len(Ws)
+    if n == 0:
+        return []
+    if n > 16:
+        return reindex_weights_batch(Ws[:16], shapes[:16]) + reindex_weights_batch(Ws[16:], shapes[16:])
+    _require_cuda(*Ws)
+    Ws = [w.detach() if w.is_contiguous() else w.detach().contiguous() for w in Ws]
+    total = sum(fi * k * fo for fi, k, fo in shapes)
+    flat = torch.empty(total, dtype=torch.float32, device=Ws[0].device)
+    outs, at = [], 0
+    for fi, k, fo in shapes:
+        outs.append(flat[at:at + fi * k * fo].view(fo * k, fi))
+        at += fi * k * fo
+    arr_p = (C.c_void_p * n)
+    arr_i = (C.c_int * n)
+    _lib.check(_lib.lib().chebgcn_reindex_weights_batch(
+        n, arr_p(*[w.data_ptr() for w in Ws]), arr_p(*[o.data_ptr() for o in outs]), arr_i(*[s[0] for s in shapes]),
+        arr_i(*[s[1] for s in shapes]), arr_i(*[s[2] for s in shapes]), _stream()), 'reindex_weights_batch')
+    return outs
+
+
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
-              dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None):
+              dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None, Wt=None):
     """``precision``: arithmetic of the contraction and of its two gradients ('auto': resolve_precision; 'f32', 'bf16', 'bf16x3':
     chebgcn_contract_fwd_bf16 / _bwd_x_bf16 / _bwd_w_bf16 with 1 or 3 passes); storage, the recurrence, its adjoint
     and the bias / ReLU / pooling gradients stay fp32."""
     precision = resolve_precision(precision, x.shape[1], K, W.shape[1])
-    bufs = Buffers(stack, out, dW, dbias, precision, done, mean, pool_maps if pool > 1 else None)
+    bufs = Buffers(stack, out, dW, dbias, precision, done, mean, pool_maps if pool > 1 else None, Wt)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 
@@ -861,7 +900,7 @@ class FeatureMean(torch.autograd.Function):
         return dx, None
 
 
-FC_BWD_MAX_INNER = 4096      # beyond: the gradients stay on the vendor GEMMs (tools/probes/fc_small_probe.py)
+FC_BWD_MAX_INNER = int(os.environ.get('CHEBGCN_FC_BWD_MAX_INNER', 4096))      # beyond: the gradients stay on the vendor GEMMs (tools/probes/fc_small_probe.py)
 FC_FWD_MAX_INNER = int(os.environ.get('CHEBGCN_FC_FWD_MAX_INNER', 1 << 20))     # A/B knob for bench runs
 
 

@@ -117,6 +117,10 @@ int chebgcn_recurrence_fwd_t(const chebgcn_graph* g, const float* x, float* stac
 /* the re-indexed weights of that contraction: Wt[(fo*K + k)*Fin + fin] = W[(fin*K + k)*Fout + fo]  ([Fout*K][Fin] from
  * [Fin*K][Fout], both row-major; one small launch -- the weights change every step) */
 int chebgcn_reindex_weights(const float* W, float* Wt, int Fin, int K, int Fout, chebgcn_stream stream);
+/* The same for n <= 16 layers in one launch (host arrays of device pointers and shapes): the weights are constant within a
+ * training step, cgcnn re-indexes every layer that forms its input gradient this way once, in front of the backward pass. */
+int chebgcn_reindex_weights_batch(int n, const float* const* W, float* const* Wt, const int* Fin, const int* K,
+                                  const int* Fout, chebgcn_stream stream);
 
 /* ---- Chebyshev recurrence, adjoint: gradient of the above wrt x -----------------
  * (TF autodiff of models_gcn.py:598-610, reached from :298-303.)

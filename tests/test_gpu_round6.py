@@ -294,3 +294,18 @@ def test_fit_tracks_float64_oracle_under_auto(dev, contraction, tmp_path, monkey
     record_measured('fit_tracks_float64_oracle[%s]' % contraction, loss_average_series=e_series, validation_losses=e_val,
                     final_loss_average=float(la[-1]))
     assert e_series <= 5e-3 and e_val <= 5e-3, (contraction, e_series, e_val)
+
+
+def test_reindex_weights_batch_is_the_index_map(dev):
+    """chebgcn_reindex_weights_batch: every layer's W'[fo*K + k][fin] = W[fin*K + k][fo] in one launch, bit for bit (more than
+    16 layers: two launches)."""
+    from gcn_fmri_decoding_amd import _lib, ops
+    shapes = [(32, 5, 32), (64, 25, 64), (128, 5, 96), (15, 20, 8), (1, 1, 1)] + [(3 + i, 2, 2 + i) for i in range(14)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    Ws = [torch.randn((fi * k, fo), generator=gen, device=dev) for fi, k, fo in shapes]
+    outs = ops.reindex_weights_batch(Ws, shapes)
+    assert _lib.last_dispatch() == 'reindex_weights_batch_kernel' and len(outs) == len(shapes)
+    for W, Wt, (fi, k, fo) in zip(Ws, outs, shapes):
+        ref = W.view(fi, k, fo).permute(2, 1, 0).reshape(fo * k, fi)
+        assert torch.equal(Wt, ref), (fi, k, fo)

@@ -33,7 +33,9 @@ for src, dst in [('bench_line.json', '%s_bench_line.json'), ('bench_kernel_stats
                  ('refshape_n360_line.json', '%s_refshape_n360_line.json'),
                  ('config4_layer.txt', '%s_config4_layer.txt'), ('ord_sizes.txt', '%s_ordered_recurrence_sizes.txt'),
                  ('wide_f32_vs_bf16x3.txt', '%s_wide_f32_vs_bf16x3.txt'), ('pool6.txt', '%s_pool6.txt'),
-                 ('pool6_kernel_stats.csv', '%s_pool6_kernel_stats.csv'),
+                 ('pool6_kernel_stats.csv', '%s_pool6_kernel_stats.csv'), ('kbench_pool6_level0.txt', '%s_kbench_pool6_level0.txt'),
+                 ('pool6_level0_recurrence_kernel_stats.csv', '%s_pool6_level0_recurrence_kernel_stats.csv'),
+                 ('events_under_rocprof_pool6_level0.txt', '%s_events_under_rocprof_pool6_level0.txt'),
                  ('ordered_n6000_kernel_stats.csv', '%s_ordered_n6000_kernel_stats.csv'),
                  ('ordered_n13000_kernel_stats.csv', '%s_ordered_n13000_kernel_stats.csv'),
                  ('events_under_rocprof_ordered_n6000.txt', '%s_events_under_rocprof_ordered_n6000.txt'),

@@ -72,6 +72,11 @@ for n in 6000 13000; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/profo_$n -o o -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --nodes $n --B 256 --iters 50 --kernels recurrence_fwd_inplace recurrence_bwd > $out/events_under_rocprof_ordered_n$n.txt 2>&1
   find $out/profo_$n -name "*kernel_stats.csv" -exec cp {} $out/ordered_n${n}_kernel_stats.csv \;
 done
+# round 6: the level-0 graph of the six-level pooling network (12672 vertices, 10000 active) in length order: the ordered kernel
+# with NQ = NG + 1 + cheb_ord_tail_kernel, at the shapes of that network's first two layers' launches
+python3 tools/kbench.py --levels 6 --B 64 --fin 32 --fout 32 --K 10 --iters 20 --kernels recurrence_fwd_inplace recurrence_bwd recurrence_fwd_t > $out/kbench_pool6_level0.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/profl0 -o l0 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --levels 6 --B 64 --fin 32 --fout 32 --K 10 --iters 30 --kernels recurrence_fwd_inplace recurrence_fwd_t > $out/events_under_rocprof_pool6_level0.txt 2>&1
+find $out/profl0 -name "*kernel_stats.csv" -exec cp {} $out/pool6_level0_recurrence_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profp -o p -- python3 $GRAFT_REPO_ROOT/tools/pool6_probe.py > $out/profp.log 2>&1
 find $out/profp -name "*kernel_stats.csv" -exec cp {} $out/pool6_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profr -o rs -- python3 $GRAFT_REPO_ROOT/tools/refshape.py --nodes 360 > $out/profr.log 2>&1
@@ -80,6 +85,6 @@ grep "^{\"shape\"" $out/profr.log | tail -1 > $out/refshape_n360_line.json
 # what the memory system and the fp32 matrix pipe give with nothing else going on (EXPERIMENTS.md 3b)
 for b in 8 16 32 64; do $GRAFT_REPO_ROOT/tools/probes/hbm_stream_probe $b; done > $out/hbm_stream_probe.txt 2>&1
 $GRAFT_REPO_ROOT/tools/probes/mfma_f32_probe > $out/mfma_f32_probe.txt 2>&1
-rm -rf $out/prof $out/profs $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr $out/profo_* $out/profp
+rm -rf $out/prof $out/profs $out/profl0 $out/prof4 $out/prof4_* $out/prof5 $out/profn_* $out/profr $out/profo_* $out/profp
 cp gpurun_out/parity_measured.jsonl $out/ 2>/dev/null
 ls -la $out
