@@ -610,7 +610,15 @@ class base_model(object):
                 self.global_step += 1
                 return self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum), loss_average
             self._drop_step_graph()
-            sg = self._sg = self._capture_step(x_storage, labels)
+            try:
+                sg = self._sg = self._capture_step(x_storage, labels)
+            except Exception as e:                       # a failed capture: say so and keep training eagerly
+                import warnings
+                warnings.warn('cgcnn: capturing the training step as a HIP graph failed (%s: %s); the step stays eager'
+                              % (type(e).__name__, e))
+                self._step_graph_on = False
+                self._sg = None
+                return self.train_step(self.as_internal(x_storage), labels)
         if sg['x'].data_ptr() != x_storage.data_ptr():
             sg['x'].copy_(x_storage)
         sg['labels'].copy_(labels)

@@ -74,7 +74,7 @@ for n in 6000 13000; do
 done
 # round 6: the level-0 graph of the six-level pooling network (12672 vertices, 10000 active) in length order: the ordered kernel
 # with NQ = NG + 1 + cheb_ord_tail_kernel, at the shapes of that network's first two layers' launches
-python3 tools/kbench.py --levels 6 --B 64 --fin 32 --fout 32 --K 10 --iters 20 --kernels recurrence_fwd_inplace recurrence_bwd recurrence_fwd_t > $out/kbench_pool6_level0.txt 2>&1
+python3 $GRAFT_REPO_ROOT/tools/kbench.py --levels 6 --B 64 --fin 32 --fout 32 --K 10 --iters 20 --kernels recurrence_fwd_inplace recurrence_bwd recurrence_fwd_t > $out/kbench_pool6_level0.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profl0 -o l0 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py --levels 6 --B 64 --fin 32 --fout 32 --K 10 --iters 30 --kernels recurrence_fwd_inplace recurrence_fwd_t > $out/events_under_rocprof_pool6_level0.txt 2>&1
 find $out/profl0 -name "*kernel_stats.csv" -exec cp {} $out/pool6_level0_recurrence_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/profp -o p -- python3 $GRAFT_REPO_ROOT/tools/pool6_probe.py > $out/profp.log 2>&1
