@@ -159,7 +159,11 @@ inline const Ell& pick_ell(const chebgcn_graph* g, bool adjoint, int nplanes, in
     // isolated vertices per thread (iso_max512: the coarsening's fake vertices), where the four-plane kernel patches them in
     // from memory once per order.  Measured on the level-0 graph of the six-level pooling network (M = 12672, 2672 fake
     // vertices, batch 64, K = 20 and 10): forward 0.97 ms on two planes, 1.49 ms on four; adjoint 0.61 ms on two, 0.43 on four.
-    if (g->M > 10752) return (adjk || e.iso_max512 <= 4) ? e : (adjoint ? g->adj2 : g->fwd2);
+    // Small launches (fewer plane groups than CUs: predict() tails, B*Fin/4 < 256) keep the two-plane image there as well --
+    // measured in round 6 at K = 10, Fin = 32 (profiles/r06_pick_ell_small_launches.txt): adjoint at batch 2 / 4 / 8 0.155 / 0.163 /
+    // 0.169 ms on four planes against 0.143 / 0.146 / 0.152 ms on two; batch 1 the same either way.
+    if (g->M > 10752)
+        return ((adjk || e.iso_max512 <= 4) && (nplanes + 3) / 4 >= g->num_cus) ? e : (adjoint ? g->adj2 : g->fwd2);
     // few groups per CU: the two-plane image keeps more workgroups in flight.  Measured in the configs[1] step
     // (M = 10466, 2048 planes per launch): both directions on two planes 4.235 ms, adjoint on four 4.27, both on
     // four 4.37 -- although the isolated adjoint launch is 5 % faster on four planes (tools/kbench.py)

@@ -643,6 +643,14 @@ class base_model(object):
         before = ops.cache_keys()
         cgcnn._captures = getattr(cgcnn, '_captures', 0) + 1
         ops.capture_tag = cgcnn._captures
+        # No cyclic garbage collection while the capture is open: a model that became garbage earlier (models are cyclic: bound
+        # layer methods) is collected whenever an allocation triggers the collector -- on THIS thread, possibly inside the capture --
+        # and its device graphs' finalizers call hipFree, which is not permitted while a stream captures and invalidates it
+        # (round 6: reproduced with a discarded twin model; the rare first-capture failures of round 5 were the same thing).
+        # torch.cuda.graph() collects once on entry; the collector comes back on when the capture is closed.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             # 'thread_local': only what THIS thread does between begin and end can fail the capture.  The backward pass runs on
             # autograd's device thread; under the default ('global') any potentially-unsafe runtime call of any other thread
@@ -653,6 +661,8 @@ class base_model(object):
                 sg['loss_average'] = self._step_body(self.as_internal(sg['x']), sg['labels'], sg['lr_t'], sg['ema_c'][0])
         finally:
             ops.capture_tag = None
+            if gc_was_on:
+                gc.enable()
         sg['graph'] = graph
         sg['cache_keys'] = ops.cache_keys() - before       # scratch allocated on the capture streams: it dies with this graph
         return sg

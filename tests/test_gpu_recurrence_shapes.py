@@ -260,6 +260,8 @@ CALLER_ORDER = [
     ((1500, 1, 0), (4, 8, 2, 256)), ((2000, 1, 0), (4, 8, 3, 256)), ((2000, 1, 2), (2, 8, 3, 512)), ((4000, 1, 2), (2, 8, 3, 768)),
     ((6000, 1, 2), (2, 11, 4, 768)), ((10000, 1, 2), (2, 14, 4, 768)), ((10500, 1, 2), (2, 24, 7, 512)),
     ((13000, 1, 2), (2, 32, 9, 512)), ((16000, 1, 2), (2, 40, 11, 512)),
+    # automatic plane choice beyond 10752 vertices, small launch (7 planes: fewer plane groups than CUs): two planes in both directions
+    ((10000, 6, 0), (2, 32, 9, 512)),
     # recurrence4.hip: <entries, rows per thread, pieces per thread, 512, adjoint, isolated vertices in registers>
     ((2600, 1, 4), ('cheb4_kernel<5120,10,3,512,false,true>', 'cheb4_kernel<5120,10,3,512,true,false>')),
     ((5000, 3, 4), ('cheb4_kernel<5120,10,3,512,false,false>', 'cheb4_kernel<5120,10,3,512,true,false>')),

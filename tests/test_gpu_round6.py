@@ -205,6 +205,22 @@ def test_relabelled_levels_are_invisible_with_pooling(dev, name, pool_kind):
         lc = ref.inference(x, 1).cpu().numpy()
         ld = rel.inference(x, 1).cpu().numpy()
     assert np.abs(lc - ld).max() <= 1e-5 * np.abs(lc).max()
+    # the relabelled network's step captured as a HIP graph (the mapped pooling kernels, their workspaces and the batched weight
+    # re-indexing inside the capture) replays bit-identically to the eager step of a twin
+    os.environ['CHEBGCN_VERTEX_ORDER'] = 'length!'
+    try:
+        twin = models_gcn.cgcnn.from_checkpoint(rel.state_dict(), config={'device': dev})
+    finally:
+        os.environ.pop('CHEBGCN_VERTEX_ORDER', None)
+    assert twin._relabelled
+    twin._loss_ema = None if rel._loss_ema is None else rel._loss_ema.clone()
+    twin.global_step = rel.global_step
+    rel.enable_step_graph(True)
+    for _ in range(4):
+        a = rel.train_step(xs, labels)[1]
+        b = twin.train_step(xs, labels)[1]
+    torch.cuda.synchronize()
+    assert rel._sg is not None and torch.equal(rel._flat, twin._flat) and float(a) == float(b)
 
 
 def test_contraction_value_is_validated(dev):
