@@ -184,7 +184,7 @@ pool_gather_fwd_kernel(const float* __restrict__ y, const int32_t* __restrict__ 
     }
     __syncthreads();
     const float inv = 1.0f / (float)pool;
-    if (pool == 4 && pmap) {
+    if (pool == 4 && pmap && (reinterpret_cast<uintptr_t>(pmap) & 15) == 0) {
         // the common case (p = 4: one 16-byte record of the map per pooled vertex), four pooled vertices per thread in flight
         for (int m0 = threadIdx.x; m0 < Mpo; m0 += 4 * nt) {
             int4 pm[4];

@@ -76,13 +76,16 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t slab_rsrc(const float* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
 }
+#ifndef CG_ORD_ST_AUX
+#define CG_ORD_ST_AUX 2      // cache policy of the slab stores (2 = nt); experiment: 0 (do they stay in the Infinity Cache for the contraction?)
+#endif
 __device__ __forceinline__ float4 ldp(rsrc_t r, unsigned voff, unsigned soff) {
     const f32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void stp(rsrc_t r, unsigned voff, unsigned soff, float4 v) {
     const f32x4 t = {v.x, v.y, v.z, v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, CG_ORD_ST_AUX);
     // a 16-byte buffer store with an SGPR offset still reads its data registers while the following instructions issue
     // (hipcc pads the hazard for the immediate-offset form only): the asm keeps the data live across the wait states
     asm volatile("s_nop 1" : : "v"(t) : "memory");
