@@ -245,14 +245,16 @@ pool_gather_fwd_kernel(const float* __restrict__ y, const int32_t* __restrict__ 
 // and stores whole 16-byte pieces of dy.  The bias gradient of a vertex is a register sum over the part's windows; the NPB
 // partial sums are added in part order by pool_bias_reduce_kernel (fixed order: bit-reproducible, no atomics).
 // `out` (optional): the forward result, read where `sel` carries no dead flag (the fused contraction epilogue's argmax byte).
-template <int BIAS, bool HAS_OUT, int EPT>
-__global__ void __launch_bounds__(512, 4)        // (two workgroups per CU: four waves per SIMD)
+// NT = 512 (two workgroups per CU) or 1024 (one: planes of more than 8192 vertices -- with 512 threads their source quads were
+// split between two workgroups that each staged the whole pooled plane: 1.4x the algorithmic HBM traffic by the counters)
+template <int BIAS, bool HAS_OUT, int EPT, int NT>
+__global__ void __launch_bounds__(NT, 4)         // (four waves per SIMD: 128 registers)
 pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, const uint8_t* __restrict__ sel,
                         const int32_t* __restrict__ smap, float* __restrict__ dy, float* __restrict__ part, int B, int M, int Mp,
                         int F, int lgp, int pool_kind, int relu, int Mo, int Mpo) {
     extern __shared__ __attribute__((aligned(16))) float2 ps_ent[];            // [2][Mpo]
     constexpr int QPT = 4;                                 // source quads per thread and pass
-    // EPT: pooled vertices a thread stages per window (prefetched one window ahead while Mpo <= EPT * 512): 2 or 8
+    // EPT: pooled vertices a thread stages per window (prefetched one window ahead while Mpo <= EPT * NT): 2, 4 or 8
     const int f = blockIdx.y, pb = blockIdx.x, NPB = gridDim.x;
     const int b0 = (int)((long long)B * pb / NPB), b1 = (int)((long long)B * (pb + 1) / NPB);
     const int Mq = Mp >> 2, pmask = (1 << lgp) - 1;
@@ -261,7 +263,7 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
     const int qpz = (Mq + (int)gridDim.z - 1) / (int)gridDim.z;
     const int qs = (int)blockIdx.z * qpz, qe = min(Mq, qs + qpz);
     const float inv = 1.0f / (float)(1 << lgp);
-    const bool pre = Mpo <= EPT * 512;
+    const bool pre = Mpo <= EPT * NT;
     const bool is_max = pool_kind == CHEBGCN_POOL_MAX;
     // One pooled vertex of a window: {gradient (scaled for the average), selection byte with the dead flag}.  Requests and
     // their use are separate and free of data-dependent branches: every load of a window is in flight before the first is used
@@ -284,12 +286,12 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
         const bool live = j < Mo;
         return make_float2(live ? g : 0.f, __int_as_float(live ? sb : 0xFF));
     };
-    for (int q0 = qs; q0 < qe; q0 += QPT * 512) {           // (more than 8192 vertices per split: another pass over the windows)
+    for (int q0 = qs; q0 < qe; q0 += QPT * NT) {           // (more than 8192 vertices per split: another pass over the windows)
         int code[QPT][4];
         float4 acc[QPT];
 #pragma unroll
         for (int u = 0; u < QPT; ++u) {
-            const int q = q0 + u * 512 + (int)threadIdx.x;
+            const int q = q0 + u * NT + (int)threadIdx.x;
             acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -301,7 +303,7 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
         int ns[EPT];
         if (pre && b0 < b1) {
 #pragma unroll
-            for (int k = 0; k < EPT; ++k) request(b0, k * 512 + (int)threadIdx.x, ng[k], ns[k], no[k]);     // (unconditional: clamped)
+            for (int k = 0; k < EPT; ++k) request(b0, k * NT + (int)threadIdx.x, ng[k], ns[k], no[k]);     // (unconditional: clamped)
         }
         int buf = 0;
         for (int b = b0; b < b1; ++b) {
@@ -309,11 +311,11 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
             if (pre) {
 #pragma unroll
                 for (int k = 0; k < EPT; ++k) {
-                    const int j = k * 512 + (int)threadIdx.x;
+                    const int j = k * NT + (int)threadIdx.x;
                     if (j < Mpo) ent[j] = finish(j, ng[k], ns[k], no[k]);
                 }
             } else {
-                for (int j = threadIdx.x; j < Mpo; j += 512) {
+                for (int j = threadIdx.x; j < Mpo; j += NT) {
                     float g, o;
                     int sb;
                     request(b, j, g, sb, o);
@@ -325,11 +327,11 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (pre && b + 1 < b1) {
 #pragma unroll
-                for (int k = 0; k < EPT; ++k) request(b + 1, k * 512 + (int)threadIdx.x, ng[k], ns[k], no[k]);
+                for (int k = 0; k < EPT; ++k) request(b + 1, k * NT + (int)threadIdx.x, ng[k], ns[k], no[k]);
             }
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
-                const int q = q0 + u * 512 + (int)threadIdx.x;
+                const int q = q0 + u * NT + (int)threadIdx.x;
                 if (q < qe) {
                     float2 e[4];
 #pragma unroll
@@ -351,7 +353,7 @@ pool_scatter_bwd_kernel(const float* __restrict__ dout, const float* __restrict_
         if (BIAS != CHEBGCN_BIAS_NONE) {
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
-                const int q = q0 + u * 512 + (int)threadIdx.x;
+                const int q = q0 + u * NT + (int)threadIdx.x;
                 if (q < qe) *reinterpret_cast<float4*>(part + ((size_t)pb * F + f) * Mp + 4 * q) = acc[u];
             }
         }
@@ -795,25 +797,32 @@ static int pool_scatter_launch(const float* dout, const float* out, const uint8_
         part = static_cast<float*>(workspace);
     }
     const size_t lds = (size_t)2 * Mpo * sizeof(float2);
-    // (source quads split between up to four workgroups where batch parts x filters leave fewer than two workgroups per CU)
-    // ... and where one workgroup's four quads per thread do not cover the plane
-    const int VS = std::max(std::min(8, (Mp / 4 + 2047) / 2048), std::max(1, std::min(std::min(4, (512 + NPB * F - 1) / (NPB * F)), (Mp / 4 + 511) / 512)));
+    // planes of more than 8192 vertices: 1024 threads, four quads each, cover 16384 vertices -- one workgroup stages the pooled
+    // plane of a window once; smaller planes: 512 threads, the source quads split between up to four workgroups where batch
+    // parts x filters leave fewer than two workgroups per CU (and beyond 16384 vertices per plane: as many as it takes)
+    const bool big = Mp / 4 > 2048;
+    const int nth = big ? 1024 : 512;
+    const int VS = big ? std::min(8, (Mp / 4 + 4 * nth - 1) / (4 * nth))
+                       : std::max(1, std::min(std::min(4, (512 + NPB * F - 1) / (NPB * F)), (Mp / 4 + 511) / 512));
     const dim3 grid(NPB, F, VS);
-#define CG_PSB3(BK, HO, EP)                                                                                                     \
+#define CG_PSB4(BK, HO, EP, NTH)                                                                                                \
     do {                                                                                                                        \
         static size_t lds_set = 0;                                                                                              \
         if (lds > lds_set) {                                                                                                    \
-            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_scatter_bwd_kernel<BK, HO, EP>),                      \
+            CG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pool_scatter_bwd_kernel<BK, HO, EP, NTH>),                 \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
             lds_set = lds;                                                                                                      \
         }                                                                                                                       \
-        hipLaunchKernelGGL((pool_scatter_bwd_kernel<BK, HO, EP>), grid, dim3(512), lds, stream, dout, out, sel, smap, dy, part, B, M, Mp, F, \
-                           lgp, pool_kind, relu, Mo, Mpo);                                                                      \
+        hipLaunchKernelGGL((pool_scatter_bwd_kernel<BK, HO, EP, NTH>), grid, dim3(NTH), lds, stream, dout, out, sel, smap, dy, part, B, M, \
+                           Mp, F, lgp, pool_kind, relu, Mo, Mpo);                                                               \
     } while (0)
 #define CG_PSB2(BK, HO)                                                                                                         \
     do {                                                                                                                        \
-        if (Mpo <= 1024) CG_PSB3(BK, HO, 2);                                                                                    \
-        else CG_PSB3(BK, HO, 8);                                                                                                \
+        if (big) {                                                                                                              \
+            if (Mpo <= 4096) CG_PSB4(BK, HO, 4, 1024);                                                                          \
+            else CG_PSB4(BK, HO, 8, 1024);                                                                                      \
+        } else if (Mpo <= 1024) CG_PSB4(BK, HO, 2, 512);                                                                        \
+        else CG_PSB4(BK, HO, 8, 512);                                                                                           \
     } while (0)
 #define CG_PSB(BK)                                                                                                              \
     do {                                                                                                                        \
@@ -825,7 +834,7 @@ static int pool_scatter_launch(const float* dout, const float* out, const uint8_
     else if (bias_kind == CHEBGCN_BIAS_FILTER) CG_PSB(CHEBGCN_BIAS_FILTER);
     else CG_PSB(CHEBGCN_BIAS_NONE);
 #undef CG_PSB2
-#undef CG_PSB3
+#undef CG_PSB4
 #undef CG_PSB
     CG_HIP(hipGetLastError());
     if (bias_kind == CHEBGCN_BIAS_VERTEX) {
