@@ -523,7 +523,9 @@ def main():
                          'configs[3] (K=25, Fin=64, batch 64), the wide layer of configs[4] (Fin=60, Fout=256) forward + '
                          'backward in fp32 / bf16 / split bf16, the reference\'s own training shape (atlas graph, K=10, batch 128) '
                          'and the data-parallel plumbing on a world of one; N=1 only')
-    ap.add_argument('--overlap-bwd-w', type=int, default=1, help='contract_bwd_w on a second stream (ops.overlap_bwd_w)')
+    ap.add_argument('--overlap-bwd-w', type=int, default=-1,
+                    help="contract_bwd_w on a second stream (ops.overlap_bwd_w): 1 / 0 force it, -1 = the library's default ('auto': wide "
+                         'layers only)')
     ap.add_argument('--repeats', type=int, default=3,
                     help='the timed region (exactly --steps steps) is run this many times; `value` comes from the FIRST, the '
                          'others are reported beside it (ms_per_step_repeats)')
@@ -566,7 +568,8 @@ def main():
 
     from gcn_fmri_decoding_amd import models_gcn, ops
     from gcn_fmri_decoding_amd import dist as gdist
-    ops.overlap_bwd_w = bool(args.overlap_bwd_w)
+    if args.overlap_bwd_w >= 0:
+        ops.overlap_bwd_w = bool(args.overlap_bwd_w)
 
     Ls, perm = load_graph(args.nodes, 1, rank, world, barrier)
     cfg = dict(F=[32] * 6, K=[args.korder] * 6, p=[1] * 6, M=[512, 256, 22], channel=args.block_dura)

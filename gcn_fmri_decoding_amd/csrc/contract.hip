@@ -18,6 +18,7 @@
 // r feeds accumulator r (vertex <-> MFMA column is a free permutation).  The A operand
 // (a 32 x 2 sliver of W) is 8 B per lane from L1/L2.
 #include <algorithm>
+#include <cstdlib>
 #include "contract_common.h"
 #ifndef CG_DY_NT
 #define CG_DY_NT 0      // dy is read by three kernels of a layer's backward (bias, bwd_w, bwd_x): cached loads, 3.83 -> 3.795 ms per step
@@ -904,7 +905,10 @@ static bool small_launch(int B, int M) { return ((M + 511) / 512) * B < 2 * num_
 static int bw_grid_x(int B, int M) {
     const int cus = num_cus();
     int total = B * ((M + 63) / 64);
-    int gx = cus * 3;                          // 48 KB of LDS per workgroup -> three per CU
+    // 48 KB of LDS per workgroup would allow three per CU (rounds 3-5); two measure faster: 0.111 -> 0.098 ms at the bench launch
+    // (0.55 -> 0.62 of the HBM roofline; 640: 0.123, 384: 0.112, 256: 0.140 -- EXPERIMENTS 8.6)
+    int gx = cus * 2;
+    if (const char* e = getenv("CHEBGCN_BWW_GX")) gx = atoi(e) > 0 ? atoi(e) : gx;                  // (experiment knob)
     // small launches: at least four chunks per workgroup -- every workgroup leaves a partial of the whole row-tile group
     // (20 KB at five row tiles) that the reduce kernels read back; one chunk per workgroup made the partials of an
     // atlas-sized layer (N = 360, batch 128) 31 MB and reduce_partials_stage1 18 us beside a 38 us kernel

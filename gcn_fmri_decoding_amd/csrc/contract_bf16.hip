@@ -21,6 +21,7 @@
 // no LDS staging, no transpose.  The four waves of a workgroup read the same rows at the same
 // time (L1 hits); the A operand comes from a bf16 image of W packed once per call in fragment
 // order (16 B per lane and tile), resident in L2.
+#include <cstdlib>
 #include <type_traits>
 
 #include "contract_common.h"
@@ -920,6 +921,7 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
         p.gz = (Fout + 255) / 256;
         const long long total = (long long)B * ((M + 15) / 16);
         long long gx = cus / (p.gy * p.gz);   // 144 KB of LDS: one workgroup per CU
+        if (const char* e = getenv("CHEBGCN_BWB_WIDE_GX")) gx = atoll(e) > 0 ? atoll(e) : gx;       // (experiment knob)
         if (gx > total) gx = total;
         p.gx = gx < 1 ? 1 : (int)gx;
         p.per = (size_t)10 * 8 * 16 * 64;
@@ -931,7 +933,13 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
     p.gy = (ntiles + p.rt - 1) / p.rt;
     p.gz = (Fout + 32 * p.ct - 1) / (32 * p.ct);
     const long long total = (long long)B * ((M + 63) / 64);
-    long long gx = 2ll * cus;                 // <= 56 KB of LDS and <= 256 registers: two workgroups per CU
+    // One workgroup per CU (registers and LDS would allow two -- rounds 2-5 launched 2 * cus): every workgroup leaves a partial of
+    // its whole tile group that two reduce kernels read back, and at 3200 chunks (the 3168-vertex level of the pooling network)
+    // 512 workgroups' partials were 38 % of the operands' bytes.  Measured, same box (EXPERIMENTS 8.6): 64*10 -> 64 at M = 3168
+    // 0.131 -> 0.118 ms, at M = 10466 0.467 -> 0.422; 32*10 -> 64 0.229 -> 0.215; 64*25 -> 64 1.116 -> 1.097 ms.  Grids that are
+    // not a multiple of 128 lose a quarter (133, 266 measured: the chunk -> workgroup stride meets the channel interleave).
+    long long gx = cus;
+    if (const char* e = getenv("CHEBGCN_BWB_GX")) gx = atoll(e) > 0 ? atoll(e) : gx;                 // (experiment knob)
     if (gx > total) gx = total;
     p.gx = gx < 1 ? 1 : (int)gx;
     p.per = (size_t)p.rt * p.ct * 16 * 64;

@@ -81,9 +81,14 @@ bf16_dy16 = True             # 'bf16' wide layers: dy handed to the two contract
 fold_relu_grad = True        # pool == 1 layers: ReluGrad inside chebgcn_contract_bwd_*_relu (False: separate brelu_pool_bwd pass)
 # atlas-sized graphs: recurrence + contraction (and the gradient wrt the input) as one on-chip launch per layer
 fused_small = os.environ.get('CHEBGCN_FUSED_SMALL', '1') != '0' 
-# contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd (dW feeds neither): +1.5 % on the
-# configs[1] step.  Not on instrumented steps, whose per-kernel event times must not include a neighbour.
-overlap_bwd_w = True
+# contract_bwd_w on a second stream beside contract_bwd_x / recurrence_bwd (dW feeds neither).  'auto' (default since round 6):
+# only for layers of more than 32 filters (both gradients are long matrix-bound kernels that share a CU well -- config-4 /
+# config-5 layer 2 % faster with it in split bf16, 8 % in fp32).  For 32-filter layers the weight gradient cannot start
+# beside the recurrence (one 160 KB workgroup per CU) and then shares HBM with the input gradient's contraction: measured in
+# round 6 with the weight gradient on two workgroups per CU, same box -- configs[1] 3.14 ms with the second stream, 3.08 without;
+# the captured atlas step (N = 360) 0.82 -> 0.76 ms, N = 1000 1.95 -> 1.88 ms (EXPERIMENTS 8.6).  True / False force it.
+# Never on instrumented steps, whose per-kernel event times must not include a neighbour.
+overlap_bwd_w = {'1': True, '0': False}.get(os.environ.get('CHEBGCN_OVERLAP_BWD_W', 'auto'), 'auto')
 # d(loss)/dx of a layer with Fout <= Fin as  sum_k [T_k(L~^T) dy] W_k^T  -- the FORWARD recurrence on the planes of dy
 # (chebgcn_recurrence_fwd_t, in place in slab 0 of the gradient stack), then the forward contraction kernel with the re-indexed
 # weights -- instead of chebgcn_contract_bwd_x + chebgcn_recurrence_bwd (the same sum in Clenshaw form): as many bytes, on the two
@@ -672,7 +677,8 @@ class ChebConv(torch.autograd.Function):
                 what = 'contract_bwd_w' + ('_' + ctx.precision if passes else '')
                 _lib.check(_launch(what, 4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout, call), what)
 
-            side = _side_stream(dev) if (overlap_bwd_w and ctx.needs_input_grad[0] and (timers is None or not timers.active)) else None
+            want_side = (Fout > 32) if overlap_bwd_w == 'auto' else bool(overlap_bwd_w)
+            side = _side_stream(dev) if (want_side and ctx.needs_input_grad[0] and (timers is None or not timers.active)) else None
             if side is not None:
                 # dW does not feed dx: it runs beside contract_bwd_x / recurrence_bwd on a second stream
                 side.wait_stream(torch.cuda.current_stream(dev))

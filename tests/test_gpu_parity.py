@@ -600,6 +600,7 @@ def test_second_stream_for_bwd_w_is_bit_identical(ops, dev):
     x = to_storage(ops, z['x'], dev)
     labels = torch.as_tensor(np.arange(z['x'].shape[0]) % int(z['M'][-1])).to(dev)
     results = []
+    before = ops.overlap_bwd_w                 # ('auto' since round 6: the second stream for wide layers only)
     for flag in (False, True):
         ops.overlap_bwd_w = flag
         try:
@@ -609,7 +610,7 @@ def test_second_stream_for_bwd_w_is_bit_identical(ops, dev):
             torch.cuda.synchronize()
             results.append({k: net.get_var(k).copy() for k in params})
         finally:
-            ops.overlap_bwd_w = False
+            ops.overlap_bwd_w = before
     for k in results[0]:
         assert np.array_equal(results[0][k], results[1][k]), k
 
