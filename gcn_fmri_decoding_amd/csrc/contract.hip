@@ -902,20 +902,25 @@ reindex_weights_batch_kernel(ReindexBatch b) {
 }
 
 static bool small_launch(int B, int M) { return ((M + 511) / 512) * B < 2 * num_cus(); }
-static int bw_grid_x(int B, int M) {
+// `groups` = row-tile groups x column tiles of the launch (gridDim.y * gridDim.z): every group walks all chunks with gx workgroups
+static int bw_grid_x(int B, int M, int groups) {
     const int cus = num_cus();
     int total = B * ((M + 63) / 64);
-    // 48 KB of LDS per workgroup would allow three per CU (rounds 3-5); two measure faster: 0.111 -> 0.098 ms at the bench launch
-    // (0.55 -> 0.62 of the HBM roofline; 640: 0.123, 384: 0.112, 256: 0.140 -- EXPERIMENTS 8.6)
-    int gx = cus * 2;
+    // 48 KB of LDS per workgroup would allow three per CU (rounds 3-5: gx = 3 * cus whatever the number of groups).  Measured in
+    // round 6 (EXPERIMENTS 8.6): TWO workgroups per CU over the whole launch -- one group (32*5 -> 32 at the bench launch): 768 /
+    // 640 / 512 / 384 / 256 workgroups 0.111 / 0.123 / 0.098 / 0.112 / 0.140 ms; two groups (15*20 -> 32 and 32*10 -> 32 at M = 12672):
+    // gx = 768 / 512 / 384 / 256 0.236 / 0.266 / 0.235 / 0.216 ms.  A multiple of 64, at least a quarter of the CUs per group.
+    int gx = (2 * cus / (groups < 1 ? 1 : groups) + 63) / 64 * 64;
+    if (gx < cus / 4) gx = cus / 4;
     if (const char* e = getenv("CHEBGCN_BWW_GX")) gx = atoi(e) > 0 ? atoi(e) : gx;                  // (experiment knob)
-    // small launches: at least four chunks per workgroup -- every workgroup leaves a partial of the whole row-tile group
+    // small launches: at least three chunks per workgroup -- every workgroup leaves a partial of the whole row-tile group
     // (20 KB at five row tiles) that the reduce kernels read back; one chunk per workgroup made the partials of an
     // atlas-sized layer (N = 360, batch 128) 31 MB and reduce_partials_stage1 18 us beside a 38 us kernel
 #ifndef CG_BWW_MINCHUNK
-#define CG_BWW_MINCHUNK 4
+#define CG_BWW_MINCHUNK 3      // (round 6, captured atlas step at N = 360: 192 workgroups 0.754 ms, 256 0.741, 384 0.742, 128 0.779, 768 0.788)
 #endif
     if (gx > (total + CG_BWW_MINCHUNK - 1) / CG_BWW_MINCHUNK) gx = (total + CG_BWW_MINCHUNK - 1) / CG_BWW_MINCHUNK;
+    if (const char* e = getenv("CHEBGCN_BWW_GX_SMALL")) gx = (atoi(e) > 0 && total < 4 * 2 * cus) ? std::min(atoi(e), total) : gx;   // (experiment knob)
     return gx < 1 ? 1 : gx;
 }
 
@@ -1114,7 +1119,7 @@ extern "C" int chebgcn_contract_bwd_x_relu_mean(const float* gmean, const uint8_
 extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K, int Fout) {
     if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
     const int ntiles = (Fin * K + 31) / 32, rt = bw_rt(ntiles);
-    const int gy = (ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
+    const int gy = (ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M, gy * gz);
     return (size_t)gx * gy * gz * rt * 16 * 64 * sizeof(float);   // one partial per workgroup
 }
 
@@ -1129,7 +1134,7 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
     a.ntiles = (a.FinK + 31) / 32;
     a.slab = (size_t)B * Fin * a.Mp;
     const int rt = bw_rt(a.ntiles);
-    const int gy = (a.ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M);
+    const int gy = (a.ntiles + rt - 1) / rt, gz = (Fout + 31) / 32, gx = bw_grid_x(B, M, gy * gz);
     dim3 grid(gx, gy, gz);
     const size_t lds = (size_t)(rt + 1) * 32 * BW_ROW * sizeof(float);
 #define CG_BWK contract_bwd_w_kernel
