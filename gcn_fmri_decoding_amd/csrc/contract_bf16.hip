@@ -21,6 +21,7 @@
 // no LDS staging, no transpose.  The four waves of a workgroup read the same rows at the same
 // time (L1 hits); the A operand comes from a bf16 image of W packed once per call in fragment
 // order (16 B per lane and tile), resident in L2.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -933,12 +934,15 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
     p.gy = (ntiles + p.rt - 1) / p.rt;
     p.gz = (Fout + 32 * p.ct - 1) / (32 * p.ct);
     const long long total = (long long)B * ((M + 63) / 64);
-    // One workgroup per CU (registers and LDS would allow two -- rounds 2-5 launched 2 * cus): every workgroup leaves a partial of
-    // its whole tile group that two reduce kernels read back, and at 3200 chunks (the 3168-vertex level of the pooling network)
-    // 512 workgroups' partials were 38 % of the operands' bytes.  Measured, same box (EXPERIMENTS 8.6): 64*10 -> 64 at M = 3168
-    // 0.131 -> 0.118 ms, at M = 10466 0.467 -> 0.422; 32*10 -> 64 0.229 -> 0.215; 64*25 -> 64 1.116 -> 1.097 ms.  Grids that are
-    // not a multiple of 128 lose a quarter (133, 266 measured: the chunk -> workgroup stride meets the channel interleave).
-    long long gx = cus;
+    // Two workgroups per CU over the WHOLE launch (rounds 2-5: 2 * cus per row-tile group): every workgroup leaves a partial of
+    // its tile group that two reduce kernels read back -- at 3200 chunks (the 3168-vertex level of the pooling network) the
+    // partials of 512 workgroups per group were 38 % of the operands' bytes -- and groups beside each other share the CUs.
+    // Measured, same box (EXPERIMENTS 8.6; gx per group 512 / 256 / 128): 32*10 -> 64 (two groups) 0.229 / 0.205 / 0.302 ms,
+    // 64*10 -> 64 (four) 0.467 / 0.408 / 0.376, 64*25 -> 64 (ten) 1.116 / 1.058 / 1.062 (64: 1.31) at M = 10466; 0.131 / 0.118 / 0.120
+    // at M = 3168.  A multiple of 128 (133 and 266 lose a quarter: the chunk -> workgroup stride meets the channel interleave),
+    // between half the CUs and twice the CUs per group.
+    long long gx = (2ll * cus / ((long long)p.gy * p.gz) + 127) / 128 * 128;
+    gx = std::max<long long>(cus / 2, std::min<long long>(gx, 2ll * cus));
     if (const char* e = getenv("CHEBGCN_BWB_GX")) gx = atoll(e) > 0 ? atoll(e) : gx;                 // (experiment knob)
     if (gx > total) gx = total;
     p.gx = gx < 1 ? 1 : (int)gx;
