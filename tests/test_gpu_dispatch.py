@@ -86,9 +86,11 @@ def elementwise_eps(got, ref, mag):
 CASES = {
     # name: (B, M, Fin, K, Fout, forward, bwd_x stem, bwd_w RT, bwd_w reduce)
     'bench_b64': (64, 10466, 32, 5, 32, 'contract_fwd_ring_kernel', 'contract_bwd_x_lds_kernel<%s>', 5, 'big'),
-    'config4_b25': (25, 10466, 64, 25, 64, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,false>', 5, 'big'),
-    'config5_f32_b64': (64, 10466, 60, 5, 256, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,false>', 5, 'big'),
-    'wide_w_b25': (25, 10466, 32, 25, 32, 'contract_fwd_kernel<1>', 'contract_bwd_x_kernel<true,%s,false>', 5, 'big'),
+    # (round 6: the weight gradient launches two workgroups per CU over ALL its row-tile groups and column tiles: launches of several
+    # groups have at most 256 workgroups per group and their partials go through reduce_partials_small)
+    'config4_b25': (25, 10466, 64, 25, 64, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,false>', 5, 'small'),
+    'config5_f32_b64': (64, 10466, 60, 5, 256, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,false>', 5, 'small'),
+    'wide_w_b25': (25, 10466, 32, 25, 32, 'contract_fwd_kernel<1>', 'contract_bwd_x_kernel<true,%s,false>', 5, 'small'),
     'small_b3': (3, 10466, 32, 5, 32, 'contract_fwd_splitk_kernel', 'contract_bwd_x_kernel<true,%s,true>', 5, 'small'),
     'small_config4_b3': (3, 10466, 64, 25, 64, 'contract_fwd_kernel<2>', 'contract_bwd_x_kernel<false,%s,true>', 5, 'small'),
     'first_layer_b64': (64, 10466, 15, 5, 32, 'contract_fwd_ring_kernel', 'contract_bwd_x_kernel<true,%s,false>', 3, 'big'),
@@ -142,6 +144,9 @@ def test_contraction_arm_vs_float64(ops, dev, lib, case):
     del S
     ntiles = (Fin * K + 31) // 32
     assert min(ntiles, 5) == rt
+    groups = ((ntiles + rt - 1) // rt) * ((Fout + 31) // 32)            # the launcher's arithmetic (contract.hip bw_grid_x)
+    gx = min(max((512 // groups + 63) // 64 * 64, 64), (B * ((M + 63) // 64) + 2) // 3)
+    assert ('small' if gx <= 256 else 'big') == red, (gx, groups)
     dWs = {}
     for folded in (True, False):
         dW = torch.full((Fin * K, Fout), float('nan'), device=dev)
