@@ -64,6 +64,8 @@ SIGNATURES = {
     'chebgcn_contract_bwd_x_relu': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_w_relu': (_i, [_p, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_fwd_mean_supported': (_i, [_i, _i, _i, _i, _i]),
+    'chebgcn_contract_fwd_gated_supported': (_i, [_i, _i, _i, _i, _i]),
+    'chebgcn_contract_fwd_gated': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_fwd_mean': (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_w_relu_mean': (_i, [_p, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_x_relu_mean': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -166,7 +166,10 @@ constexpr int RING = CG_FWD_RING;
 #ifndef CG_LB_RING
 #define CG_LB_RING 3
 #endif
-template <bool LEAN>       // LEAN: pool == 1, no out_K scatter (the launcher's choice): the row epilogue without the pooling variants
+// LEAN: pool == 1, no out_K scatter (the launcher's choice): the row epilogue without the pooling variants
+// GATE (LEAN, no bias, no ReLU): the stored result gated by the mask a.gate -- the register slots that prefetch the bias rows
+// carry the mask byte of the lane's four vertices instead (FwdArgs::gate)
+template <bool LEAN, bool GATE = false>
 __global__ void __launch_bounds__(256, CG_LB_RING)
 contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
     extern __shared__ __align__(16) unsigned char ring_smem[];
@@ -244,7 +247,13 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
     const size_t bpitch = vb ? (size_t)a.Mp : fbk ? 1 : 0;
     const int blane = vb ? (valid ? n0 : 0) : 0;
     auto bias_base = [&](int fo) { return fbk ? (fo < a.Fout - 4 ? fo : a.Fout - 4) : (fo < a.Fout ? fo : 0); };
+    const size_t mrow = (size_t)(a.Mpo >> 2);
+    const uint8_t* gsrc = GATE ? a.gate + (size_t)b * a.Fout * mrow + (valid ? (n0 >> 2) : 0) : nullptr;
     auto bias_row = [&](int j) __attribute__((always_inline)) -> float4 {
+        if (GATE) {                                                      // (unconditional, on a clamped row: see above)
+            const int fo = acc_row(j, h);
+            return make_float4(__int_as_float((int)gsrc[(size_t)(fo < a.Fout ? fo : 0) * mrow]), 0.f, 0.f, 0.f);
+        }
         const float* p = bsrc + (size_t)bias_base(acc_row(j, h)) * bpitch + blane;
         typedef f32x4 f32x4_a4 __attribute__((aligned(4)));           // (a cached load: the bias is re-read by every window)
         const f32x4 t = *reinterpret_cast<const f32x4_a4*>(p);
@@ -262,12 +271,15 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
     // behind run-time branches, ~400 instructions per row in the binary
     float ms[4] = {0.f, 0.f, 0.f, 0.f};              // mean_out: sum over this lane's 16 filter rows (after bias + ReLU)
     const float relu_floor = a.relu ? 0.f : -__builtin_inff();
-    const size_t mrow = (size_t)(a.Mpo >> 2);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int fo = acc_row(j, h);
         float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-        {
+        if (GATE) {
+            const int bits = __float_as_int(bv[j % RING].x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((bits >> r) & 1) ? v[r] : 0.f;
+        } else {
             const float4 bb = bv[j % RING];
             const int sel = fo - bias_base(fo);      // per filter: which of the four loaded values is bias[fo]
             const float f = sel == 0 ? bb.x : sel == 1 ? bb.y : sel == 2 ? bb.z : bb.w;
@@ -278,8 +290,10 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
             v[3] += vb ? bb.w : (fbk && fo_ok) ? f : 0.f;
         }
         if (LEAN) {
+            if (!GATE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], relu_floor);
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], relu_floor);
+            }
             if (fo < a.Fout && valid) {
                 const size_t row = (size_t)b * a.Fout + fo;
                 if (a.out) *reinterpret_cast<float4*>(a.out + row * a.Mpo + n0) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1043,6 +1057,32 @@ extern "C" int chebgcn_contract_fwd_mean(const float* stack, const float* W, con
     const int nrows_pad = ring_rows(a.FinK);
     note_dispatch("contract_fwd_ring_kernel<mean>");
     hipLaunchKernelGGL(contract_fwd_ring_kernel<true>, dim3((M + 511) / 512, B, 1), dim3(256), (size_t)nrows_pad * 136, stream, a, nrows_pad);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_contract_fwd_gated_supported(int B, int M, int Fin, int K, int Fout) {
+    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0 || Fout > 32 || B > 65535) return 0;
+    return !small_launch(B, M) && (size_t)ring_rows(Fin * K) * 136 <= 48 * 1024;
+}
+
+extern "C" int chebgcn_contract_fwd_gated(const float* stack, const float* W, const uint8_t* gate, float* out, int B, int M,
+                                          int Fin, int K, int Fout, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(stack && W && gate && out, "contract_fwd_gated: NULL argument");
+    if (!chebgcn_contract_fwd_gated_supported(B, M, Fin, K, Fout))
+        return fail(CHEBGCN_EUNSUPPORTED, "contract_fwd_gated: shape not served (chebgcn_contract_fwd_gated_supported)");
+    FwdArgs a;
+    a.stack = stack; a.W = W; a.bias = nullptr; a.out = out; a.argmax = nullptr; a.gate = gate;
+    a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
+    a.pool = 1; a.pool_kind = CHEBGCN_POOL_MAX; a.relu = 0; a.bias_kind = CHEBGCN_BIAS_NONE;
+    a.Mo = M; a.Mpo = a.Mp;
+    a.slab = (size_t)B * Fin * a.Mp;
+    const int nrows_pad = ring_rows(a.FinK);
+    static const int lds_min = [] { const char* e = getenv("CHEBGCN_GATED_LDS"); return e ? atoi(e) : 0; }();
+    note_dispatch("contract_fwd_ring_kernel<gated>");
+    hipLaunchKernelGGL((contract_fwd_ring_kernel<true, true>), dim3((M + 511) / 512, B, 1), dim3(256),
+                       std::max((size_t)nrows_pad * 136, (size_t)lds_min), stream, a, nrows_pad);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

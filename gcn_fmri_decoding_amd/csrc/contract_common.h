@@ -32,6 +32,10 @@ struct FwdArgs {
     // mean over the filters of the (bias + ReLU) result, [B][Mp] (tf.reduce_mean(x, -1), models_gcn.py:673, fused into the
     // last layer's epilogue: contract_fwd_ring_kernel only); `out` may then be NULL (the layer output itself is not stored)
     float* mean_out = nullptr;
+    // gate (contract_fwd_ring_kernel<true, true> only: chebgcn_contract_fwd_gated): a ReLU mask in the layout of `relu_mask`,
+    // [B][Fout][Mp/4] -- the result is stored as bit ? value : 0.  The kernel is then the last step of the gradient wrt a
+    // layer's input in forward form, and the mask is the one the layer BELOW left: what is stored is that layer's dy
+    const uint8_t* gate = nullptr;
 };
 
 // Epilogue of one filter row for the four vertices n0..n0+3 held by lane c of a half-wave:

@@ -1170,6 +1170,9 @@ class cgcnn(base_model):
                 outs = ops.reindex_weights_batch([self._params['conv%d/weights' % (i + 1)] for i in idxs],
                                                  [(fins[i], self.K[i], self.F[i]) for i in idxs])
                 Wts = dict(zip(idxs, outs))
+        # layer i's output feeds layer i + 1 and nothing else: the ReluGrad of layer i can run in the epilogue of layer i + 1's
+        # input gradient (ops.GateLink; the layers decide by themselves whether their kernels serve it)
+        links = [ops.GateLink() for _ in range(nl - 1)] if (self.training_mode and torch.is_grad_enabled()) else None
         for i in range(nl):
             g = self.graphs[i]
             W = self._params['conv%d/weights' % (i + 1)]
@@ -1189,7 +1192,9 @@ class cgcnn(base_model):
             x = ops.cheb_conv(x, W, b, g, self.K[i], self.p[i], pool_kind, True,
                               BIAS_VERTEX if per_vertex else BIAS_FILTER, stack=stack, out=out,
                               dW=W.grad if direct else None, dbias=b.grad if direct else None,
-                              precision=self.contraction, done=done, mean=mean, pool_maps=self._pool_maps[i], Wt=Wts.get(i))
+                              precision=self.contraction, done=done, mean=mean, pool_maps=self._pool_maps[i], Wt=Wts.get(i),
+                              link_in=links[i - 1] if (links and i > 0) else None,
+                              link_out=links[i] if (links and i + 1 < nl) else None)
             stack = next_stack
         M_last = self.graphs[-1].M // self.p[-1]
         if mean:

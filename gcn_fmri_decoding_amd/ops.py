@@ -369,16 +369,25 @@ def resolve_precision(precision, Fin, K, Fout):
 
 
 def contract_fwd_into(stack, W, bias, bias_kind, out, argmax, B, M, Fin, K, Fout, pool, pool_kind, relu, precision='f32',
-                      what='contract_fwd'):
+                      what='contract_fwd', gate=None):
     """Launches the forward contraction (models_gcn.py:611-648) into ``out``.
 
     precision 'f32' = chebgcn_contract_fwd (exact fp32 MFMA); 'bf16' / 'bf16x3' =
-    chebgcn_contract_fwd_bf16 with 1 / 3 passes (wide layers, BASELINE config 5)."""
+    chebgcn_contract_fwd_bf16 with 1 / 3 passes (wide layers, BASELINE config 5).
+    ``gate``: a ReLU mask [B, Fout, Mp/4]; the result is stored gated by it (chebgcn_contract_fwd_gated: fp32, no bias / ReLU /
+    pooling -- the input gradient in forward form with the ReluGrad of the layer below in its epilogue)."""
     lib = _lib.lib()
     if precision not in PRECISIONS:
         raise ValueError('precision must be one of %s' % sorted(PRECISIONS))
     Mo = M // pool
     nbytes, flops = 4.0 * B * (M * Fin * K + Mo * Fout), 2.0 * B * M * Fin * K * Fout
+    if gate is not None:
+        if precision != 'f32' or bias is not None or pool != 1 or relu or argmax is not None:
+            raise ValueError('contract_fwd_into(gate=...): fp32, no bias, no ReLU, no pooling')
+        _lib.check(_launch(what, nbytes + 0.25 * B * M * Fout, flops,
+                           lambda: lib.chebgcn_contract_fwd_gated(_p(stack), _p(W), _p(gate), _p(out), B, M, Fin, K, Fout,
+                                                                  _stream())), what)
+        return
     if precision == 'f32':
         _lib.check(_launch(what, nbytes, flops,
                            lambda: lib.chebgcn_contract_fwd(_p(stack), _p(W), _p(bias), bias_kind, _p(out), _p(argmax), B, M,
@@ -459,6 +468,7 @@ class ChebConv(torch.autograd.Function):
             ctx.precision = 'f32'
             ctx.pool_maps = None
             ctx.Wt = bufs.Wt
+            ctx.link_in, ctx.link_out = bufs.link_in, None
             return y[:, :M]                   # the logical [B, M] mean (row stride Mp): its gradient arrives dense
         if out is None:
             out = plane_empty(B, Fout, Mo, x.device)
@@ -489,6 +499,7 @@ class ChebConv(torch.autograd.Function):
             ctx.precision = precision
             ctx.pool_maps = maps
             ctx.Wt = bufs.Wt
+            ctx.link_in, ctx.link_out = bufs.link_in, None
             return out
         if pool > 1 and (pool_kind == POOL_MAX or relu):
             argmax = torch.empty(out.shape, dtype=torch.uint8, device=x.device)
@@ -511,6 +522,14 @@ class ChebConv(torch.autograd.Function):
         ctx.precision = precision
         ctx.pool_maps = None
         ctx.Wt = bufs.Wt if bufs is not None else None
+        ctx.link_in = bufs.link_in if bufs is not None else None
+        ctx.link_out = lo = bufs.link_out if bufs is not None else None
+        if lo is not None:
+            # this layer's backward takes its gated dy as slab 0 of the stack its recurrence_fwd_t fills (the by_fwd arm below)
+            lo.gstack = None
+            ok = bool(gate_links and pool == 1 and relu and wants_grad and argmax is not None and precision != 'bf16'
+                      and dx_by_forward and ctx.needs_input_grad[0] and K > 1 and Fout <= Fin and graph.ordered)
+            lo.mask, lo.shape = (argmax, (K, B, Fout, Mp)) if ok else (None, None)
         return out
 
     @staticmethod
@@ -549,6 +568,7 @@ class ChebConv(torch.autograd.Function):
         ctx.precision = 'f32'
         ctx.pool_maps = None
         ctx.Wt = None
+        ctx.link_in = ctx.link_out = None
         return out
 
     @staticmethod
@@ -623,7 +643,20 @@ class ChebConv(torch.autograd.Function):
             bws, nbws = _brelu_bwd_ws(B, M, Fout, 1, bk, dev)
             _lib.check(_launch('relu_grad_bf16', B * Fout * M * (6.0 + 0.25), 0.0, lambda: lib.chebgcn_relu_grad_bf16(
                 _p(gout), _p(argmax), _p(dy), _p(dbias), bk, B, M, Fout, _p(bws), nbws, _stream())), 'relu_grad_bf16')
+        elif (by_fwd and ctx.link_out is not None and ctx.link_out.gstack is not None
+              and ctx.link_out.gstack.data_ptr() == gout.data_ptr() and tuple(gout.shape) == (B, Fout, g.Mp)):
+            # the layer above stored its input gradient gated by this layer's mask, straight into slab 0 of this stack
+            # (GateLink): what is left of the ReluGrad pass is the bias reduction (the mask again: a no-op on gated values)
+            gstack, ctx.link_out.gstack = ctx.link_out.gstack, None
+            dy, mask = gstack[0], None
+            if dbias is not None:
+                bws, nbws = _brelu_bwd_ws(B, M, Fout, 1, bias_kind, dev)
+                _lib.check(_launch('bias_grad', B * Fout * M * (4.0 + 0.25), 0.0, lambda: lib.chebgcn_brelu_pool_bwd(
+                    _p(dy), None, _p(argmax), None, _p(dbias), bias_kind, B, M, Fout, 1, pool_kind, 1, _p(bws), nbws,
+                    _stream())), 'brelu_pool_bwd')
         else:
+            if ctx.link_out is not None:
+                ctx.link_out.gstack = None
             if by_fwd:
                 gstack = torch.empty((K, B, Fout, g.Mp), dtype=torch.float32, device=dev)
                 dy, mask = gstack[0], None          # T_0 of the recurrence on dy: written in place
@@ -708,9 +741,17 @@ class ChebConv(torch.autograd.Function):
             if Wt is None or tuple(Wt.shape) != (Fout * K, Fin):
                 Wt = torch.empty((Fout * K, Fin), dtype=torch.float32, device=dev)
                 _lib.check(lib.chebgcn_reindex_weights(_p(Wc), _p(Wt), Fin, K, Fout, _stream()), 'reindex_weights')
-            dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
+            li, gate = ctx.link_in, None
+            if (li is not None and li.mask is not None and ctx.precision == 'f32' and li.shape[1:] == (B, Fin, g.Mp)
+                    and lib.chebgcn_contract_fwd_gated_supported(B, M, Fout, K, Fin)):
+                # the layer below wants its dy as slab 0 of a gradient stack: this contraction stores it there, gated by that
+                # layer's ReLU mask
+                li.gstack = torch.empty(li.shape, dtype=torch.float32, device=dev)
+                dx, gate = li.gstack[0], li.mask
+            else:
+                dx = torch.empty((B, Fin, g.Mp), dtype=torch.float32, device=dev)
             contract_fwd_into(gstack, Wt, None, BIAS_NONE, dx, None, B, M, Fout, K, Fin, 1, POOL_MAX, False, ctx.precision,
-                              what='contract_bwd_x')
+                              what='contract_bwd_x', gate=gate)
         elif ctx.needs_input_grad[0]:
             gstack = torch.empty((K, B, Fin, g.Mp), dtype=torch.float32, device=dev)
             passes = PRECISIONS[ctx.precision]
@@ -762,9 +803,13 @@ class Buffers:
     kernels are enqueued (dist.DataParallel starts the layer's all-reduce from it).  ``mean``: the
     layer is followed by ``tf.reduce_mean(x, -1)`` (models_gcn.py:673) and returns that mean, storage
     [B, Mp], instead of its output (chebgcn_contract_fwd_mean; the gradients read one plane per window)."""
-    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean', 'grad_mode', 'pool_maps', 'Wt')
+    __slots__ = ('stack', 'out', 'dW', 'dbias', 'precision', 'done', 'mean', 'grad_mode', 'pool_maps', 'Wt', 'link_in', 'link_out')
 
-    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None, Wt=None):
+    def __init__(self, stack=None, out=None, dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None, Wt=None,
+                 link_in=None, link_out=None):
+        # ``GateLink`` objects shared with the layer below (link_in) / above (link_out) when this layer's input IS that layer's
+        # output and nothing else reads it: the upper layer's input gradient is then stored gated by the lower layer's ReLU mask
+        self.link_in, self.link_out = link_in, link_out
         # the layer's weights already re-indexed for the forward form of the input gradient (reindex_weights_batch: the model
         # does every layer in one launch in front of the backward pass); None: the backward pass re-indexes them itself
         self.Wt = Wt
@@ -777,6 +822,25 @@ class Buffers:
         # Parameter even under torch.no_grad() -- with this off nothing that only a backward pass would read is written
         # (the ReLU mask; in the fused atlas layer the whole K-slab stack)
         self.grad_mode = torch.is_grad_enabled()
+
+
+class GateLink:
+    """What two consecutive ``cheb_conv`` layers share so that the ReluGrad of the lower one runs in the epilogue of the upper
+    one's input gradient (TF autodiff chains exactly these two ops: models_gcn.py:616 -> :625/:629 of the previous layer).
+
+    The caller creates one per pair -- ``Buffers(link_out=l)`` for the lower layer, ``Buffers(link_in=l)`` for the upper -- and
+    thereby states that the lower layer's output feeds the upper layer and NOTHING else.  The lower layer's forward fills
+    ``mask`` / ``shape`` when its own backward will want its dy as slab 0 of a gradient stack; the upper layer's backward then
+    allocates that stack, stores its gated input gradient there (``gstack``) and returns the slab to autograd; the lower layer's
+    backward recognises the slab BY ADDRESS (anything else -- a copy, a sum with another gradient -- takes the ordinary pass, and
+    gating a gated gradient again changes nothing) and only reduces its bias gradient."""
+    __slots__ = ('mask', 'shape', 'gstack')
+
+    def __init__(self):
+        self.mask = self.shape = self.gstack = None
+
+
+gate_links = os.environ.get('CHEBGCN_GATE_LINKS', '1') != '0'
 
 
 def conv_mean_supported(B, M, Fin, K, Fout, pool, relu, precision='f32'):
@@ -838,12 +902,12 @@ def reindex_weights_batch(Ws, shapes):
 
 
 def cheb_conv(x, W, bias, graph, K, pool=1, pool_kind=POOL_MAX, relu=False, bias_kind=BIAS_NONE, stack=None, out=None,
-              dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None, Wt=None):
+              dW=None, dbias=None, precision='f32', done=None, mean=False, pool_maps=None, Wt=None, link_in=None, link_out=None):
     """``precision``: arithmetic of the contraction and of its two gradients ('auto': resolve_precision; 'f32', 'bf16', 'bf16x3':
     chebgcn_contract_fwd_bf16 / _bwd_x_bf16 / _bwd_w_bf16 with 1 or 3 passes); storage, the recurrence, its adjoint
-    and the bias / ReLU / pooling gradients stay fp32."""
+    and the bias / ReLU / pooling gradients stay fp32.  ``link_in`` / ``link_out``: ``GateLink``."""
     precision = resolve_precision(precision, x.shape[1], K, W.shape[1])
-    bufs = Buffers(stack, out, dW, dbias, precision, done, mean, pool_maps if pool > 1 else None, Wt)
+    bufs = Buffers(stack, out, dW, dbias, precision, done, mean, pool_maps if pool > 1 else None, Wt, link_in, link_out)
     return ChebConv.apply(x, W, bias, graph, K, pool, pool_kind, relu, bias_kind, bufs)
 
 

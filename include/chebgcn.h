@@ -121,6 +121,17 @@ int chebgcn_reindex_weights(const float* W, float* Wt, int Fin, int K, int Fout,
  * training step, cgcnn re-indexes every layer that forms its input gradient this way once, in front of the backward pass. */
 int chebgcn_reindex_weights_batch(int n, const float* const* W, float* const* Wt, const int* Fin, const int* K,
                                   const int* Fout, chebgcn_stream stream);
+/* The contraction of that stack with the ReluGrad of the layer BELOW in its epilogue (TF autodiff chains the two:
+ * models_gcn.py:616 MatMul gradient -> :625/:629 ReluGrad of the previous layer): out[b][fo][m] = gate bit ? sum : 0, `gate` a
+ * ReLU mask as chebgcn_contract_fwd leaves it, [B][Fout][Mp/4].  With stack = T_k(L~^T) dy of layer l and W = W' of layer l,
+ * `out` IS the gated gradient wrt the output of layer l-1 -- written straight into slab 0 of the stack its own
+ * chebgcn_recurrence_fwd_t fills, so the separate ReluGrad pass of layer l-1 (chebgcn_brelu_pool_bwd writing dy) shrinks to the
+ * bias reduction.  No bias, no ReLU, no pooling; Fout <= 32 on a big launch (chebgcn_contract_fwd_gated_supported),
+ * CHEBGCN_EUNSUPPORTED otherwise.  Same products in the same order as chebgcn_contract_fwd: bit-identical to
+ * chebgcn_contract_fwd followed by the gating pass. */
+int chebgcn_contract_fwd_gated_supported(int B, int M, int Fin, int K, int Fout);
+int chebgcn_contract_fwd_gated(const float* stack, const float* W, const uint8_t* gate, float* out, int B, int M,
+                               int Fin, int K, int Fout, chebgcn_stream stream);
 
 /* ---- Chebyshev recurrence, adjoint: gradient of the above wrt x -----------------
  * (TF autodiff of models_gcn.py:598-610, reached from :298-303.)

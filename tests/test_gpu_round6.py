@@ -325,3 +325,92 @@ def test_reindex_weights_batch_is_the_index_map(dev):
     for W, Wt, (fi, k, fo) in zip(Ws, outs, shapes):
         ref = W.view(fi, k, fo).permute(2, 1, 0).reshape(fo * k, fi)
         assert torch.equal(Wt, ref), (fi, k, fo)
+
+
+# ---------------------------------------------------------------------------------------
+# the ReluGrad of a layer in the epilogue of the input gradient of the layer above (ops.GateLink)
+# ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('B,M,Fin,K,Fout', [(25, 10466, 32, 5, 32), (27, 10466, 32, 5, 15), (110, 2500, 8, 3, 32), (64, 4111, 20, 7, 7)])
+def test_contract_fwd_gated_is_contract_fwd_then_the_mask(dev, B, M, Fin, K, Fout):
+    """chebgcn_contract_fwd_gated against chebgcn_contract_fwd (no bias, no ReLU) followed by the mask in torch: bit for bit
+    (same products, same order), random masks with whole rows / quads of zeros."""
+    from gcn_fmri_decoding_amd import _lib, ops
+    lib = _lib.lib()
+    assert lib.chebgcn_contract_fwd_gated_supported(B, M, Fin, K, Fout) == 1
+    assert lib.chebgcn_contract_fwd_gated_supported(B, M, Fin, K, 33) == 0
+    assert lib.chebgcn_contract_fwd_gated_supported(1, 300, Fin, K, Fout) == 0          # a small launch: another kernel's shape
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(M + Fout)
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    W = torch.randn((Fin * K, Fout), generator=gen, device=dev) * 0.2
+    gate = torch.randint(0, 16, (B, Fout, Mp // 4), generator=gen, device=dev, dtype=torch.uint8)
+    gate[0, 0] = 0
+    gate[-1, -1, ::3] = 15
+    ref = torch.full((B, Fout, Mp), 7.0, device=dev)
+    got = torch.full((B, Fout, Mp), 7.0, device=dev)
+    _lib.check(lib.chebgcn_contract_fwd(_P(stack), _P(W), None, 0, _P(ref), None, B, M, Fin, K, Fout, 1, 0, 0, _stream()), 'fwd')
+    assert _lib.last_dispatch() == 'contract_fwd_ring_kernel'
+    _lib.check(lib.chebgcn_contract_fwd_gated(_P(stack), _P(W), _P(gate), _P(got), B, M, Fin, K, Fout, _stream()), 'gated')
+    assert _lib.last_dispatch() == 'contract_fwd_ring_kernel<gated>'
+    bits = torch.stack([(gate >> r) & 1 for r in range(4)], dim=-1).reshape(B, Fout, Mp).bool()
+    # (whole padded planes: both kernels store every quad of a plane, the pad's values come from the stack's pad)
+    assert torch.equal(got, torch.where(bits, ref, torch.zeros_like(ref)))
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.chebgcn_contract_fwd_gated(_P(stack), _P(W), _P(gate), _P(got), 1, 300, Fin, K, Fout, _stream()), 'gated')
+
+
+def test_gate_links_are_invisible_in_the_benchmark_network(dev, monkeypatch):
+    """BASELINE configs[1] at batch 26 (the smallest launches the big-launch contraction kernels take at this size are 25
+    windows) with the layers linked (default) and not: every gradient bit-identical -- the linked
+    step stores dy of layers 2..5 from the epilogue of the layer above (`contract_fwd_ring_kernel<gated>`), their ReluGrad
+    pass is the bias reduction alone; and the linked network captured as a HIP graph replays the eager step."""
+    import bench
+    from gcn_fmri_decoding_amd import models_gcn, ops
+    Ls, _ = bench.load_graph(10000, 1, 0, 1, None)
+    L = Ls[0]
+    M = L.shape[0]
+    F, K, p, Mfc, C, B = [32] * 6, [5] * 6, [1] * 6, [512, 256, 22], 15, 26
+
+    def make():
+        torch.manual_seed(5)
+        return models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1',
+                                initial='he', channel=C, regularization=5e-4, dropout=1, batch_size=B, verbose=False)
+    a, b = make(), make()
+    b.load_state_dict(a.state_dict())
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    x = a.as_internal(ops.plane_storage(torch.randn((B, M, C), generator=gen, device=dev)))
+    labels = (torch.arange(B, device=dev) * 5) % 21
+    names = {}
+    for net, on in ((a, True), (b, False)):
+        monkeypatch.setattr(ops, 'gate_links', on)
+        ops.timers = ops.KernelTimers(every=1, by_dispatch=True)
+        try:
+            ops.timers.next_step()
+            net.train_step(x, labels)
+            names[on] = sorted(ops.timers.summary())
+        finally:
+            ops.timers = None
+    gated = [n for n in names[True] if 'contract_fwd_ring_kernel<gated>' in n]
+    assert gated and gated[0].startswith('contract_bwd_x'), names[True]
+    assert not [n for n in names[False] if '<gated>' in n], names[False]
+    # with the links the full ReluGrad pass (op brelu_pool_bwd: dy written) is gone from the step, the bias reductions remain
+    assert not [n for n in names[True] if n.startswith('brelu_pool_bwd')], names[True]
+    assert [n for n in names[False] if n.startswith('brelu_pool_bwd')], names[False]
+    assert torch.equal(a._grad, b._grad)
+    assert torch.equal(a._flat, b._flat)
+    monkeypatch.setattr(ops, 'gate_links', True)
+    twin = make()
+    twin.load_state_dict(a.state_dict())
+    twin._loss_ema = None if a._loss_ema is None else a._loss_ema.clone()
+    twin.global_step = a.global_step
+    twin._adam_m.copy_(a._adam_m)
+    twin._adam_v.copy_(a._adam_v)
+    a.enable_step_graph(True)
+    for _ in range(3):
+        la = a.train_step(x, labels)[1]
+        lb = twin.train_step(x, labels)[1]
+    torch.cuda.synchronize()
+    assert a._sg is not None and torch.equal(a._flat, twin._flat) and float(la) == float(lb)
