@@ -86,7 +86,9 @@ brelu_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ 
 // that each walk the batch in 8 serial rounds) 16 subsets x 16 quads.
 // DY16: the gated gradient is written as bf16 (RNE), [B][F][Mp] -- the operand of the bf16 contraction gradients, which
 // round it to bf16 anyway (chebgcn_relu_grad_bf16)
-template <int BIAS, int NP = 4, bool DY16 = false>
+// MASKED = false: dout is a gated gradient already (the layer above stored it gated: chebgcn_contract_fwd_gated) -- no mask is
+// read, nothing but dbias is written
+template <int BIAS, int NP = 4, bool DY16 = false, bool MASKED = true>
 __global__ void __launch_bounds__(256)
 bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dy,
                       float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F,
@@ -101,20 +103,20 @@ bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict_
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         const float* gp = dout + (size_t)f * d_fstride + 4 * q;
-        const uint8_t* mp = mask + (size_t)f * Mq + q;
+        const uint8_t* mp = MASKED ? mask + (size_t)f * Mq + q : nullptr;
 #pragma unroll 4
         for (int b = part; b < B; b += NP) {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const f32x4 g = CG_DY_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride))
                                      : *reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride);
-            const int bits = mp[(size_t)b * F * Mq];
+            const int bits = MASKED ? mp[(size_t)b * F * Mq] : 15;
             const float4 d = make_float4((bits & 1) ? g.x : 0.f, (bits & 2) ? g.y : 0.f, (bits & 4) ? g.z : 0.f,
                                          (bits & 8) ? g.w : 0.f);
             if (DY16) {
                 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 const bf16x4 h = {(__bf16)d.x, (__bf16)d.y, (__bf16)d.z, (__bf16)d.w};
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dy) + ((size_t)b * F + f) * Mp + 4 * q) = h;
-            } else if (dy) {
+            } else if (MASKED && dy) {
                 *reinterpret_cast<float4*>(dy + ((size_t)b * F + f) * Mp + 4 * q) = d;
             }
             sum.x += d.x; sum.y += d.y; sum.z += d.z; sum.w += d.w;
@@ -641,9 +643,9 @@ extern "C" int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bia
 }
 
 // workgroups along the vertex axis of the gradient kernels below (= per-filter partials of a b1relu layer)
-static int brelu_bwd_blocks(int M, int F, int pool, int relu, bool have_mask, int* parts_out) {
+static int brelu_bwd_blocks(int M, int F, int pool, int relu, bool have_mask, int* parts_out, bool bias_only = false) {
     const int Mp = plane_stride(M);
-    if (pool == 1 && relu && have_mask) {
+    if (pool == 1 && ((relu && have_mask) || bias_only)) {
         // bias_grad_relu_kernel: 64 quads x 4 batch subsets per workgroup, or 16 x 16 where that leaves the chip short of work
         const bool fine = ((Mp / 4 + 63) / 64) * F < 512;
         if (parts_out) *parts_out = fine ? 16 : 4;
@@ -692,14 +694,32 @@ extern "C" int chebgcn_brelu_pool_bwd(const float* dout, const float* out, const
         return pool_scatter_launch(dout, out, argmax, nullptr, dy, dbias, bias_kind, B, M, F, pool, pool_kind, relu, workspace,
                                    workspace_bytes, stream);
     int parts = 0;
-    const int nblk = brelu_bwd_blocks(M, F, pool, relu, argmax != nullptr, &parts);
+    // no ReLU, no pooling, no dy: the plain sum of dout over the windows -- the bias gradient of a layer whose gated dy the
+    // layer above stored (chebgcn_contract_fwd_gated)
+    const bool bias_only = pool == 1 && !relu && !dy;
+    const int nblk = brelu_bwd_blocks(M, F, pool, relu, argmax != nullptr, &parts, bias_only);
     float* fpart = nullptr;
     if (bias_kind == CHEBGCN_BIAS_FILTER) {
         CG_REQUIRE(workspace && workspace_bytes >= (size_t)F * nblk * sizeof(float),
                    "brelu_pool_bwd: the per-filter bias gradient needs a workspace of chebgcn_brelu_pool_bwd_workspace() bytes");
         fpart = static_cast<float*>(workspace);
     }
-    if (pool == 1 && relu && argmax) {                  // ReLU mask of contract_fwd: vertices in fours, dy optional
+    if (bias_only) {
+        const dim3 grid(nblk, F);
+#define CG_BGS(BK)                                                                                                         \
+    do {                                                                                                                   \
+        note_dispatch(parts == 16 ? "bias_grad_sum_kernel<" #BK ",16>" : "bias_grad_sum_kernel<" #BK ",4>");               \
+        if (parts == 16)                                                                                                   \
+            hipLaunchKernelGGL((bias_grad_relu_kernel<BK, 16, false, false>), grid, dim3(256), 0, stream, dout, nullptr, nullptr, \
+                               dbias, fpart, B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);                                     \
+        else                                                                                                               \
+            hipLaunchKernelGGL((bias_grad_relu_kernel<BK, 4, false, false>), grid, dim3(256), 0, stream, dout, nullptr, nullptr, \
+                               dbias, fpart, B, M, Mp, F, (size_t)F * Mp, (size_t)Mp);                                     \
+    } while (0)
+        if (bias_kind == CHEBGCN_BIAS_FILTER) CG_BGS(CHEBGCN_BIAS_FILTER);
+        else CG_BGS(CHEBGCN_BIAS_VERTEX);
+#undef CG_BGS
+    } else if (pool == 1 && relu && argmax) {                  // ReLU mask of contract_fwd: vertices in fours, dy optional
         const dim3 grid(nblk, F);
 #define CG_BGR(BK)                                                                                                         \
     do {                                                                                                                   \

@@ -428,8 +428,10 @@ STEP_KERNELS = {
         'recurrence_fwd': {'cheb_ord_kernel<10240,6,5,512,false>'},
         'recurrence_fwd_t': {'cheb_ord_kernel<10240,6,5,512,false>'},
         'contract_fwd': {'contract_fwd_ring_kernel'},
-        'contract_bwd_x': {'contract_fwd_ring_kernel'},
-        'brelu_pool_bwd': {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>'},
+        # layers 3-6 store their input gradient gated by the mask of the layer below (ops.GateLink), whose ReluGrad pass is then
+        # the plain sum for the bias; layer 2 feeds layer 1, which folds its ReluGrad into the weight gradient
+        'contract_bwd_x': {'contract_fwd_ring_kernel<gated>', 'contract_fwd_ring_kernel'},
+        'brelu_pool_bwd': {'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>', 'bias_grad_sum_kernel<CHEBGCN_BIAS_VERTEX,4>'},
     },
 }
 
