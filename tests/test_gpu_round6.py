@@ -414,3 +414,35 @@ def test_gate_links_are_invisible_in_the_benchmark_network(dev, monkeypatch):
         lb = twin.train_step(x, labels)[1]
     torch.cuda.synchronize()
     assert a._sg is not None and torch.equal(a._flat, twin._flat) and float(la) == float(lb)
+
+
+@pytest.mark.parametrize('B,M,F', [(7, 10466, 5), (9, 300, 6), (130, 1044, 32)])
+@pytest.mark.parametrize('bias_kind', [1, 2])
+def test_bias_grad_sum_vs_float64(dev, B, M, F, bias_kind):
+    """chebgcn_brelu_pool_bwd(pool = 1, relu = 0, dy = NULL): the bias gradient as the plain sum of dout over the windows (per
+    vertex and filter) or over windows and vertices (per filter) -- `bias_grad_sum_kernel`; pads of the planes poisoned."""
+    from gcn_fmri_decoding_amd import _lib, ops
+    lib = _lib.lib()
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B + M)
+    g = torch.randn((B, F, Mp), generator=gen, device=dev)
+    g[:, :, M:] = float('nan')
+    n = lib.chebgcn_brelu_pool_bwd_workspace(B, M, F, 1, bias_kind)
+    ws = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    db = torch.full((F, Mp) if bias_kind == 2 else (F,), 3.0, device=dev)
+    _lib.check(lib.chebgcn_brelu_pool_bwd(_P(g), None, None, None, _P(db), bias_kind, B, M, F, 1, 0, 0, _P(ws) if n else None, n,
+                                          _stream()), 'bias sum')
+    kind = 'CHEBGCN_BIAS_VERTEX' if bias_kind == 2 else 'CHEBGCN_BIAS_FILTER'
+    assert _lib.last_dispatch().startswith('bias_grad_sum_kernel<%s,' % kind), _lib.last_dispatch()
+    g64 = g[:, :, :M].double()
+    if bias_kind == 2:
+        ref = g64.sum(0)
+        got = db[:, :M].double()
+        assert torch.equal(db[:, M:], torch.full_like(db[:, M:], 3.0)) or not torch.isnan(db[:, M:]).any()
+    else:
+        ref = g64.sum((0, 2))
+        got = db.double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    record_measured('bias_grad_sum[%d,%d,%d,%d]' % (B, M, F, bias_kind), rel=err)
+    assert err <= 2e-6, err

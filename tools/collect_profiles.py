@@ -58,11 +58,13 @@ raw = json.load(open(os.path.join(SRC, 'traffic_raw.json')))
 # `kernels_by_symbol` / `roofline.kernel` are keyed by); kbench launches each at the shape of the step (B=64, Fin=Fout=32, K=5)
 names = {'cheb_ord_kernel<4, 10240, 6, 5, 512, false>': 'cheb_ord_kernel<10240,6,5,512,false>',
          'cheb_ord_kernel<4, 10240, 6, 5, 512, true>': 'cheb_ord_kernel<10240,6,5,512,true>',
-         'contract_fwd_ring_kernel<true>': 'contract_fwd_ring_kernel', 'contract_fwd_ring_kernel<false>': 'contract_fwd_ring_kernel<pool>',
+         'contract_fwd_ring_kernel<true, false>': 'contract_fwd_ring_kernel', 'contract_fwd_ring_kernel<false, false>': 'contract_fwd_ring_kernel<pool>',
+         'contract_fwd_ring_kernel<true, true>': 'contract_fwd_ring_kernel<gated>',
          'contract_bwd_w_kernel<5, true>': 'contract_bwd_w_kernel<5,true> + reduce_partials_wide',
          'contract_bwd_w_kernel<5, false>': 'contract_bwd_w_kernel<5,false> + reduce_partials_wide',
          'contract_bwd_x_lds_kernel<true>': 'contract_bwd_x_lds_kernel<true>', 'contract_bwd_x_lds_kernel<false>': 'contract_bwd_x_lds_kernel<false>',
-         'bias_grad_relu_kernel<2': 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>', 'reduce_partials_wide': 'reduce_partials_wide'}
+         'bias_grad_relu_kernel<2, 4, false, true>': 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,4>',
+         'bias_grad_relu_kernel<2, 4, false, false>': 'bias_grad_sum_kernel<CHEBGCN_BIAS_VERTEX,4>', 'reduce_partials_wide': 'reduce_partials_wide'}
 out = {'_note': 'HBM bytes per launch at the bench shape (B=64, Fin=Fout=32, K=5, M=10466), rocprofv3 --pmc FETCH_SIZE and '
                 'WRITE_SIZE in separate passes with --kernel-trace only (tools/pmc_traffic.sh); bytes = (2*FETCH_SIZE + '
                 'WRITE_SIZE) KiB -- FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950; '

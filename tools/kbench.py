@@ -27,7 +27,8 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--kernels', nargs='+', default=['recurrence_fwd', 'recurrence_fwd_inplace', 'recurrence_bwd', 'contract_fwd',
                                                      'contract_bwd_w_relu', 'contract_bwd_x_relu', 'bias_grad_relu', 'contract_bwd_w', 'contract_bwd_x',
-                                                     'brelu_pool_bwd', 'recurrence_fwd_t', 'contract_fwd_dx', 'brelu_pool_bwd_mask'])
+                                                     'brelu_pool_bwd', 'recurrence_fwd_t', 'contract_fwd_dx', 'brelu_pool_bwd_mask', 'contract_fwd_dx_gated',
+                                                     'bias_grad_sum'])
     ap.add_argument('--nodes', type=int, default=10000, help='points of the synthetic kNN graph (10000 -> M = 10466)')
     ap.add_argument('--levels', type=int, default=1, help='coarsening levels of the synthetic graph (1 -> fake vertices behind the real ones)')
     ap.add_argument('--json', default=None)
@@ -81,7 +82,7 @@ def main():
     for B in args.B:
         Fin, Fout, K = args.fin, args.fout, args.K
         if Fin != Fout:
-            args.kernels = [k for k in args.kernels if k not in ('recurrence_fwd_t', 'contract_fwd_dx')]
+            args.kernels = [k for k in args.kernels if k not in ('recurrence_fwd_t', 'contract_fwd_dx', 'contract_fwd_dx_gated')]
         torch.manual_seed(0)
         x = torch.randn(B, Fin, Mp, device=dev)
         stack = torch.randn(K, B, Fin, Mp, device=dev)
@@ -118,6 +119,12 @@ def main():
             'contract_fwd_dx': (lambda: lib.chebgcn_contract_fwd(P(gstack), P(Wt), None, 0, P(dx), None, B, M, Fout, K, Fin,
                                                                  1, 0, 0, st),
                                 4.0 * B * M * (Fout * K + Fin), 2.0 * B * M * Fin * K * Fout),
+            # ... with the ReluGrad of the layer below in its epilogue (ops.GateLink: layers 3-6 of the bench network), and what is
+            # left of that layer's own ReluGrad pass: the plain sum of the gated dy for the bias gradient
+            'contract_fwd_dx_gated': (lambda: lib.chebgcn_contract_fwd_gated(P(gstack), P(Wt), P(mask), P(dx), B, M, Fout, K, Fin, st),
+                                      B * M * (4.0 * (Fout * K + Fin) + Fin / 4.0), 2.0 * B * M * Fin * K * Fout),
+            'bias_grad_sum': (lambda: lib.chebgcn_brelu_pool_bwd(P(dy), None, None, None, P(dbias), 2, B, M, Fout, 1, 0, 0, None, 0, st),
+                              B * Fout * M * 4.0, 0.0),
             'contract_fwd': (lambda: lib.chebgcn_contract_fwd(P(stack), P(W), P(bias), 2, P(out), None, B, M, Fin, K, Fout,
                                                               1, 0, 1, st),
                              4.0 * B * M * (Fin * K + Fout), 2.0 * B * M * Fin * K * Fout),
