@@ -213,7 +213,9 @@ int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bias_kind, flo
  * dout, out: [B][F][Mp(M/pool)] (out = forward result); argmax as written by the
  * forward; dy: [B][F][Mp(M)] receives d(loss)/d(pre-bias activation); dbias: [F] or
  * [F][Mp(M)] (overwritten) or NULL.  pool == 1 with relu: a non-NULL argmax is the ReLU mask of
- * contract_fwd and replaces `out` (which may then be NULL).  dy == NULL: only dbias is computed.
+ * contract_fwd and replaces `out` (which may then be NULL).  dy == NULL: only dbias is computed; with pool == 1 and relu == 0
+ * as well that is the plain sum of dout over the windows (per filter: and vertices) -- the bias gradient of a layer whose
+ * gated dy the layer above stored (chebgcn_contract_fwd_gated).
  * workspace: device scratch of at least chebgcn_brelu_pool_bwd_workspace() bytes.  bias_kind CHEBGCN_BIAS_FILTER needs
  * it: the per-filter sum of b1relu (models_gcn.py:619-623) is a two-stage reduction in a fixed order (per-workgroup
  * partials, then one wave per filter), so every gradient this library returns is bit-reproducible from run to run.  A
