@@ -5,12 +5,16 @@
 
 namespace chebgcn {
 
-// Shape of the ordered kernel for a graph of Mq vertex quads of which the first SQ have rows: NQ = quads per thread (512
-// threads), NG = quad levels with rows, planes = 4 while 16 bytes per active vertex fit the LDS (+ zero and trash slot), else 2.
-// Served: 2049 ... 20476 active vertices (below, the generic on-chip kernel and the fused atlas layer work in the caller's
-// order and gain nothing from a relabelling); isolated / padding vertices beyond one quad level behind the rows: the tail kernel.
+// Shape of the ordered kernel for a graph of Mq vertex quads of which the first SQ have rows: NT = threads, NQ = quads per thread,
+// NG = quad levels with rows, planes = 4 while 16 bytes per active vertex fit the LDS (+ zero and trash slot), else 2.
+// Served: 2049 ... 20476 active vertices on 512 threads; round 6: planes of 1025 ... 2048 vertices (at most 2048 active) on 256
+// threads -- there the on-chip kernel of recurrence.hip needs two linear pieces per thread and plane and drops to 0.23 of the
+// roofline (N = 1000, M = 1044, K = 10, batch 128: forward 0.094 -> 0.065 ms, N = 2000: 0.156 -> 0.112 ms; below, in the caller's
+// order, it is the faster one: N = 800 0.055 against 0.059 ms, N = 500 0.031 against 0.046 -- EXPERIMENTS 8.8).  Isolated / padding
+// vertices beyond one quad level behind the rows: the tail kernel.  CHEBGCN_ORD_SMALL=0: the 512-thread shapes only.
 bool ordered_shape(int Mq, int SQ, int* NT, int* NQ, int* NG, int* planes) {
-    if (SQ <= 512) return false;
+    static const int small_on = [] { const char* e = getenv("CHEBGCN_ORD_SMALL"); return e ? atoi(e) : 1; }();
+    if (SQ <= 512 && (Mq <= 256 || !small_on)) return false;
     auto shape = [&](int nt, int ng0, int ng1, int cap) {
         const int ng = (SQ + nt - 1) / nt;
         // quad levels per thread: the levels with rows + at most ONE level of isolated / padding vertices, whose state sits in
@@ -23,6 +27,11 @@ bool ordered_shape(int Mq, int SQ, int* NT, int* NQ, int* NG, int* planes) {
         *NG = ng;
         return true;
     };
+    if (SQ <= 512) {
+        if (!shape(kOrdSNT, kOrdSNG0, kOrdSNG1, ord_entries<4, 1, kOrdSNT>::cap)) return false;
+        *planes = 4;
+        return true;
+    }
     if (shape(kOrd4NT, kOrd4NG0, kOrd4NG1, ord_entries<4, 1, kOrd4NT>::cap)) *planes = 4;
     // (two planes: up to 10752 vertices the 768-thread kernel of recurrence.hip on the caller's order is faster -- N = 10242, batch
     // 256: 0.596 / 0.630 ms against 0.678 / 0.699 ms; beyond, the ordered kernel wins by 1.2x (N = 13000) to 2.9x (N = 19000))
@@ -68,8 +77,12 @@ int dispatch_ordered(const chebgcn_graph* g, const Ell& ell, const float* src, f
                      hipStream_t stream) {
     if (!ordered_fits(g, nplanes))
         return fail(CHEBGCN_EUNSUPPORTED, "recurrence: %d planes of %d vertices exceed 4 GB per slab", nplanes, g->Mp);
-    const int rc = ell.planes == 4 ? launch_ord_shape<4, kOrd4NT, kOrd4NG0, kOrd4NG1, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
-                                   : launch_ordered2<ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
+    if constexpr (ADJ) {
+        if (ell.ord_NT <= kOrdSNT) return fail(CHEBGCN_EUNSUPPORTED, "recurrence: the 256-thread ordered shapes are forward kernels");
+    }
+    const int rc = (!ADJ && ell.ord_NT <= kOrdSNT) ? launch_ordered_small<false>(g, ell, src, dst, nplanes, K, copy_t0, stream)
+                   : ell.planes == 4 ? launch_ord_shape<4, kOrd4NT, kOrd4NG0, kOrd4NG1, ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream)
+                                     : launch_ordered2<ADJ>(g, ell, src, dst, nplanes, K, copy_t0, stream);
     if (rc != CHEBGCN_OK || !ell.ord_tail || ell.ord_tail >= g->Mp) return rc;
     // the vertices behind the kernel's quad levels: no rows, no column entries -- T_k = c(k) x, dx = sum_m c(m) G_m
     const int tq = (g->Mp - ell.ord_tail) / 4;

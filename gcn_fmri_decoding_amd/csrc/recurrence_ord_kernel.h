@@ -171,8 +171,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (ceil(Mp/4 / NT)); NG = leading quad levels that hold rows (ceil(SQ / NT)): levels NG..NQ-1 are isolated vertices and
 // padding only.
 template <int PL, int ENT, int NQ, int NG, int NT, bool ADJ>
-// (two workgroups per CU where two images fit; HIP's second launch bound counts waves per SIMD)
-__global__ void __launch_bounds__(NT, (CG_ORD_WG2 && NQ == NG && 2 * ENT * 4 * PL <= 160 * 1024 && 2 * NT <= 1024) ? 2 * NT / 256 : NT / 256)
+// (two workgroups per CU where two images fit; HIP's second launch bound counts waves per SIMD; the 256-thread shapes of the
+// graphs below 2049 vertices: four workgroups per CU)
+__global__ void __launch_bounds__(NT, NT <= 256 ? 4 : (CG_ORD_WG2 && NQ == NG && 2 * ENT * 4 * PL <= 160 * 1024 && 2 * NT <= 1024) ? 2 * NT / 256 : NT / 256)
 cheb_ord_kernel(EllView e, const float* __restrict__ src, float* __restrict__ dst, int M, int Mp, int nplanes, int K, size_t slab,
                 int SQ, int flags) {
     typedef typename entry_of<PL>::type ent_t;
@@ -563,6 +564,12 @@ int launch_ord_shape(const chebgcn_graph* g, const Ell& ell, const float* src, f
 #define CG_ORD2_NT 512
 #endif
 constexpr int kOrd4NT = 512, kOrd4NG0 = 2, kOrd4NG1 = 5;
+// graphs of 1025 ... 2048 vertices (more than 256 quads per plane, at most 512 with rows): 256 threads, one or two quad levels
+// with rows (recurrence_ord_small.hip)
+constexpr int kOrdSNT = 256, kOrdSNG0 = 1, kOrdSNG1 = 2;
+template <bool ADJ>
+int launch_ordered_small(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,
+                         hipStream_t stream);
 constexpr int kOrd2NT = CG_ORD2_NT, kOrd2NG0 = (2560 + kOrd2NT - 1) / kOrd2NT, kOrd2NG1 = (5119 + kOrd2NT - 1) / kOrd2NT;
 template <bool ADJ>
 int launch_ordered2(const chebgcn_graph* g, const Ell& ell, const float* src, float* dst, int nplanes, int K, int copy_t0,

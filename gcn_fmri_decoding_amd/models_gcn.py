@@ -903,7 +903,7 @@ class cgcnn(base_model):
         # Internal vertex order.  The network does not depend on how the vertices of a level are numbered as long as everything
         # per-vertex follows: the model relabels the vertices of every graph level that is large enough by descending number
         # of neighbours (graph.length_order), for which the library has faster recurrence kernels (csrc/recurrence_ord*.hip,
-        # 2049 ... 20476 active vertices); activations, per-vertex biases and the rows of the first FC layer live in the order of
+        # planes of more than 1024 vertices, up to 20476 active ones); activations, per-vertex biases and the rows of the first FC layer live in the order of
         # THEIR level, the accessors (variable / set_variable / gradient / state_dict) and the input staging translate.
         # Pooling (models_gcn.py:631-648: p consecutive vertices of the coarsening's tree order) between two levels of which
         # either is relabelled runs through index maps (ops.pool_maps, chebgcn_pool_gather_fwd / _scatter_bwd) instead of
@@ -927,7 +927,7 @@ class cgcnn(base_model):
                 # N = 360 0.943 -> 0.911 ms) -- not taken: in the coarsening's tree order spatial neighbours are adjacent and
                 # the weight gradients' long cancelling sums over the vertices come out within 2e-7 of float64; in degree
                 # order they carry plain fp32 summation noise (1e-4 of their scale, like NumPy's fp32).
-                if self.vertex_order == 'length' and self._fusable() and (Li.shape[0] > 2048 or force):
+                if self.vertex_order == 'length' and self._fusable() and (Li.shape[0] > 1024 or force):
                     # (CHEBGCN_BANK_ORDER=1: the length order refined inside its classes of equal row length against the gather's
                     # LDS bank conflicts, graph.bank_order -- measured in round 6: the conflict cost of the image drops by 16 %, the
                     # kernel by 0-2 %, the configs[1] step not at all (EXPERIMENTS 8.2): off by default)

@@ -93,7 +93,9 @@ void chebgcn_graph_destroy(chebgcn_graph* g);
  * the ORDERED operator image: the rows of the caller's matrix are sorted by descending length
  * (isolated vertices last) and the graph was created with planes = 0 -- recurrence launches then
  * run the kernel that moves planes between HBM and registers directly (csrc/recurrence_ord_kernel.h;
- * served: 2049 ... 20476 active vertices with at most 2047 isolated / padding ones behind them);
+ * served: planes of more than 1024 vertices, up to 20476 active ones -- 256 threads per workgroup up to 2048 active vertices
+ * (forward recurrences only: the Clenshaw adjoint of such a graph runs the kernel of the caller's order), 512 beyond --, any
+ * number of isolated / padding vertices behind them);
  * 13 / 14 / 15 = items 9 / 10 / 11 for that image, 16 = its planes per workgroup (4 up to 10238
  * active vertices, 2 beyond; 0 = no ordered image). */
 int chebgcn_graph_query(const chebgcn_graph* g, int what, int64_t* value);

@@ -6,7 +6,8 @@ do not serve (csrc/recurrence.hip ``dispatch_onchip``: 256 / 512 / 768 threads, 
 csrc/recurrence4.hip ``dispatch_onchip4``: four planes beyond 2048 rows).
 
 A network without pooling relabels its vertices by descending row length (``graph.length_order``), and the library then runs
-``cheb_ord_kernel<ENT,NQ,NG,512,*>`` (four planes per workgroup, 16-byte LDS entries: 2049 ... 10238 active vertices) or
+``cheb_ord_kernel<ENT,NQ,NG,512,*>`` (four planes per workgroup, 16-byte LDS entries: 2049 ... 10238 active vertices; round 6:
+``cheb_ord_kernel<ENT,NQ,NG,256,false>`` for planes of more than 1024 vertices with at most 2048 active ones, forward only) or
 ``cheb_ord2_kernel<...>`` (two planes, 8-byte entries: from 10753 vertices up to 20476 active ones; in the window between, the
 768-thread two-plane kernel of recurrence.hip on the caller's order is faster and is what runs).  NG = quad levels with rows = ceil(active / 4 / 512),
 NQ = quad levels in all = ceil(Mp / 4 / 512).  Reference semantics: ``lib_new/models_gcn.py:598-610`` (the recurrence),
@@ -31,6 +32,11 @@ REL, GREL = 1e-5, 2e-5
 
 # (points of the synthetic kNN graph, coarsening levels) -> (kernel family, ENT, NQ, NG)
 SHAPES = [
+    # round 6: planes of 1025 ... 2048 vertices on the 256-thread shapes (forward; the Clenshaw adjoint of such a graph stays on the
+    # on-chip kernel of recurrence.hip, which runs in any vertex order and is the faster one there)
+    ((1000, 1), ('cheb_ord_kernel', 1040, 2, 1, 256, 'cheb_onchip_kernel<4,4,2,256,true>')),
+    ((2000, 1), ('cheb_ord_kernel', 2064, 3, 2, 256, 'cheb_onchip_kernel<4,8,3,256,true>')),
+    ((800, 1), ('cheb_onchip_kernel', 4, 4, 1, 256)),       # at most 1024 vertices per plane: the caller's order
     ((2600, 1), ('cheb_ord_kernel', 4112, 2, 2)),
     ((6000, 1), ('cheb_ord_kernel', 6160, 4, 3)),
     ((8000, 1), ('cheb_ord_kernel', 8208, 5, 4)),
@@ -69,10 +75,11 @@ def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
     from gcn_fmri_decoding_amd import _lib, graph, ops
     from oracle import graph_ref as GR
     lib = _lib.lib()
-    family, ENT, NQ, NG = shape
-    PL = 4 if family == 'cheb_ord_kernel' else 2
+    family, ENT, NQ, NG = shape[:4]
+    nt_small = shape[4] if len(shape) > 4 else None
+    PL = 2 if (family == 'cheb_ord2_kernel' or (family == 'cheb_onchip_kernel' and nt_small is None)) else 4
     ordered = family != 'cheb_onchip_kernel'
-    if K != 5 and graph_key not in ((2600, 1), (10000, 1), (11000, 1)):
+    if K != 5 and graph_key not in ((1000, 1), (2600, 1), (10000, 1), (11000, 1)):
         pytest.skip('K = 2, 3 on one graph per kernel family and the smallest shape')
     Ls, _ = bench.load_graph(graph_key[0], graph_key[1], 0, 1, None)
     L0 = Ls[0]
@@ -86,18 +93,20 @@ def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
     else:
         assert not g.ordered                      # cgcnn then keeps the caller's order (models_gcn.cgcnn.__init__)
         g, L = ops.Graph(L0, dev), L0
-        assert g.query(6) == 2
+        assert g.query(6) == PL
     Mp = g.Mp
-    nt = 512 if ordered else 768
+    nt = (nt_small or 512) if ordered else (nt_small or 768)
     name_f = '%s<%d,%d,%d,%d,false>' % (family, ENT, NQ, NG, nt)
     name_a = '%s<%d,%d,%d,%d,true>' % (family, ENT, NQ, NG, nt)
-    if ordered and Mp > 4 * 512 * NQ:             # vertices behind the kernel's quad levels: the streamed tail
-        assert g.query(17) == 4 * 512 * NQ
+    if ordered and Mp > 4 * nt * NQ:              # vertices behind the kernel's quad levels: the streamed tail
+        assert g.query(17) == 4 * nt * NQ
         name_f, name_a = name_f + ' + cheb_ord_tail_kernel<false>', name_a + ' + cheb_ord_tail_kernel<true>'
     elif ordered:
         assert g.query(17) == 0
+    if len(shape) > 5:
+        name_a = shape[5]
     # more plane groups than the launch has workgroups (256 CUs x at most 2 workgroups), partial last group
-    B, Fin = 7, 301 if PL == 4 else 151
+    B, Fin = (15 if nt_small and ordered else 7), 301 if PL == 4 else 151     # (the 256-thread shapes: four workgroups per CU)
     nplanes = B * Fin
     assert nplanes % PL != 0 and (nplanes + PL - 1) // PL > 2 * 256
     gen = torch.Generator(device=dev)
@@ -167,6 +176,10 @@ def test_ordered_recurrence_every_plane(dev, graph_key, shape, K):
 ORD_TABLE = [(4, ng, nq) for ng in (2, 3, 4, 5) for nq in (ng, ng + 1)] + [(2, 5, 6)] + [(2, ng, nq) for ng in range(6, 11) for nq in (ng, ng + 1)]
 # nq = ng + 2 / ng + 3: more isolated vertices than one quad level -- the NQ = NG + 1 kernel + cheb_ord_tail_kernel
 ORD_TABLE += [(4, 2, 4), (4, 5, 7), (2, 6, 8), (4, 3, 6)]
+ORD_TABLE = [t + (512,) for t in ORD_TABLE]
+# round 6: the 256-thread shapes (planes of more than 1024 vertices, at most 2048 active: NG = 1, 2; NQ = 1 cannot occur -- such a
+# plane has at most 1024 vertices), with and without a streamed tail
+ORD_TABLE += [(4, 1, 2, 256), (4, 2, 2, 256), (4, 2, 3, 256), (4, 1, 3, 256), (4, 2, 5, 256)]
 
 
 def _random_graph(n_active, n_iso, seed):
@@ -182,26 +195,27 @@ def _random_graph(n_active, n_iso, seed):
     return graph.laplacian(W.astype(np.float32), normalized=True)
 
 
-@pytest.mark.parametrize('pl,ng,nq', ORD_TABLE, ids=['p%d_ng%d_nq%d' % t for t in ORD_TABLE])
-def test_ordered_shape_table(dev, pl, ng, nq):
+@pytest.mark.parametrize('pl,ng,nq,nt', ORD_TABLE, ids=['p%d_ng%d_nq%d' % t[:3] + ('' if t[3] == 512 else '_nt%d' % t[3]) for t in ORD_TABLE])
+def test_ordered_shape_table(dev, pl, ng, nq, nt):
     """One launch per instantiated shape, named; every plane of the forward and of the adjoint against float64 on the device
     (K = 4, partial last plane group, more plane groups than workgroups, isolated vertices carrying data)."""
     from gcn_fmri_decoding_amd import _lib, graph, ops
     from oracle import graph_ref as GR
     lib = _lib.lib()
-    n_active = 2048 * (ng - 1) + 1000 if not (pl == 2 and ng == 5) else 10240
-    M = n_active + 4 if nq == ng else (2048 * (nq - 1) + 40 if not (pl == 2 and ng == 5) else 10800)
+    lvl = 4 * nt                                   # vertices per quad level
+    n_active = lvl * (ng - 1) + lvl // 2 - 24 if not (pl == 2 and ng == 5) else 10240
+    M = n_active + 4 if nq == ng else (lvl * (nq - 1) + 40 if not (pl == 2 and ng == 5) else 10800)
     L0 = _random_graph(n_active, M - n_active, 100 * pl + 10 * ng + nq)
     order = graph.length_order(L0)
     g = ops.Graph(L0, dev, order=order)
     assert g.ordered and g.query(16) == pl, (g.ordered, g.query(16))
     L = graph.permute(L0, order)
     Mp = g.Mp
-    ent = min(2048 * ng + 16, 160 * 1024 // (4 * pl))
-    stem = '%s<%d,%d,%d,512,' % ('cheb_ord_kernel' if pl == 4 else 'cheb_ord2_kernel', ent, min(nq, ng + 1), ng)
+    ent = min(lvl * ng + 16, 160 * 1024 // (4 * pl))
+    stem = '%s<%d,%d,%d,%d,' % ('cheb_ord_kernel' if pl == 4 else 'cheb_ord2_kernel', ent, min(nq, ng + 1), ng, nt)
     tail_f, tail_a = (' + cheb_ord_tail_kernel<false>', ' + cheb_ord_tail_kernel<true>') if nq > ng + 1 else ('', '')
-    assert g.query(17) == (2048 * (ng + 1) if nq > ng + 1 else 0)
-    B, Fin, K = 7, 301 if pl == 4 else 151, 4
+    assert g.query(17) == (lvl * (ng + 1) if nq > ng + 1 else 0)
+    B, Fin, K = (15 if nt == 256 else 7), 301 if pl == 4 else 151, 4
     nplanes = B * Fin
     gen = torch.Generator(device=dev)
     gen.manual_seed(M)
@@ -229,7 +243,11 @@ def test_ordered_shape_table(dev, pl, ng, nq):
     G[:, :, :, M:] = float('nan')
     dx = torch.full((B, Fin, Mp), float('nan'), device=dev)
     _lib.check(lib.chebgcn_recurrence_bwd(g.handle, P(G), P(dx), B, Fin, K, st), 'bwd')
-    assert _lib.last_dispatch() == stem + 'true>' + tail_a, _lib.last_dispatch()
+    if nt == 256:                                  # (the Clenshaw adjoint of these graphs: recurrence.hip's kernel, in this vertex order)
+        # (beyond 2048 rows in all -- isolated vertices count there --: the four-plane kernel of recurrence4.hip)
+        assert _lib.last_dispatch().startswith(('cheb_onchip_kernel<4,', 'cheb4_kernel<')) and ',true' in _lib.last_dispatch(), _lib.last_dispatch()
+    else:
+        assert _lib.last_dispatch() == stem + 'true>' + tail_a, _lib.last_dispatch()
     LTd = _sparse64(L64.T.tocsr(), dev)
     Gk = lambda k: G[k, :, :, :M].double().reshape(nplanes, M).t().contiguous()
     c2, c1 = torch.zeros_like(Gk(0)), Gk(K - 1)
@@ -237,16 +255,17 @@ def test_ordered_shape_table(dev, pl, ng, nq):
         c2, c1 = c1, Gk(j) + 2 * torch.sparse.mm(LTd, c1) - c2
     dref = (Gk(0) + torch.sparse.mm(LTd, c1) - c2).t()
     per_plane = (dx[:, :, :M].reshape(nplanes, M).double() - dref).abs().amax(dim=1) / dref.abs().amax(dim=1)
-    record_measured('ordered_shape_table[p%d_ng%d_nq%d]' % (pl, ng, nq), fwd_worst_plane=worst_f, adjoint_worst_plane=float(per_plane.max()))
+    record_measured('ordered_shape_table[p%d_ng%d_nq%d%s]' % (pl, ng, nq, '' if nt == 512 else '_nt%d' % nt), fwd_worst_plane=worst_f, adjoint_worst_plane=float(per_plane.max()))
     assert float(per_plane.max()) <= GREL, '%s: %.3e' % (stem, float(per_plane.max()))
 
 
 def test_ordered_recurrence_not_for_atlas_sizes(dev):
-    """Up to 2048 active vertices the generic on-chip kernel and the fused atlas layer work in the caller's order: a graph in
+    """Up to 1024 vertices per plane the generic on-chip kernel and the fused atlas layer work in the caller's order: a graph in
     length order gets no ordered image there (and cgcnn keeps the reference's tree order, models_gcn.py)."""
     import bench
     from gcn_fmri_decoding_amd import graph, ops
-    Ls, _ = bench.load_graph(1000, 1, 0, 1, None)
+    Ls, _ = bench.load_graph(900, 1, 0, 1, None)
+    assert Ls[0].shape[0] <= 1024
     g = ops.Graph(Ls[0], dev, order=graph.length_order(Ls[0]))
     assert not g.ordered and g.query(16) == 0
 

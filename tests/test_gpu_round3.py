@@ -135,8 +135,9 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
     """The network the reference's ``training.py`` actually builds (model.py:271-280, training.py:34,
     configure_fmri.py:28, 41): atlas-sized graph (360 = MMP atlas; 1000), kNN-8, one coarsening level, ChebNet
     K = 10 x 6, F = 32, p = 1, b2relu, FC 512-256-22, batch 128, block_dura 15 -- logits, loss, every gradient and
-    one TF-form Adam step against the oracle, on the kernels this shape selects (generic four-plane recurrence, batch
-    split of the bias gradient), eagerly and through the captured HIP graph."""
+    one TF-form Adam step against the oracle, on the kernels this shape selects (fused atlas layer / generic four-plane recurrence /
+    the 256-thread ordered recurrence on the relabelled graph; batch split of the bias gradient), eagerly and through the
+    captured HIP graph."""
     from gcn_fmri_decoding_amd import graph, models_gcn
     from conftest import assert_adam_params_close
     Ls, perm, _ = graph.synthetic_graph(n_nodes, k=8, levels=1)
@@ -198,7 +199,11 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
     record_measured('reference_training_shape_vs_oracle[%d]' % n_nodes, what='[quantile, max] of the GPU, of the fp32 oracle; of scale',
                     **measured)
     for k, (q_gpu, m_gpu, q_o32, m_o32, group) in measured.items():
-        assert q_gpu <= max(1e-4 if group == 'convb' else 5e-4, 3 * q_o32), \
+        # (round 6, tools/probes/n1000_grad_noise.py: the same variables in the caller's and in the length order, three seeds each --
+        # an instance without a ReLU flip comes out at 1e-7 for EVERY conv gradient in either order, one with flips at 5e-5 ...
+        # 4.5e-4 at these quantiles in either order (a flip in layer l moves dy of every vertex within K - 1 = 9 hops in the layers
+        # below: most of a 1000-vertex graph).  The instance of this test has its flip; the bound is the weights' for both groups)
+        assert q_gpu <= max(5e-4, 3 * q_o32), \
             'grad %s: quantile %.3e (fp32 oracle %.3e)' % (k, q_gpu, q_o32)
         if group != 'convb':          # a weight gradient sums over every vertex and window: single flips average out
             assert m_gpu <= max(2e-3, 3 * m_o32), 'grad %s: max %.3e (fp32 oracle %.3e)' % (k, m_gpu, m_o32)
@@ -220,8 +225,15 @@ def test_reference_training_shape_vs_oracle(ops, dev, n_nodes):
                      'fused_layer_bwd_x | fused_layer_kernel<%d,8,true>' % nw):
             assert want in names, (want, names)
         assert not any(n.startswith('recurrence') for n in names), names
-    else:
+    elif ops.plane_stride(M) <= 1024:
         assert not any('fused_layer' in n for n in names) and any(n.startswith('recurrence_fwd | cheb_onchip_kernel<4,') for n in names), names
+    else:
+        # planes of more than 1024 vertices (N = 1000: M = 1044): cgcnn relabels the level by row length and the forward recurrence --
+        # on the activations and, for the input gradient, on dy -- is the 256-thread ordered kernel (round 6)
+        assert net.vertex_order == 'length' and net.graphs[0].ordered
+        for want in ('recurrence_fwd | cheb_ord_kernel<1040,2,1,256,false>', 'recurrence_fwd_t | cheb_ord_kernel<1040,2,1,256,false>'):
+            assert want in names, (want, names)
+        assert not any('fused_layer' in n or n.startswith('recurrence_bwd') for n in names), names
     # the same model through the captured graph: two more eager steps, capture, replay -- bit-identical to a twin that
     # runs all of them eagerly
     twin = models_gcn.cgcnn({'device': dev}, [L] * 6, F, K, p, Mfc, filter='chebyshev5', brelu='b2relu', pool='mpool1', initial='he',

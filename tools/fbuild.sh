@@ -10,5 +10,5 @@ while [ $# -gt 1 ]; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on $flags -Rpass-analysis=kernel-resource-usage -c fused_small.hip -o ../../build_x/fused_small_$name.o 2>&1 \
     | grep -i "Function Name\|VGPRs:\|AGPRs:\|Occupancy\|Scratch" | sed 's/.*remark: *//' | paste - - - - - | sed 's/\[-Rpass[^]]*\]//g' \
     | grep "fused_layer_kernelILi12ELi8" | sed "s/^/$name: /" | cut -c1-220
-  /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 graph.o recurrence.o recurrence4.o recurrence_ord.o recurrence_ord2.o recurrence_ord2a.o contract.o contract_bf16.o pointwise.o head.o ../../build_x/fused_small_$name.o coarsen_host.o -o ../../build_x/libchebgcn_$name.so
+  /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 graph.o recurrence.o recurrence4.o recurrence_ord.o recurrence_ord2.o recurrence_ord2a.o recurrence_ord_small.o contract.o contract_bf16.o pointwise.o head.o ../../build_x/fused_small_$name.o coarsen_host.o -o ../../build_x/libchebgcn_$name.so
 done

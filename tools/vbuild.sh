@@ -8,9 +8,9 @@ make -s -j8
 mkdir -p ../../build_x
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
-  for f in recurrence recurrence4 recurrence_ord recurrence_ord2 recurrence_ord2a; do
+  for f in recurrence recurrence4 recurrence_ord recurrence_ord2 recurrence_ord2a recurrence_ord_small; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on $flags -c $f.hip -o ../../build_x/${f}_$name.o &
   done
   wait
-  /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 graph.o ../../build_x/recurrence_$name.o ../../build_x/recurrence4_$name.o ../../build_x/recurrence_ord_$name.o ../../build_x/recurrence_ord2_$name.o ../../build_x/recurrence_ord2a_$name.o contract.o contract_bf16.o pointwise.o head.o fused_small.o coarsen_host.o -o ../../build_x/libchebgcn_$name.so
+  /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 graph.o ../../build_x/recurrence_$name.o ../../build_x/recurrence4_$name.o ../../build_x/recurrence_ord_$name.o ../../build_x/recurrence_ord2_$name.o ../../build_x/recurrence_ord2a_$name.o ../../build_x/recurrence_ord_small_$name.o contract.o contract_bf16.o pointwise.o head.o fused_small.o coarsen_host.o -o ../../build_x/libchebgcn_$name.so
 done
