@@ -322,9 +322,15 @@ contract_fwd_ring_kernel(FwdArgs a, int nrows_pad) {
 // 0, 1, 2, 3), and every wave finishes a quarter of the filter rows (bias, ReLU, pooling, store).  Four times the waves,
 // a quarter of the chain per wave.  (The sum is the same products in four chains instead of one: fp32 round-off differs
 // from the big-launch kernel in the last bits, deterministic for a given shape.)
-__global__ void __launch_bounds__(256)
+// (round 6: the reduction in two halves of the accumulator rows through 32 KB instead of 64 -- three workgroups per CU instead of
+// two; mid-sized launches, N = 1000 at batch 128: 1152 workgroups, ran in 2.25 rounds of 512 resident ones.  Same sums in the
+// same order.)
+#ifndef CG_LB_SPLITK
+#define CG_LB_SPLITK 3
+#endif
+__global__ void __launch_bounds__(256, CG_LB_SPLITK)
 contract_fwd_splitk_kernel(FwdArgs a) {
-    __shared__ float red[4][64][64];                   // [wave][accumulator register r*16+j][lane]
+    __shared__ float red[4][32][64];                   // [wave][accumulator register r*8 + (j & 7)][lane], rows j < 8 then j >= 8
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
@@ -381,20 +387,26 @@ contract_fwd_splitk_kernel(FwdArgs a) {
             acc[3] = mfma(w, bv[u].w, acc[3]);
         }
     }
+    // wave w finishes the accumulator registers j = 4w .. 4w+3 (filter rows acc_row(j, h)): waves 0, 1 in the first half, 2, 3 in the second
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) red[wave][r * 16 + j][lane] = acc[r][j];
-    __syncthreads();
-    // wave w finishes the accumulator registers j = 4w .. 4w+3 (filter rows acc_row(j, h))
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = 4 * wave + jj;
-        float v[4];
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                     // the first half's sums are read
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            v[r] = ((red[0][r * 16 + j][lane] + red[1][r * 16 + j][lane]) + red[2][r * 16 + j][lane]) + red[3][r * 16 + j][lane];
-        fwd_epilogue_row(a, b, acc_row(j, h), v, n0, valid, c);
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8) red[wave][r * 8 + j8][lane] = acc[r][8 * half + j8];
+        __syncthreads();
+        if ((wave >> 1) == half) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j8 = 4 * (wave & 1) + jj;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] = ((red[0][r * 8 + j8][lane] + red[1][r * 8 + j8][lane]) + red[2][r * 8 + j8][lane]) + red[3][r * 8 + j8][lane];
+                fwd_epilogue_row(a, b, acc_row(8 * half + j8, h), v, n0, valid, c);
+            }
+        }
     }
 }
 
