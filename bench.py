@@ -258,10 +258,13 @@ def refshape_leg(dev, n_nodes, steps, warmup, batch=128, korder=10, block_dura=1
         xbuf = ops.plane_empty(batch, block_dura, int(Ls[0].shape[0]), dev)
         perm_dev = net.compose_perm(perm)
 
+        lab_order = labels[order.long()]      # (the labels of every step's batch, gathered once like fit()'s per-epoch label pool)
+
         def step(i):
             idx = order[i]
-            x = net.as_internal(ops.perm_data(data, perm_dev, idx, out=xbuf))
-            return net.train_step(x, labels[idx.long()])
+            xb = net.step_inputs()[0]          # the captured step's input buffer, once there is one: no copy into it
+            x = net.as_internal(ops.perm_data(data, perm_dev, idx, out=xb if xb is not None else xbuf))
+            return net.train_step(x, lab_order[i])
         for i in range(warmup):
             step(i)
         torch.cuda.synchronize()

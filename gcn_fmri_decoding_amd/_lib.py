@@ -46,7 +46,9 @@ SIGNATURES = {
     'chebgcn_contract_bwd_w_bf16': (_i, [_p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _i, _p]),
     'chebgcn_adam_partials': (_i, [_i64]),
     'chebgcn_adam_step_sq': (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _p]),
+    'chebgcn_adam_step_sq_all': (_i, [_p, _p, _p, _p, _i64, _i64, _f, _p, _f, _f, _f, _f, _f, _p, _p]),
     'chebgcn_loss_bookkeeping': (_i, [_p, _p, _i, _f, _p, _f, _f, _p, _p, _p, _p]),
+    'chebgcn_set_scalars': (_i, [_p, C.c_float, C.c_float, _p]),
     'chebgcn_softmax_xent': (_i, [_p, _p, _i, _p, _p, _i, _i, _p]),
     'chebgcn_relu_grad_bf16': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p]),
     'chebgcn_bf16_dy16_supported': (_i, [_i, _i, _i, _i, _i]),
@@ -63,6 +65,8 @@ SIGNATURES = {
     'chebgcn_contract_bwd_x': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_x_relu': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_bwd_w_relu': (_i, [_p, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
+    'chebgcn_contract_bwd_w_relu_bias_merged': (_i, [_i, _i, _i, _i, _i]),
+    'chebgcn_contract_bwd_w_relu_bias': (_i, [_p, _p, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _i, _i, _p]),
     'chebgcn_contract_fwd_mean_supported': (_i, [_i, _i, _i, _i, _i]),
     'chebgcn_contract_fwd_gated_supported': (_i, [_i, _i, _i, _i, _i]),
     'chebgcn_contract_fwd_gated': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

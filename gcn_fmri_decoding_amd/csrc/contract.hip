@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "contract_common.h"
+#include "bias_grad_body.h"
 #ifndef CG_DY_NT
 #define CG_DY_NT 0      // dy is read by three kernels of a layer's backward (bias, bwd_w, bwd_x): cached loads, 3.83 -> 3.795 ms per step
 #endif
@@ -820,12 +821,11 @@ contract_bwd_w_kernel(BwdWArgs a) {
 // Both stages in one launch for few partials (small launches: an atlas-sized layer leaves 192): block (row, y, z), four
 // thread groups take every fourth partial (eight in flight), fixed-order LDS sum, scatter to dW[kk][o].  One launch and
 // one pass instead of two launches with a round trip through `stage` (6.5 + 4.8 us + a launch gap at N = 360).
-__global__ void __launch_bounds__(256)
-reduce_partials_small(const float* __restrict__ partial, float* __restrict__ dW, int nx, int ny, int rt, int FinK, int Fout) {
+__device__ __forceinline__ void reduce_partials_small_body(const float* __restrict__ partial, float* __restrict__ dW, int nx, int ny,
+                                                           int rt, int FinK, int Fout, int row, int y, int z) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int per = rt * 16 * 64;
-    const int row = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
     const float* base = partial + ((size_t)z * ny + y) * nx * per + (size_t)row * 64 + lane;
     float s = 0.f;
     for (int x0 = part; x0 < nx; x0 += 8 * 4) {
@@ -847,6 +847,31 @@ reduce_partials_small(const float* __restrict__ partial, float* __restrict__ dW,
         const int kk = (y * rt + tt) * 32 + acc_row(j, h);
         const int fo = z * 32 + (lane & 31);
         if (kk < FinK && fo < Fout) dW[(size_t)kk * Fout + fo] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+reduce_partials_small(const float* __restrict__ partial, float* __restrict__ dW, int nx, int ny, int rt, int FinK, int Fout) {
+    reduce_partials_small_body(partial, dW, nx, ny, rt, FinK, Fout, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// The same launch also reducing the per-vertex bias gradient of the layer (round 6): an atlas-sized layer's backward is a chain of
+// launches of about 5 us each, and the bias reduction (bias_grad_relu_kernel<VERTEX,16>: 192 workgroups at N = 360) was one of them
+// -- its workgroups ride behind the 160 of this reduction: blocks [0, nred) add partials, blocks [nred, nred + nbx*F) are the bias
+// kernel's (bx, f) jobs.  Same code, same sums, same order as the two launches.
+__global__ void __launch_bounds__(256)
+reduce_partials_small_bias_kernel(const float* __restrict__ partial, float* __restrict__ dW, int nx, int ny, int nz, int rt, int FinK,
+                                  int Fout, const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dbias,
+                                  int B, int M, int Mp, int nbx) {
+    const int nrow = rt * 16, nred = nrow * ny * nz;
+    const int id = blockIdx.x;                        // (uniform: every thread of a block takes the same arm)
+    if (id < nred) {
+        const int row = id % nrow, yz = id / nrow;
+        reduce_partials_small_body(partial, dW, nx, ny, rt, FinK, Fout, row, yz % ny, yz / ny);
+    } else {
+        const int j = id - nred;
+        bias_grad_relu_body<CHEBGCN_BIAS_VERTEX, 16, false, true>(dout, mask, nullptr, dbias, nullptr, B, M, Mp, Fout,
+                                                                   (size_t)Fout * Mp, (size_t)Mp, j % nbx, j / nbx, nbx);
     }
 }
 
@@ -1175,8 +1200,9 @@ extern "C" size_t chebgcn_contract_bwd_w_workspace(int B, int M, int Fin, int K,
     return (size_t)gx * gy * gz * rt * 16 * 64 * sizeof(float);   // one partial per workgroup
 }
 
+static bool bwd_w_merges_bias(int B, int M, int Fin, int K, int Fout);
 static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask, float* dW, void* workspace, int B, int M,
-                        int Fin, int K, int Fout, hipStream_t stream, bool one_plane = false) {
+                        int Fin, int K, int Fout, hipStream_t stream, bool one_plane = false, float* dbias_vertex = nullptr) {
     BwdWArgs a;
     a.stack = stack; a.dy = dy; a.partial = (float*)workspace; a.mask = mask;
     a.B = B; a.M = M; a.Mp = plane_stride(M); a.Fin = Fin; a.K = K; a.Fout = Fout; a.FinK = Fin * K;
@@ -1210,6 +1236,15 @@ static int launch_bwd_w(const float* stack, const float* dy, const uint8_t* mask
 #undef CG_BW
 #undef CG_BWK
     CG_HIP(hipGetLastError());
+    if (dbias_vertex) {                               // (the caller checked bwd_w_merges_bias: a small launch, the 16-subset bias shape)
+        int parts = 0;
+        const int nbx = bias_grad_blocks(M, Fout, &parts);
+        note_dispatch_more("reduce_partials_small_bias_kernel");
+        hipLaunchKernelGGL(reduce_partials_small_bias_kernel, dim3(rt * 16 * gy * gz + nbx * Fout), dim3(256), 0, stream,
+                           (const float*)workspace, dW, gx, gy, gz, rt, a.FinK, Fout, dy, mask, dbias_vertex, B, M, a.Mp, nbx);
+        CG_HIP(hipGetLastError());
+        return CHEBGCN_OK;
+    }
     if (gx <= 256) {
         note_dispatch_more("reduce_partials_small");
         hipLaunchKernelGGL(reduce_partials_small, dim3(rt * 16, gy, gz), dim3(256), 0, stream, (const float*)workspace, dW, gx, gy, rt,
@@ -1252,4 +1287,31 @@ extern "C" int chebgcn_contract_bwd_w_relu(const float* stack, const float* dout
     CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout),
                "contract_bwd_w_relu: workspace too small");
     return launch_bwd_w(stack, dout, relu_mask, dW, workspace, B, M, Fin, K, Fout, (hipStream_t)stream_);
+}
+
+// one launch for the partials' sum and the per-vertex bias gradient: where the weight gradient leaves few partials (a small launch)
+// and the bias reduction takes its 16-subset shape (the same condition chebgcn_brelu_pool_bwd applies)
+static bool bwd_w_merges_bias(int B, int M, int Fin, int K, int Fout) {
+    const int ntiles = (Fin * K + 31) / 32, rt = bw_rt(ntiles);
+    const int gy = (ntiles + rt - 1) / rt, gz = (Fout + 31) / 32;
+    int parts = 0;
+    bias_grad_blocks(M, Fout, &parts);
+    return bw_grid_x(B, M, gy * gz) <= 256 && parts == 16;
+}
+
+extern "C" int chebgcn_contract_bwd_w_relu_bias_merged(int B, int M, int Fin, int K, int Fout) {
+    if (B <= 0 || M <= 0 || Fin <= 0 || K <= 0 || Fout <= 0) return 0;
+    return bwd_w_merges_bias(B, M, Fin, K, Fout) ? 1 : 0;
+}
+
+extern "C" int chebgcn_contract_bwd_w_relu_bias(const float* stack, const float* dout, const uint8_t* relu_mask, float* dW,
+                                                float* dbias, void* workspace, size_t workspace_bytes, int B, int M, int Fin,
+                                                int K, int Fout, chebgcn_stream stream_) {
+    CG_REQUIRE(stack && dout && relu_mask && dW && dbias && workspace, "contract_bwd_w_relu_bias: NULL argument");
+    CG_REQUIRE(B > 0 && M > 0 && Fin > 0 && K > 0 && Fout > 0, "contract_bwd_w_relu_bias: bad shape");
+    CG_REQUIRE(workspace_bytes >= chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout),
+               "contract_bwd_w_relu_bias: workspace too small");
+    if (!bwd_w_merges_bias(B, M, Fin, K, Fout))
+        return fail(CHEBGCN_EUNSUPPORTED, "contract_bwd_w_relu_bias: not a small launch (chebgcn_contract_bwd_w_relu_bias_merged)");
+    return launch_bwd_w(stack, dout, relu_mask, dW, workspace, B, M, Fin, K, Fout, (hipStream_t)stream_, false, dbias);
 }

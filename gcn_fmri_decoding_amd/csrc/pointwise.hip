@@ -4,9 +4,7 @@
 #include <algorithm>
 
 #include "common.h"
-#ifndef CG_DY_NT
-#define CG_DY_NT 0      // see contract.hip
-#endif
+#include "bias_grad_body.h"
 
 namespace chebgcn {
 
@@ -93,58 +91,8 @@ __global__ void __launch_bounds__(256)
 bias_grad_relu_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ mask, float* __restrict__ dy,
                       float* __restrict__ dbias, float* __restrict__ fpart, int B, int M, int Mp, int F,
                       size_t d_bstride, size_t d_fstride) {      // element strides of dout: F*Mp and Mp, or Mp and 0 (one plane per window)
-    __shared__ float4 psum[256];
-    constexpr int QL = 256 / NP;                        // quads per workgroup
-    const int ql = threadIdx.x % QL, part = threadIdx.x / QL;
-    const int Mq = Mp >> 2;
-    const int q = blockIdx.x * QL + ql;
-    const int f = blockIdx.y;
-    const bool live = q < Mq;
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
-        const float* gp = dout + (size_t)f * d_fstride + 4 * q;
-        const uint8_t* mp = MASKED ? mask + (size_t)f * Mq + q : nullptr;
-#pragma unroll 4
-        for (int b = part; b < B; b += NP) {
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const f32x4 g = CG_DY_NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride))
-                                     : *reinterpret_cast<const f32x4*>(gp + (size_t)b * d_bstride);
-            const int bits = MASKED ? mp[(size_t)b * F * Mq] : 15;
-            const float4 d = make_float4((bits & 1) ? g.x : 0.f, (bits & 2) ? g.y : 0.f, (bits & 4) ? g.z : 0.f,
-                                         (bits & 8) ? g.w : 0.f);
-            if (DY16) {
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                const bf16x4 h = {(__bf16)d.x, (__bf16)d.y, (__bf16)d.z, (__bf16)d.w};
-                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(dy) + ((size_t)b * F + f) * Mp + 4 * q) = h;
-            } else if (MASKED && dy) {
-                *reinterpret_cast<float4*>(dy + ((size_t)b * F + f) * Mp + 4 * q) = d;
-            }
-            sum.x += d.x; sum.y += d.y; sum.z += d.z; sum.w += d.w;
-        }
-        const int m = 4 * q;                            // the padding of the plane takes no gradient
-        sum.x = m + 0 < M ? sum.x : 0.f;
-        sum.y = m + 1 < M ? sum.y : 0.f;
-        sum.z = m + 2 < M ? sum.z : 0.f;
-        sum.w = m + 3 < M ? sum.w : 0.f;
-    }
-    if (BIAS == CHEBGCN_BIAS_NONE) return;
-    psum[threadIdx.x] = sum;
-    __syncthreads();
-    if (part == 0) {
-        float4 t = psum[ql];
-#pragma unroll
-        for (int p = 1; p < NP; ++p) {
-            const float4 o = psum[p * QL + ql];
-            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-        }
-        if (BIAS == CHEBGCN_BIAS_VERTEX) {
-            if (live) *reinterpret_cast<float4*>(dbias + (size_t)f * Mp + 4 * q) = t;
-        } else {
-            float s = (t.x + t.y) + (t.z + t.w);
-            for (int d = QL / 2; d > 0; d >>= 1) s += __shfl_xor(s, d);      // the QL lanes of part 0 (QL <= 64: one wave)
-            if (ql == 0) fpart[(size_t)f * gridDim.x + blockIdx.x] = s;
-        }
-    }
+    bias_grad_relu_body<BIAS, NP, DY16, MASKED>(dout, mask, dy, dbias, fpart, B, M, Mp, F, d_bstride, d_fstride, (int)blockIdx.x,
+                                                (int)blockIdx.y, (int)gridDim.x);
 }
 
 // second stage of the per-filter bias gradient (b1relu, models_gcn.py:619-623): one wave per filter adds the
@@ -564,14 +512,15 @@ adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
 __global__ void __launch_bounds__(256)
 adam_sq_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                float lr_t_val, const float* __restrict__ lr_t_dev, float b1, float b2, float eps, float gscale, float l2,
-               float* __restrict__ sq_part) {
+               float* __restrict__ sq_part, int64_t n_reg) {      // elements [n_reg, n): no L2 term, not in the sum of squares
     __shared__ float red[256];
     const float lr_t = lr_t_dev ? *lr_t_dev : lr_t_val;
     float sq = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float pi = p[i];
-        sq = fmaf(pi, pi, sq);
-        const float gi = fmaf(l2, pi, gscale * g[i]);
+        const bool rg = i < n_reg;
+        sq = rg ? fmaf(pi, pi, sq) : sq;
+        const float gi = fmaf(rg ? l2 : 0.f, pi, gscale * g[i]);
         const float mi = m[i] + (1.f - b1) * (gi - m[i]);
         const float vi = v[i] + (1.f - b2) * (gi * gi - v[i]);
         m[i] = mi;
@@ -644,13 +593,7 @@ extern "C" int chebgcn_brelu_pool_fwd(const float* x, const float* bias, int bia
 
 // workgroups along the vertex axis of the gradient kernels below (= per-filter partials of a b1relu layer)
 static int brelu_bwd_blocks(int M, int F, int pool, int relu, bool have_mask, int* parts_out, bool bias_only = false) {
-    const int Mp = plane_stride(M);
-    if (pool == 1 && ((relu && have_mask) || bias_only)) {
-        // bias_grad_relu_kernel: 64 quads x 4 batch subsets per workgroup, or 16 x 16 where that leaves the chip short of work
-        const bool fine = ((Mp / 4 + 63) / 64) * F < 512;
-        if (parts_out) *parts_out = fine ? 16 : 4;
-        return fine ? (Mp / 4 + 15) / 16 : (Mp / 4 + 63) / 64;
-    }
+    if (pool == 1 && ((relu && have_mask) || bias_only)) return bias_grad_blocks(M, F, parts_out);       // bias_grad_relu_kernel
     // enough workgroups for the chip: small graphs split the batch over 4 or 8 thread groups
     const int parts = ((M + 255) / 256) * F >= 1024 ? 1 : ((M + 63) / 64) * F >= 1024 ? 4 : 8;
     if (parts_out) *parts_out = parts;
@@ -1058,7 +1001,34 @@ extern "C" int chebgcn_adam_step_sq(float* p, const float* g, float* m, float* v
     CG_REQUIRE(p && g && m && v && sq_partials && n > 0, "adam_step_sq: bad argument");
     note_dispatch("adam_sq_kernel");
     hipLaunchKernelGGL(adam_sq_kernel, dim3((unsigned)chebgcn_adam_partials(n)), dim3(256), 0, stream, p, g, m, v, n, lr_t, lr_t_dev,
-                       beta1, beta2, eps, grad_scale, l2, sq_partials);
+                       beta1, beta2, eps, grad_scale, l2, sq_partials, n);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+extern "C" int chebgcn_adam_step_sq_all(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_reg, float lr_t,
+                                        const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, float l2,
+                                        float* sq_partials, chebgcn_stream stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CG_REQUIRE(p && g && m && v && sq_partials && n > 0 && n_reg >= 0 && n_reg <= n, "adam_step_sq_all: bad argument");
+    note_dispatch("adam_sq_kernel<all>");
+    hipLaunchKernelGGL(adam_sq_kernel, dim3((unsigned)chebgcn_adam_partials(n)), dim3(256), 0, stream, p, g, m, v, n, lr_t, lr_t_dev,
+                       beta1, beta2, eps, grad_scale, l2, sq_partials, n_reg);
+    CG_HIP(hipGetLastError());
+    return CHEBGCN_OK;
+}
+
+namespace chebgcn {
+__global__ void set_scalars_kernel(float* dst, float v0, float v1) {
+    dst[0] = v0;
+    dst[1] = v1;
+}
+}  // namespace chebgcn
+
+extern "C" int chebgcn_set_scalars(float* dst, float v0, float v1, chebgcn_stream stream_) {
+    CG_REQUIRE(dst, "set_scalars: NULL argument");
+    note_dispatch("set_scalars_kernel");
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, dst, v0, v1);
     CG_HIP(hipGetLastError());
     return CHEBGCN_OK;
 }

@@ -135,11 +135,12 @@ class base_model(object):
             data = data.toarray()       # sparse matrices, like the reference (:42-46)
         return torch.as_tensor(np.ascontiguousarray(data, np.float32)).to(self.device)
 
-    def _gather(self, data_dev, idx):
+    def _gather(self, data_dev, idx, out=None):
         """``data[idx]`` gathered on the GPU straight into plane storage [B, channel, Mp], in the model's internal vertex
-        order (replaces the host gather + feed of :142-146)."""
+        order (replaces the host gather + feed of :142-146).  ``out``: a buffer of that shape (``step_inputs()``)."""
         S, M, C = data_dev.shape
-        out = ops.plane_empty(int(idx.numel()), C, M, self.device)
+        if out is None or tuple(out.shape) != (int(idx.numel()), C, ops.plane_stride(M)):
+            out = ops.plane_empty(int(idx.numel()), C, M, self.device)
         from . import _lib
         _lib.check(_lib.lib().chebgcn_perm_data(ops._p(data_dev), ops._p(self._order_dev) if self._order is not None else None,
                                                 ops._p(idx), ops._p(out), int(idx.numel()), M, M, C, ops._stream()), 'perm_data')
@@ -302,7 +303,7 @@ class base_model(object):
             idx_dev = pool_dev[pool_at:pool_at + self.batch_size]
             batch_labels = pool_labels[pool_at:pool_at + self.batch_size]
             pool_at += self.batch_size
-            x = self._gather(train_dev, idx_dev)
+            x = self._gather(train_dev, idx_dev, out=self.step_inputs()[0])      # (straight into the captured step's input buffer)
             learning_rate, loss_average = self.train_step(x, batch_labels)
             if self.record_fit:
                 self.fit_log['idx'].append(np.asarray(idx))
@@ -619,23 +620,35 @@ class base_model(object):
                 self._step_graph_on = False
                 self._sg = None
                 return self.train_step(self.as_internal(x_storage), labels)
-        if sg['x'].data_ptr() != x_storage.data_ptr():
+        if sg['x'].data_ptr() != x_storage.data_ptr():      # (a caller that gathered its batch into step_inputs() saves the copy)
             sg['x'].copy_(x_storage)
-        sg['labels'].copy_(labels)
+        if sg['labels'].data_ptr() != labels.data_ptr():
+            sg['labels'].copy_(labels)
         t = self.global_step + 1
-        sg['lr_t'].fill_(self._adam_lr_t(t))
-        sg['ema_c'].fill_(self._ema_read(t))
+        from . import _lib                                  # this step's two scalars, one launch
+        _lib.check(_lib.lib().chebgcn_set_scalars(ops._p(sg['scal']), float(self._adam_lr_t(t)), float(self._ema_read(t)),
+                                                  ops._stream()), 'set_scalars')
         sg['graph'].replay()
         reported_lr = self.training(None, self.learning_rate, self.decay_steps, self.decay_rate, self.momentum)
         self.global_step += 1
         return reported_lr, sg['loss_average'].clone()
 
+    def step_inputs(self):
+        """The input buffers of the captured training step, ``(x [B, channel, Mp] in the internal vertex order, labels [B])``, or
+        ``(None, None)`` while there is none (eager steps, the first calls before the capture).  A caller that gathers its batch
+        straight into them (``_gather(..., out=x)``, ``ops.perm_data(..., out=x)``; hand ``as_internal(x)`` and the labels buffer
+        to ``train_step``) saves the two copies ``train_step`` would make."""
+        sg = getattr(self, '_sg', None)
+        if sg is None or not self._step_graph_on:
+            return None, None
+        return sg['x'], sg['labels']
+
     def _capture_step(self, x_storage, labels):
         if ops.timers is not None:
             raise RuntimeError('per-kernel event timers cannot run inside a captured step')
         dev = self.device
-        sg = {'x': x_storage.detach().clone(), 'labels': labels.detach().clone(),
-              'lr_t': torch.zeros(1, dtype=torch.float32, device=dev), 'ema_c': torch.zeros(1, dtype=torch.float32, device=dev)}
+        scal = torch.zeros(2, dtype=torch.float32, device=dev)
+        sg = {'x': x_storage.detach().clone(), 'labels': labels.detach().clone(), 'scal': scal, 'lr_t': scal[0:1], 'ema_c': scal[1:2]}
         if self._loss_ema is None:
             self._loss_ema = torch.zeros((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
@@ -686,8 +699,10 @@ class base_model(object):
         if r > 0 and want_sq:
             if getattr(self, '_sq_part', None) is None:
                 self._sq_part = torch.zeros(4096, dtype=torch.float32, device=self.device)
-            nparts = ops.adam_step_sq(self._flat[:r], self._grad[:r], self._adam_m[:r], self._adam_v[:r], lr_t, self._sq_part, b1, b2,
-                                      1e-8, grad_scale, self.regularization)
+            # every variable in ONE launch: the regularised ones (weights: the first r elements of the flat buffer) with the L2 term
+            # and the partial sums of their squares, the biases behind them without
+            return ops.adam_step_sq_all(self._flat, self._grad, self._adam_m, self._adam_v, r, lr_t, self._sq_part, b1, b2, 1e-8,
+                                        grad_scale, self.regularization)
         elif r > 0:
             ops.adam_step(self._flat[:r], self._grad[:r], self._adam_m[:r], self._adam_v[:r], lr_t, b1, b2, 1e-8,
                           grad_scale, self.regularization)

@@ -610,6 +610,7 @@ class ChebConv(torch.autograd.Function):
         dy16 = bool(bf16_dy16 and not fold and ctx.precision == 'bf16' and pool == 1 and relu and argmax is not None
                     and lib.chebgcn_bf16_dy16_supported(B, M, Fin, K, Fout))
         gstack = None
+        merge_bias = False
         if by_fwd and mean:
             # the last layer under the fused feature mean: every filter's gradient is the plane gout / Fout; one pass gates it
             # with the ReLU mask into slab 0 of the stack the recurrence fills and reduces the bias gradient
@@ -623,7 +624,12 @@ class ChebConv(torch.autograd.Function):
             # ReluGrad folded into the two contraction gradients (chebgcn_contract_bwd_*_relu read gout and the
             # mask); what is left of this pass is the bias reduction, which writes nothing but dbias
             dy, mask = gout, argmax
-            if dbias is not None:
+            # small launches (atlas-sized layers): the per-vertex bias gradient rides in the launch that adds the weight gradient's
+            # partials (chebgcn_contract_bwd_w_relu_bias) -- one ~5 us launch less per layer
+            merge_bias = bool(merge_bias_small and dbias is not None and bias_kind == BIAS_VERTEX and not mean
+                              and ctx.needs_input_grad[1] and not PRECISIONS[ctx.precision]
+                              and lib.chebgcn_contract_bwd_w_relu_bias_merged(B, M, Fin, K, Fout))
+            if dbias is not None and not merge_bias:
                 # feeds nothing in backward: enqueued BEHIND contract_bwd_x / recurrence_bwd (the chain the next layer waits
                 # for) -- 3.88 against 3.93 ms per step at the bench shape; on the second stream it costs 4 %
                 def bias_job():
@@ -703,6 +709,9 @@ class ChebConv(torch.autograd.Function):
                 elif fold and mean:
                     call = lambda: lib.chebgcn_contract_bwd_w_relu_mean(_p(stack), _p(dy), _p(mask), _p(dW), _p(ws), ws.numel(),
                                                                         B, M, Fin, K, Fout, _stream())
+                elif fold and merge_bias:
+                    call = lambda: lib.chebgcn_contract_bwd_w_relu_bias(_p(stack), _p(dy), _p(mask), _p(dW), _p(dbias), _p(ws),
+                                                                        ws.numel(), B, M, Fin, K, Fout, _stream())
                 elif fold:
                     call = lambda: lib.chebgcn_contract_bwd_w_relu(_p(stack), _p(dy), _p(mask), _p(dW), _p(ws), ws.numel(), B,
                                                                    M, Fin, K, Fout, _stream())
@@ -843,6 +852,7 @@ class GateLink:
 
 
 gate_links = os.environ.get('CHEBGCN_GATE_LINKS', '1') != '0'
+merge_bias_small = os.environ.get('CHEBGCN_MERGE_BIAS_SMALL', '1') != '0'     # the bias gradient in the weight gradient's reduce launch (small launches)
 
 
 def conv_mean_supported(B, M, Fin, K, Fout, pool, relu, precision='f32'):
@@ -1011,6 +1021,26 @@ def fc_backward(x, W, g, y, dW, db, need_dx):
     _lib.check(L.chebgcn_fc_bwd(_p(x), x.stride(0), _p(W), _p(g), _p(y), _p(dW), _p(db), _p(dx), I, B, I, O, _stream()),
                'fc_bwd')
     return (dx,)
+
+
+def adam_step_sq_all(p, g, m, v, n_reg, lr_t, sq_partials, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):
+    """``adam_step_sq`` over ALL variables in one launch: the first ``n_reg`` elements are regularised (L2 term in the gradient,
+    counted in the partial sums of squares), the rest -- the biases -- take plain Adam.  Returns the number of partials."""
+    _require_cuda(p, g, m, v, sq_partials)
+    n = p.numel()
+    if not (g.numel() == m.numel() == v.numel() == n) or n == 0 or not (0 <= n_reg <= n):
+        raise ValueError('adam_step_sq_all: size mismatch')
+    lib = _lib.lib()
+    nparts = lib.chebgcn_adam_partials(n)
+    if sq_partials.dtype != torch.float32 or sq_partials.numel() < nparts:
+        raise ValueError('adam_step_sq_all: sq_partials needs %d float32' % nparts)
+    dev_lr = isinstance(lr_t, torch.Tensor)
+    if dev_lr and (lr_t.dtype != torch.float32 or lr_t.numel() != 1 or not lr_t.is_cuda):
+        raise ValueError('adam_step_sq_all: a device lr_t must be one float32')
+    _lib.check(lib.chebgcn_adam_step_sq_all(_p(p), _p(g), _p(m), _p(v), n, int(n_reg), 0.0 if dev_lr else float(lr_t),
+                                            _p(lr_t) if dev_lr else None, float(beta1), float(beta2), float(eps), float(grad_scale),
+                                            float(l2), _p(sq_partials), _stream()), 'adam_step_sq_all')
+    return nparts
 
 
 def adam_step_sq(p, g, m, v, lr_t, sq_partials, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, l2=0.0):

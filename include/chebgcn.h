@@ -267,6 +267,15 @@ int chebgcn_contract_bwd_w(const float* stack, const float* dy, float* dW, void*
 int chebgcn_contract_bwd_w_relu(const float* stack, const float* dout, const uint8_t* relu_mask,
                                 float* dW, void* workspace, size_t workspace_bytes, int B, int M,
                                 int Fin, int K, int Fout, chebgcn_stream stream);
+/* chebgcn_contract_bwd_w_relu with the per-vertex bias gradient of the layer (b2relu, models_gcn.py:625-629: dbias[o][m] = sum over
+ * the windows of the gated dout, [Fout][Mp]) in its second launch -- the one that adds the per-workgroup partials of dW: an
+ * atlas-sized layer's backward is a chain of ~5 us launches, and chebgcn_brelu_pool_bwd(dout, NULL, relu_mask, NULL, dbias, ...) was
+ * one of them.  Same sums in the same order as the two calls it replaces.  Served where chebgcn_contract_bwd_w_relu_bias_merged()
+ * returns 1 (few partials -- a small launch -- and the bias reduction's small-graph shape); CHEBGCN_EUNSUPPORTED otherwise. */
+int chebgcn_contract_bwd_w_relu_bias_merged(int B, int M, int Fin, int K, int Fout);
+int chebgcn_contract_bwd_w_relu_bias(const float* stack, const float* dout, const uint8_t* relu_mask,
+                                     float* dW, float* dbias, void* workspace, size_t workspace_bytes,
+                                     int B, int M, int Fin, int K, int Fout, chebgcn_stream stream);
 int chebgcn_contract_bwd_x_relu(const float* dout, const uint8_t* relu_mask, const float* W,
                                 float* gstack, int B, int M, int Fin, int K, int Fout,
                                 chebgcn_stream stream);
@@ -359,6 +368,11 @@ int chebgcn_fc_fwd(const float* x, int64_t ldx, const float* W, const float* bia
 int chebgcn_fc_bwd(const float* x, int64_t ldx, const float* W, const float* g, const float* y, float* dW, float* db,
                    float* dx, int64_t lddx, int B, int I, int O, chebgcn_stream stream);
 
+/* The two scalars a captured training step reads from device memory -- Adam's step size lr_t of this step (models_gcn.py:296:
+ * tf.train.AdamOptimizer's lr * sqrt(1 - b2^t) / (1 - b1^t)) and the read factor of the loss average (models_gcn.py:269-275) --,
+ * written in one launch in front of the graph's replay: dst[0] = v0, dst[1] = v1. */
+int chebgcn_set_scalars(float* dst, float v0, float v1, chebgcn_stream stream);
+
 /* Adam as above (lr_t by value, or read from *lr_t_dev when that is not NULL) which also leaves the sum of squares of the
  * PRE-update variables -- the L2 term of the loss, models_gcn.py:262-266 -- as chebgcn_adam_partials(n) per-workgroup partial
  * sums in sq_partials; and the rest of the loss bookkeeping of a step in one launch:
@@ -369,6 +383,11 @@ int chebgcn_adam_partials(int64_t n);
 int chebgcn_adam_step_sq(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, const float* lr_t_dev,
                          float beta1, float beta2, float eps, float grad_scale, float l2, float* sq_partials,
                          chebgcn_stream stream);
+/* ... over ALL variables of a model in one launch: elements [0, n_reg) as chebgcn_adam_step_sq (L2 term l2 * p in the gradient,
+ * counted in the sum of squares), elements [n_reg, n) -- the biases, which models_gcn.py:262-266 does not regularise -- plain Adam. */
+int chebgcn_adam_step_sq_all(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_reg, float lr_t,
+                             const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale, float l2,
+                             float* sq_partials, chebgcn_stream stream);
 int chebgcn_loss_bookkeeping(const float* cross_entropy, const float* sq_partials, int nparts, float half_reg, float* ema,
                              float decay, float corr, const float* corr_dev, float* loss_out, float* loss_average_out,
                              chebgcn_stream stream);

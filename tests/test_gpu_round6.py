@@ -446,3 +446,42 @@ def test_bias_grad_sum_vs_float64(dev, B, M, F, bias_kind):
     err = float((got - ref).abs().max() / ref.abs().max())
     record_measured('bias_grad_sum[%d,%d,%d,%d]' % (B, M, F, bias_kind), rel=err)
     assert err <= 2e-6, err
+
+
+@pytest.mark.parametrize('B,M,Fin,K,Fout', [(128, 376, 32, 10, 32), (128, 422, 32, 10, 32), (40, 1044, 32, 5, 24), (7, 260, 20, 4, 30)])
+def test_bwd_w_relu_bias_merged_is_the_two_calls(dev, B, M, Fin, K, Fout):
+    """chebgcn_contract_bwd_w_relu_bias (small launches: the per-vertex bias gradient in the launch that adds the weight gradient's
+    partials) against chebgcn_contract_bwd_w_relu + chebgcn_brelu_pool_bwd(dout, NULL, mask, NULL, dbias): dW and dbias bit for
+    bit (the same code and order); not served on a big launch."""
+    from gcn_fmri_decoding_amd import _lib, ops
+    lib = _lib.lib()
+    assert lib.chebgcn_contract_bwd_w_relu_bias_merged(B, M, Fin, K, Fout) == 1
+    assert lib.chebgcn_contract_bwd_w_relu_bias_merged(64, 10466, 32, 5, 32) == 0
+    Mp = ops.plane_stride(M)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B + M + Fin)
+    stack = torch.randn((K, B, Fin, Mp), generator=gen, device=dev)
+    stack[:, :, :, M:] = 0
+    dout = torch.randn((B, Fout, Mp), generator=gen, device=dev)
+    dout[:, :, M:] = float('nan')                            # the pad of a plane carries no gradient: masked out below, never summed
+    mask = torch.randint(0, 16, (B, Fout, Mp // 4), generator=gen, device=dev, dtype=torch.uint8)
+    q0 = M // 4
+    if M % 4:
+        mask[:, :, q0] &= (1 << (M % 4)) - 1                 # (the forward never sets bits of pad vertices)
+    mask[:, :, q0 + (1 if M % 4 else 0):] = 0
+    nws = lib.chebgcn_contract_bwd_w_workspace(B, M, Fin, K, Fout)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    dW1, dW2 = torch.full((Fin * K, Fout), 5.0, device=dev), torch.full((Fin * K, Fout), 6.0, device=dev)
+    db1, db2 = torch.full((Fout, Mp), 5.0, device=dev), torch.full((Fout, Mp), 6.0, device=dev)
+    _lib.check(lib.chebgcn_contract_bwd_w_relu(_P(stack), _P(dout), _P(mask), _P(dW1), _P(ws), nws, B, M, Fin, K, Fout, _stream()), 'bwd_w')
+    assert _lib.last_dispatch().endswith('reduce_partials_small'), _lib.last_dispatch()
+    _lib.check(lib.chebgcn_brelu_pool_bwd(_P(dout), None, _P(mask), None, _P(db1), 2, B, M, Fout, 1, 0, 1, None, 0, _stream()), 'bias')
+    assert _lib.last_dispatch() == 'bias_grad_relu_kernel<CHEBGCN_BIAS_VERTEX,16>', _lib.last_dispatch()
+    _lib.check(lib.chebgcn_contract_bwd_w_relu_bias(_P(stack), _P(dout), _P(mask), _P(dW2), _P(db2), _P(ws), nws, B, M, Fin, K, Fout,
+                                                    _stream()), 'merged')
+    assert _lib.last_dispatch().endswith('reduce_partials_small_bias_kernel'), _lib.last_dispatch()
+    assert torch.equal(dW1, dW2)
+    assert torch.equal(db1[:, :M], db2[:, :M]) and torch.isfinite(db2[:, :M]).all()
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.chebgcn_contract_bwd_w_relu_bias(_P(stack), _P(dout), _P(mask), _P(dW2), _P(db2), _P(ws), nws, 64, 10466, 32, 5,
+                                                        32, _stream()), 'merged big')
