@@ -943,6 +943,11 @@ static BwbPlan bwb_plan(int B, int M, int Fin, int K, int Fout) {
     // between half the CUs and twice the CUs per group.
     long long gx = (2ll * cus / ((long long)p.gy * p.gz) + 127) / 128 * 128;
     gx = std::max<long long>(cus / 2, std::min<long long>(gx, 2ll * cus));
+    // Eight groups and more (64*25 -> 64: ten): every group re-reads dy -- 5.81 GB moved against 4.46 algorithmic with 128 workgroups
+    // per group (EXPERIMENTS 8.9) -- unless all groups walk the same chunks at the same time: 2 * CUs workgroups over the WHOLE
+    // launch, all resident at once, the groups of a chunk range side by side in time (gx per group 128 / 96 / 51 / 48 / 40 / 32:
+    // 1.183 / 1.127 / 1.105 / 1.117 / 1.176 / 1.292 ms)
+    if (p.gy * p.gz >= 8) gx = std::max<long long>(1, 2ll * cus / ((long long)p.gy * p.gz));
     if (const char* e = getenv("CHEBGCN_BWB_GX")) gx = atoll(e) > 0 ? atoll(e) : gx;                 // (experiment knob)
     if (gx > total) gx = total;
     p.gx = gx < 1 ? 1 : (int)gx;
